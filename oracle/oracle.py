@@ -1,0 +1,213 @@
+"""ctypes wrapper around libur5_oracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg. Nothing under
+mujoco_rl_ur5_amd/ imports this module (tests/test_layout.py enforces it).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+RES_SUCCESS, RES_MAX_STEPS, RES_IK_FAIL = 0, 1, 2
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libur5_oracle.so")
+    src = os.path.join(_HERE, "ur5_oracle.cpp")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "libur5_oracle.so"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p
+        L.ur5o_create.restype = vp
+        L.ur5o_create.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int]
+        L.ur5o_destroy.argtypes = [vp]
+        for f in ("ur5o_nq", "ur5o_nv", "ur5o_nu", "ur5o_ncon", "ur5o_nefc", "ur5o_solver_iter_last", "ur5o_last_steps"):
+            getattr(L, f).argtypes = [vp]
+            getattr(L, f).restype = C.c_int
+        for f in ("ur5o_total_steps", "ur5o_solver_iters"):
+            getattr(L, f).argtypes = [vp]
+            getattr(L, f).restype = C.c_long
+        L.ur5o_set_options.argtypes = [vp, C.c_int, C.c_double, C.c_int]
+        L.ur5o_get_state.argtypes = [vp, dp, dp, dp, dp]
+        L.ur5o_set_state.argtypes = [vp, dp, dp, dp, dp]
+        L.ur5o_set_ctrl.argtypes = [vp, dp]
+        L.ur5o_get_ctrl.argtypes = [vp, dp]
+        L.ur5o_forward.argtypes = [vp]
+        L.ur5o_step.argtypes = [vp, C.c_int]
+        L.ur5o_reset.argtypes = [vp, C.c_uint64, C.c_int, C.c_int]
+        L.ur5o_move_group.argtypes = [vp, C.c_uint, dp, C.c_double, C.c_int, ip]
+        L.ur5o_move_group.restype = C.c_int
+        L.ur5o_stay.argtypes = [vp, C.c_double]
+        L.ur5o_ik.argtypes = [vp, dp, dp]
+        L.ur5o_ik.restype = C.c_int
+        L.ur5o_move_ee.argtypes = [vp, dp, C.c_double, C.c_int, ip]
+        L.ur5o_move_ee.restype = C.c_int
+        L.ur5o_open_gripper.argtypes = [vp, C.c_int]
+        L.ur5o_open_gripper.restype = C.c_int
+        L.ur5o_close_gripper.argtypes = [vp, C.c_int]
+        L.ur5o_close_gripper.restype = C.c_int
+        L.ur5o_grasp_attempt.argtypes = [vp, dp, C.c_int, C.c_int, C.c_double, ip, ip]
+        L.ur5o_grasp_attempt.restype = C.c_int
+        L.ur5o_body_xpos.argtypes = [vp, dp]
+        L.ur5o_body_xmat.argtypes = [vp, dp]
+        L.ur5o_mass_matrix.argtypes = [vp, dp]
+        L.ur5o_get_vec.argtypes = [vp, C.c_int, dp]
+        L.ur5o_get_contacts.argtypes = [vp, dp]
+        L.ur5o_get_rows.argtypes = [vp, dp]
+        _LIB = L
+    return _LIB
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+
+
+class Oracle:
+    """One fp64 scene. Mirrors the C functions 1:1; arrays are numpy float64."""
+
+    def __init__(self, model):
+        self.model = model
+        blob = model.to_blob()
+        self._h = lib().ur5o_create(blob, len(blob), model.body_name2id("ee_link"), model.body_name2id("base_link"))
+        if not self._h:
+            raise RuntimeError("oracle rejected the model blob")
+        self.nq, self.nv, self.nu = model.nq, model.nv, model.nu
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().ur5o_destroy(self._h)
+            self._h = None
+
+    def set_options(self, contacts_enabled=1, pid_dt=0.0, solver=0):
+        """solver: 0 = Newton (default), 1 = PGS."""
+        lib().ur5o_set_options(self._h, contacts_enabled, pid_dt, solver)
+
+    def get_state(self):
+        qpos, qvel, warm, pid = np.zeros(self.nq), np.zeros(self.nv), np.zeros(self.nv), np.zeros((self.nu, 4))
+        lib().ur5o_get_state(self._h, _dp(qpos), _dp(qvel), _dp(warm), _dp(pid))
+        return dict(qpos=qpos, qvel=qvel, warmstart=warm, pid=pid)
+
+    def set_state(self, qpos=None, qvel=None, warmstart=None, pid=None):
+        arrs = [None if a is None else np.ascontiguousarray(a, dtype=np.float64) for a in (qpos, qvel, warmstart, pid)]
+        lib().ur5o_set_state(self._h, *[_dp(a) for a in arrs])
+
+    @property
+    def qpos(self):
+        return self.get_state()["qpos"]
+
+    @property
+    def qvel(self):
+        return self.get_state()["qvel"]
+
+    def set_ctrl(self, ctrl):
+        c = np.ascontiguousarray(ctrl, dtype=np.float64)
+        lib().ur5o_set_ctrl(self._h, _dp(c))
+
+    def get_ctrl(self):
+        c = np.zeros(self.nu)
+        lib().ur5o_get_ctrl(self._h, _dp(c))
+        return c
+
+    def forward(self):
+        lib().ur5o_forward(self._h)
+
+    def step(self, n=1):
+        lib().ur5o_step(self._h, n)
+
+    def reset(self, seed, mode=1, settle=True):
+        lib().ur5o_reset(self._h, seed, mode, int(settle))
+
+    def move_group(self, mask, target, tol, max_steps):
+        steps = C.c_int(0)
+        t = None if target is None else np.ascontiguousarray(target, dtype=np.float64)
+        r = lib().ur5o_move_group(self._h, mask, _dp(t), tol, max_steps, C.byref(steps))
+        return r, steps.value
+
+    def stay(self, ms):
+        lib().ur5o_stay(self._h, float(ms))
+
+    def ik(self, xyz):
+        out = np.zeros(5)
+        x = np.ascontiguousarray(xyz, dtype=np.float64)
+        ok = lib().ur5o_ik(self._h, _dp(x), _dp(out))
+        return bool(ok), out
+
+    def move_ee(self, xyz, tol, max_steps):
+        steps = C.c_int(0)
+        x = np.ascontiguousarray(xyz, dtype=np.float64)
+        r = lib().ur5o_move_ee(self._h, _dp(x), tol, max_steps, C.byref(steps))
+        return r, steps.value
+
+    def open_gripper(self, half=False):
+        return lib().ur5o_open_gripper(self._h, int(half))
+
+    def close_gripper(self, max_steps):
+        return lib().ur5o_close_gripper(self._h, max_steps)
+
+    def grasp_attempt(self, xyz, rot=0, check_mode=0, table_height=0.91):
+        ps, pr = np.zeros(12, dtype=np.int32), np.zeros(12, dtype=np.int32)
+        x = np.ascontiguousarray(xyz, dtype=np.float64)
+        r = lib().ur5o_grasp_attempt(self._h, _dp(x), rot, check_mode, table_height,
+                                     ps.ctypes.data_as(C.POINTER(C.c_int)), pr.ctypes.data_as(C.POINTER(C.c_int)))
+        return r, ps, pr
+
+    @property
+    def total_steps(self):
+        return lib().ur5o_total_steps(self._h)
+
+    @property
+    def solver_iters(self):
+        return lib().ur5o_solver_iters(self._h)
+
+    @property
+    def last_steps(self):
+        return lib().ur5o_last_steps(self._h)
+
+    def body_xpos(self):
+        out = np.zeros((self.model.nbody, 3))
+        lib().ur5o_body_xpos(self._h, _dp(out))
+        return out
+
+    def body_xmat(self):
+        out = np.zeros((self.model.nbody, 3, 3))
+        lib().ur5o_body_xmat(self._h, _dp(out))
+        return out
+
+    def mass_matrix(self):
+        out = np.zeros((self.nv, self.nv))
+        lib().ur5o_mass_matrix(self._h, _dp(out))
+        return out
+
+    def vec(self, name):
+        which = ["qfrc_bias", "qfrc_passive", "qfrc_actuator", "qacc_smooth", "qacc", "qfrc_constraint"].index(name)
+        out = np.zeros(self.nv)
+        lib().ur5o_get_vec(self._h, which, _dp(out))
+        return out
+
+    def contacts(self):
+        n = lib().ur5o_ncon(self._h)
+        out = np.zeros((max(n, 1), 12))
+        lib().ur5o_get_contacts(self._h, _dp(out))
+        return out[:n]
+
+    def rows(self):
+        n = lib().ur5o_nefc(self._h)
+        out = np.zeros((max(n, 1), 6))
+        lib().ur5o_get_rows(self._h, _dp(out))
+        return out[:n]
+
+    @property
+    def solver_iter_last(self):
+        return lib().ur5o_solver_iter_last(self._h)
