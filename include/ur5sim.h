@@ -1,0 +1,85 @@
+/* ur5sim.h -- C ABI of the MI355X batched UR5 grasp-scene engine (libur5sim.so).
+ *
+ * This is the drop-in boundary for the reference's hot path. Each entry point replaces, for a
+ * whole batch of N independent scenes, one call the reference makes through mujoco_py / simple_pid / ikpy [3P]
+ * (paths under /root/reference):
+ *
+ *   ur5_create            mujoco_py.load_model_from_path + MjSim + MJ_Controller.__init__/create_lists
+ *                         gym_grasper/controller/MujocoController.py:29-51,136-254 ; gym_grasper/envs/GraspingEnv.py:47-51
+ *   ur5_reset             GraspEnv.reset_model                      GraspingEnv.py:409-477 (IT4 variant :435-463)
+ *   ur5_set_state/get     MujocoEnv.set_state, sim.data.qpos/qvel   GraspingEnv.py:412-466 ; MujocoController.py:319
+ *   ur5_set_ctrl          MJ_Controller.actuate_joint_group         MujocoController.py:256-267
+ *   ur5_step              sim.step()                                MujocoController.py:379,611
+ *   ur5_move_group        MJ_Controller.move_group_to_joint_target  MujocoController.py:269-393
+ *   ur5_stay              MJ_Controller.stay                        MujocoController.py:621-636 (deterministic: 10-step chunks)
+ *   ur5_move_ee           MJ_Controller.move_ee + ik                MujocoController.py:446-517
+ *   ur5_grasp_attempt     GraspEnv.move_and_grasp                   GraspingEnv.py:205-386
+ *   ur5_body_xpos         sim.data.body_xpos[...]                   MujocoController.py:341,488
+ *
+ * Conventions: every function returns 0 on success and a negative code on error (ur5_last_error() has the text). Per-env
+ * soft outcomes use the result codes below, which the Python facade maps back to the reference's strings "success",
+ * "max. steps reached: N", "No valid joint angles received, could not move EE to position.". All array arguments are
+ * caller-owned; "host" pointers are ordinary memory, "dev" pointers are HIP device pointers (e.g. torch data_ptr()).
+ * One handle = one GPU = one HIP stream; a handle is not thread-safe. No torch types cross this boundary.
+ */
+#ifndef UR5SIM_H
+#define UR5SIM_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ur5_sim ur5_sim;
+
+enum { UR5_RES_NONE = -1, UR5_RES_SUCCESS = 0, UR5_RES_MAX_STEPS = 1, UR5_RES_IK_FAIL = 2 };
+enum { UR5_ERR_ARG = -1, UR5_ERR_MODEL = -2, UR5_ERR_DEVICE = -3, UR5_ERR_NOGPU = -4 };
+
+typedef struct ur5_config {
+  int ee_body;           /* model body id of "ee_link" (MujocoController.py:341) */
+  int contacts_enabled;  /* 1 = full physics; 0 = contact-free (tests) */
+  double pid_dt;         /* <= 0: model timestep */
+} ur5_config;
+
+const char* ur5_last_error(void);
+int ur5_create(const void* model_blob, size_t nbytes, int n_env, int device_id, const ur5_config* cfg, ur5_sim** out);
+void ur5_destroy(ur5_sim* h);
+int ur5_num_envs(const ur5_sim* h);
+int ur5_nq(const ur5_sim* h);
+int ur5_nv(const ur5_sim* h);
+int ur5_nu(const ur5_sim* h);
+
+/* seeds[n] (host). mode is informational (object joint type decides the distribution); settle_ms = 1000 in the reference. */
+int ur5_reset(ur5_sim* h, const uint64_t* seeds, int mode, double settle_ms);
+/* host arrays, any may be NULL: qpos[n][nq] qvel[n][nv] warmstart[n][nv] pid[n][nu][4] = target, last_input, last_output, Kp */
+int ur5_set_state(ur5_sim* h, const double* qpos, const double* qvel, const double* warmstart, const double* pid);
+int ur5_get_state(ur5_sim* h, double* qpos, double* qvel, double* warmstart, double* pid);
+int ur5_set_ctrl(ur5_sim* h, const double* ctrl /* [n][nu] host */);
+int ur5_get_ctrl(ur5_sim* h, double* ctrl);
+int ur5_step(ur5_sim* h, int nsteps);
+/* mask[n] bit j = actuator j in the group; target [n][8] in group order (NaN keeps the old target) or NULL. host pointers. */
+int ur5_move_group(ur5_sim* h, const uint32_t* mask, const double* target, const double* tol, const int* max_steps,
+                   int* result, int* steps);
+int ur5_stay(ur5_sim* h, double ms);
+int ur5_move_ee(ur5_sim* h, const double* xyz /* [n][3] */, const double* tol, const int* max_steps, int* result, int* steps);
+/* action[n][4] = world x, y, z, rotation index 0..5 (GraspingEnv.py:40). check_mode 0 = in-tree script, 1 = IT1. */
+int ur5_grasp_attempt(ur5_sim* h, const double* action, int check_mode, double table_height, int* reward,
+                      int* phase_steps /* [n][12] or NULL */, int* phase_result /* [n][12] or NULL */);
+/* same with HIP device pointers: action_dev [n][8] doubles (x y z rot - - - -), reward_dev [n] int32; asynchronous */
+int ur5_grasp_attempt_dev(ur5_sim* h, const double* action_dev, int check_mode, double table_height, int* reward_dev);
+int ur5_sync(ur5_sim* h);
+/* duration of the last launch in ms, from HIP events recorded on the handle's stream around the kernel */
+double ur5_last_launch_ms(ur5_sim* h);
+/* counters[n][4] host: total physics steps, last_movement_steps, status bits, Newton iterations */
+int ur5_get_counters(ur5_sim* h, int64_t* counters);
+/* world positions of the engine's bodies [n][14][3]: 8 robot weld groups (dof order) then the objects */
+int ur5_body_xpos(ur5_sim* h, double* out);
+/* raw device pointer of the [n][192] double state records (layout: csrc/ur5_devmodel.h) */
+void* ur5_state_device_ptr(ur5_sim* h);
+/* test hook: runs forward dynamics once without integrating and dumps internals, [n][2048] doubles host */
+int ur5_forward_debug(ur5_sim* h, double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

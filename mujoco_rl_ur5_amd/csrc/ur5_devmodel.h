@@ -1,0 +1,97 @@
+// ur5_devmodel.h -- the scene description the HIP engine consumes (POD, lives in device global memory).
+//
+// It is the *specialised* view of a CompiledModel blob (mujoco_rl_ur5_amd/model.py): one articulated robot tree whose
+// weld groups each carry exactly one hinge ("cbody" d <-> dof d), plus up to UR5_MAXOBJ free-floating single-geom objects
+// (3 slides + ball, UR5gripper_2_finger.xml:233-279, or a free joint, objects.xml), plus static geoms. ur5_model_build()
+// (ur5sim_host.cpp) derives it and rejects scenes that do not fit, loudly.
+#pragma once
+
+#define UR5_MAXRD 8                                // robot dofs == robot weld groups ("cbodies")
+#define UR5_MAXOBJ 6                               // free objects handled by one wavefront
+#define UR5_MAXB (UR5_MAXRD + UR5_MAXOBJ)          // cbodies
+#define UR5_MAXNV (UR5_MAXRD + 6 * UR5_MAXOBJ)     // 44
+#define UR5_MAXNQ (UR5_MAXRD + 7 * UR5_MAXOBJ)     // 50
+#define UR5_MAXNU 8
+#define UR5_MAXG 48
+#define UR5_MAXDG 16                               // dynamic (robot / object) collidable geoms
+#define UR5_MAXPAIR 384
+#define UR5_MAXCON 32
+#define UR5_MAXSR 32                               // equality + limit rows
+#define UR5_MAXCAND 64
+#define UR5_MAXHV 1024                             // hull vertices of collidable meshes
+
+enum { UR5_GEOM_PLANE = 0, UR5_GEOM_SPHERE = 2, UR5_GEOM_CAPSULE = 3, UR5_GEOM_CYLINDER = 5, UR5_GEOM_BOX = 6, UR5_GEOM_MESH = 7 };
+enum { UR5_KIND_STATIC = 0, UR5_KIND_ROBOT = 1, UR5_KIND_OBJECT = 2 };
+
+// per-env record in HBM: doubles, [env][field]; one wavefront reads its record with coalesced 64-lane loads
+#define UR5_REC_QPOS 0
+#define UR5_REC_QVEL (UR5_REC_QPOS + UR5_MAXNQ)        // 50
+#define UR5_REC_WARM (UR5_REC_QVEL + UR5_MAXNV)        // 94
+#define UR5_REC_CTRL (UR5_REC_WARM + UR5_MAXNV)        // 138
+#define UR5_REC_TARGET (UR5_REC_CTRL + UR5_MAXNU)      // 146
+#define UR5_REC_PIDIN (UR5_REC_TARGET + UR5_MAXNU)     // 154
+#define UR5_REC_PIDOUT (UR5_REC_PIDIN + UR5_MAXNU)     // 162
+#define UR5_REC_KP (UR5_REC_PIDOUT + UR5_MAXNU)        // 170
+#define UR5_REC_MISC (UR5_REC_KP + UR5_MAXNU)          // 178: total_steps, last_steps, time, status, solver_iters, ncon_max, -, -
+#define UR5_REC_STRIDE 192
+
+// status bits (per env, sticky until reset)
+#define UR5_ST_CONTACT_OVERFLOW 1
+#define UR5_ST_NAN 2
+#define UR5_ST_ROW_OVERFLOW 4
+
+struct Ur5DevModel {
+  int nrd, nobj, nv, nq, nu, ngeom, npair, neq, ndg, iterations, ee_cbody, pad0;
+  // ---- robot weld groups (cbody d == dof d)
+  int rd_parent[UR5_MAXRD];
+  unsigned rd_anc[UR5_MAXRD];   // ancestors incl. self (bit e set: dof e moves cbody d)
+  unsigned rd_desc[UR5_MAXRD];  // descendants incl. self
+  int rd_limited[UR5_MAXRD];
+  double rd_pos[UR5_MAXRD][3], rd_quat[UR5_MAXRD][4];  // weld-root frame in the parent cbody frame (world for the root)
+  double rd_jpos[UR5_MAXRD][3], rd_jaxis[UR5_MAXRD][3];
+  double rd_mass[UR5_MAXRD], rd_ipos[UR5_MAXRD][3], rd_inertia[UR5_MAXRD][6];  // welded children folded in
+  double rd_armature[UR5_MAXRD], rd_damping[UR5_MAXRD], rd_lo[UR5_MAXRD], rd_hi[UR5_MAXRD], rd_invweight[UR5_MAXRD], rd_qpos0[UR5_MAXRD];
+  double ref_point[3];
+  double ee_pos[3], ee_mat[9];  // ee_link frame inside its cbody (for IK / move_ee)
+  // ---- objects
+  int obj_kind[UR5_MAXOBJ];     // 0 = 3 slides + ball, 1 = free joint
+  int obj_limited[UR5_MAXOBJ][3];
+  double obj_pos0[UR5_MAXOBJ][3];
+  double obj_mass[UR5_MAXOBJ], obj_inertia[UR5_MAXOBJ][3];
+  double obj_arm[UR5_MAXOBJ][2], obj_damp[UR5_MAXOBJ][2];     // [lin, rot]
+  double obj_invweight[UR5_MAXOBJ][2];                         // dof_invweight0 lin / rot
+  double obj_lo[UR5_MAXOBJ][3], obj_hi[UR5_MAXOBJ][3];
+  // ---- geoms
+  int g_type[UR5_MAXG], g_kind[UR5_MAXG], g_owner[UR5_MAXG], g_condim[UR5_MAXG], g_vadr[UR5_MAXG], g_vnum[UR5_MAXG], g_dg[UR5_MAXG];
+  double g_size[UR5_MAXG][3], g_pos[UR5_MAXG][3], g_mat[UR5_MAXG][9], g_rbound[UR5_MAXG], g_margin[UR5_MAXG];
+  double g_friction[UR5_MAXG][3], g_solref[UR5_MAXG][2], g_solimp[UR5_MAXG][5], g_invw[UR5_MAXG][2], g_center[UR5_MAXG][3];
+  int dg_geom[UR5_MAXDG];
+  int pair_g1[UR5_MAXPAIR], pair_g2[UR5_MAXPAIR];
+  double hullvert[UR5_MAXHV][3];
+  // ---- joint equality (robot dofs), actuators, options
+  int eq_d1[2], eq_d2[2];
+  double eq_poly[2][5], eq_solref[2][2], eq_solimp[2][5];
+  int act_dof[UR5_MAXNU];
+  double act_gear[UR5_MAXNU], act_lo[UR5_MAXNU], act_hi[UR5_MAXNU];
+  double pid_kd[UR5_MAXNU], pid_lo[UR5_MAXNU], pid_hi[UR5_MAXNU];
+  double timestep, tolerance, impratio, gravity[3], jnt_solref[2], jnt_solimp[5], meaninertia;
+};
+
+// run-time parameters of one launch (wave-uniform unless per-env arrays are given)
+enum { UR5_OP_MOVE = 0, UR5_OP_STAY = 1, UR5_OP_MOVE_EE = 2, UR5_OP_GRASP = 3, UR5_OP_STEP = 4, UR5_OP_FORWARD = 5 };
+struct Ur5Launch {
+  int op, n_env, contacts_enabled, check_mode;
+  double pid_dt, table_height;
+  // per-env inputs (device pointers, may be null depending on op)
+  const unsigned* group_mask;   // [n]
+  const double* target;         // [n][8]  (MOVE: group targets in group order; NaN = keep)  / xyz for MOVE_EE, GRASP ([n][8]: x y z rot)
+  const double* tol;            // [n]
+  const int* max_steps;         // [n]   (STAY: number of 10-step chunks; STEP: number of steps)
+  // per-env outputs
+  int* result;                  // [n]
+  int* steps;                   // [n]
+  int* phase_steps;             // [n][12] (GRASP)
+  int* phase_result;            // [n][12]
+  double* debug;                // optional [n][UR5_DEBUG_STRIDE] introspection dump (FORWARD)
+};
+#define UR5_DEBUG_STRIDE 2048

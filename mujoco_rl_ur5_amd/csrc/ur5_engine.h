@@ -1,0 +1,1489 @@
+// ur5_engine.h -- one-wavefront-per-env UR5 grasp-scene engine (device code shared by every kernel).
+//
+// Replaces, for a whole batch of scenes, what the reference does one scene at a time through mujoco_py [3P]:
+//   sim.step()                      gym_grasper/controller/MujocoController.py:379  -> Engine::step()
+//   PID.__call__ / ctrl writes      MujocoController.py:325-327                     -> Engine::pid_and_deltas()
+//   move_group_to_joint_target      MujocoController.py:269-393                     -> Engine::move_group()
+//   stay / open / close / grasp     MujocoController.py:408-444, 621-636            -> Engine::stay() ...
+//   move_ee / ik                    MujocoController.py:446-517                     -> Engine::move_ee(), Engine::ik()
+//   move_and_grasp                  gym_grasper/envs/GraspingEnv.py:205-386         -> Engine::grasp_attempt()
+//
+// Execution model: ONE 64-lane wavefront owns ONE scene. All per-scene state lives in LDS (struct Lds) for the whole
+// launch -- thousands of 2 ms physics steps -- and is read/written from HBM once. The code is a sequence of *phases*:
+// PAR(i, n) distributes n independent items over the 64 lanes, SYNC() separates phases, WAVE_SUM/WAVE_MAX combine lane
+// partials. Statements outside PAR are wave-uniform (every lane computes the same value from LDS).
+//
+// Contacts act on bodies through wrenches and bodies map twists to dofs ("twist space"): a contact never sees more than
+// two 6-vectors, the robot's 8x8 block and each object's 6x6 block of the Newton Hessian are assembled from per-body
+// 6x6 accumulators, and only contacts between two movable bodies add coupling blocks. Solver = MuJoCo's default
+// Newton on the primal with exact line search [3P], same as oracle/ur5_oracle.cpp solve_newton().
+//
+// -DUR5_EMUL compiles the same source for the host with lanes run sequentially; tests use that build to check the kernel
+// logic without a GPU. It is never loaded by the package (see DESIGN.md "Lane emulation").
+#pragma once
+#include <math.h>
+#include "ur5_devmodel.h"
+
+#ifdef UR5_EMUL
+#define UR5_FN inline
+#define UR5_BIG inline
+#define PAR(i, n) for (int i = 0; i < (n); ++i)
+#define SYNC() ((void)0)
+#define WAVE_SUM(v) (v)
+#define WAVE_MAX(v) (v)
+#define UR5_LANE 0
+#else
+#include <hip/hip_runtime.h>
+#define UR5_FN __device__ __forceinline__
+#define UR5_BIG __device__ __noinline__   // phase-sized routines: one copy in the code object, called from the script
+#define PAR(i, n) for (int i = (int)threadIdx.x; i < (n); i += 64)
+#define SYNC() __syncthreads()
+#define UR5_LANE ((int)threadIdx.x)
+template <class T> __device__ __forceinline__ T ur5_wave_sum(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <class T> __device__ __forceinline__ T ur5_wave_max(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { T w = __shfl_xor(v, o, 64); v = w > v ? w : v; }
+  return v;
+}
+#define WAVE_SUM(v) ur5_wave_sum(v)
+#define WAVE_MAX(v) ur5_wave_max(v)
+#endif
+
+namespace ur5 {
+
+enum { RES_NONE = -1, RES_SUCCESS = 0, RES_MAX_STEPS = 1, RES_IK_FAIL = 2 };
+constexpr int NB = 6;  // base directions per contact: normal, 2 tangents, torsion, 2 rolling
+
+// ---------------------------------------------------------------------------------------------- small maths
+template <class T> struct V3 {
+  T x, y, z;
+  UR5_FN V3() : x(0), y(0), z(0) {}
+  UR5_FN V3(T a, T b, T c) : x(a), y(b), z(c) {}
+  template <class U> UR5_FN explicit V3(const U* p) : x((T)p[0]), y((T)p[1]), z((T)p[2]) {}
+  UR5_FN T operator[](int i) const { return i == 0 ? x : (i == 1 ? y : z); }
+  UR5_FN void set(int i, T v) { if (i == 0) x = v; else if (i == 1) y = v; else z = v; }
+  template <class U> UR5_FN void store(U* p) const { p[0] = x; p[1] = y; p[2] = z; }
+};
+template <class T> UR5_FN V3<T> operator+(V3<T> a, V3<T> b) { return V3<T>(a.x + b.x, a.y + b.y, a.z + b.z); }
+template <class T> UR5_FN V3<T> operator-(V3<T> a, V3<T> b) { return V3<T>(a.x - b.x, a.y - b.y, a.z - b.z); }
+template <class T> UR5_FN V3<T> operator-(V3<T> a) { return V3<T>(-a.x, -a.y, -a.z); }
+template <class T> UR5_FN V3<T> operator*(V3<T> a, T s) { return V3<T>(a.x * s, a.y * s, a.z * s); }
+template <class T> UR5_FN T dot(V3<T> a, V3<T> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <class T> UR5_FN V3<T> cross(V3<T> a, V3<T> b) { return V3<T>(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+template <class T> UR5_FN T norm(V3<T> a) { return sqrt(dot(a, a)); }
+template <class T> UR5_FN V3<T> normalized(V3<T> a) {
+  T n = norm(a);
+  return n > (T)1e-300 ? a * ((T)1 / n) : V3<T>(1, 0, 0);
+}
+template <class T> struct Q4 { T w, x, y, z; };
+template <class T> UR5_FN Q4<T> qmul(Q4<T> a, Q4<T> b) {
+  return Q4<T>{a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+               a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x, a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
+}
+template <class T> UR5_FN Q4<T> qnormalize(Q4<T> q) {
+  T n = sqrt(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+  if (n < (T)1e-300) return Q4<T>{1, 0, 0, 0};
+  T s = (T)1 / n;
+  return Q4<T>{q.w * s, q.x * s, q.y * s, q.z * s};
+}
+template <class T> struct M3 {  // row-major
+  T m[9];
+  UR5_FN V3<T> col(int j) const { return V3<T>(m[j], m[3 + j], m[6 + j]); }
+  UR5_FN V3<T> row(int i) const { return V3<T>(m[3 * i], m[3 * i + 1], m[3 * i + 2]); }
+  template <class U> UR5_FN void load(const U* p) { for (int i = 0; i < 9; i++) m[i] = (T)p[i]; }
+  template <class U> UR5_FN void store(U* p) const { for (int i = 0; i < 9; i++) p[i] = m[i]; }
+};
+template <class T> UR5_FN M3<T> qmat(Q4<T> q) {
+  T w = q.w, x = q.x, y = q.y, z = q.z;
+  M3<T> r;
+  r.m[0] = w * w + x * x - y * y - z * z; r.m[1] = 2 * (x * y - w * z); r.m[2] = 2 * (x * z + w * y);
+  r.m[3] = 2 * (x * y + w * z); r.m[4] = w * w - x * x + y * y - z * z; r.m[5] = 2 * (y * z - w * x);
+  r.m[6] = 2 * (x * z - w * y); r.m[7] = 2 * (y * z + w * x); r.m[8] = w * w - x * x - y * y + z * z;
+  return r;
+}
+template <class T> UR5_FN V3<T> mul(const M3<T>& a, V3<T> v) { return V3<T>(dot(a.row(0), v), dot(a.row(1), v), dot(a.row(2), v)); }
+template <class T> UR5_FN V3<T> mulT(const M3<T>& a, V3<T> v) { return V3<T>(dot(a.col(0), v), dot(a.col(1), v), dot(a.col(2), v)); }
+template <class T> UR5_FN M3<T> matmul(const M3<T>& a, const M3<T>& b) {
+  M3<T> r;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) r.m[3 * i + j] = a.m[3 * i] * b.m[j] + a.m[3 * i + 1] * b.m[3 + j] + a.m[3 * i + 2] * b.m[6 + j];
+  return r;
+}
+template <class T> UR5_FN T clampv(T v, T lo, T hi) { return v < lo ? lo : (v > hi ? hi : v); }
+template <class T> UR5_FN T maxv(T a, T b) { return a > b ? a : b; }
+template <class T> UR5_FN T minv(T a, T b) { return a < b ? a : b; }
+
+// index of (i, j), i >= j, in a packed symmetric 6x6 (21 entries, row-major lower)
+UR5_FN int sym6(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
+
+// ---------------------------------------------------------------------------------------------- LDS image of one scene
+template <class real, int NV_> struct Lds {
+  static constexpr int NV = NV_;
+  static constexpr int LD = NV_ + 1;                 // padded leading dimension of H (odd multiple of the bank width)
+  real rec[UR5_REC_STRIDE];                          // persistent state, same layout as the HBM record
+  // kinematics
+  real jq[UR5_MAXRD][4];
+  real bpos[UR5_MAXB][3], bmat[UR5_MAXB][9], bquat[UR5_MAXRD][4];
+  real anchor[UR5_MAXRD][3], axis[UR5_MAXRD][3], cdof[UR5_MAXRD][6], cdd[UR5_MAXRD][6];
+  real cinert[UR5_MAXRD][10], buf[UR5_MAXRD][6], cfrc[UR5_MAXRD][6];
+  real cvel[UR5_MAXB][6];                            // body twist velocity [rot; lin] about the body's reference point
+  real Mr[UR5_MAXRD][UR5_MAXRD + 1], Lr[UR5_MAXRD][UR5_MAXRD + 1], Ld[UR5_MAXRD][UR5_MAXRD + 1];
+  real Mobj[6 * UR5_MAXOBJ];
+  real dgpos[UR5_MAXDG][3], dgmat[UR5_MAXDG][9];
+  // dynamics vectors (dof space)
+  real fs[NV_], as[NV_], x[NV_], Ma[NV_], grad[NV_], search[NV_], Mv[NV_], tmpv[NV_ + 4];
+  // contacts
+  int ncon, nsr, ncand, ncouple;
+  int cA[UR5_MAXCON], cB[UR5_MAXCON], cdim[UR5_MAXCON], cg1[UR5_MAXCON], cg2[UR5_MAXCON];
+  int cand[UR5_MAXCAND], couple[UR5_MAXCON];
+  real cpos[UR5_MAXCON][3], cframe[UR5_MAXCON][9], cdist[UR5_MAXCON], cfri[UR5_MAXCON][3];
+  real cD[UR5_MAXCON], cbv[UR5_MAXCON], ckr[UR5_MAXCON];
+  real cvb[UR5_MAXCON][NB], ce[UR5_MAXCON][NB], cde[UR5_MAXCON][NB], cfb[UR5_MAXCON][NB], cW[UR5_MAXCON][2 * NB - 1];
+  // special rows (joint equality, joint limits): jar = c1 x[d1] + c2 x[d2] - aref
+  int sr_d1[UR5_MAXSR], sr_d2[UR5_MAXSR], sr_uni[UR5_MAXSR];
+  real sr_c1[UR5_MAXSR], sr_c2[UR5_MAXSR], sr_D[UR5_MAXSR], sr_aref[UR5_MAXSR], sr_jar[UR5_MAXSR], sr_jv[UR5_MAXSR];
+  // body accumulators (twist space)
+  real tw[UR5_MAXB][6], WB[UR5_MAXB][6], G[UR5_MAXB][21];
+  real H[NV_ * (NV_ + 1)];
+  real scal[16];
+  int status, solver_iters, ncon_max;
+};
+
+// ---------------------------------------------------------------------------------------------- the engine
+template <class real, int NV_> struct Engine {
+  typedef Lds<real, NV_> L;
+  typedef V3<real> v3;
+  typedef M3<real> m3;
+  typedef Q4<real> q4;
+  L& S;
+  const Ur5DevModel& M;
+  real pid_dt;
+  int contacts_enabled;
+  int last_steps;
+  long total_steps;
+
+  UR5_FN Engine(L& s, const Ur5DevModel& m, real dt, int con) : S(s), M(m), pid_dt(dt), contacts_enabled(con), last_steps(0), total_steps(0) {}
+
+  // views into the persistent record
+  UR5_FN real* qpos() { return S.rec + UR5_REC_QPOS; }
+  UR5_FN real* qvel() { return S.rec + UR5_REC_QVEL; }
+  UR5_FN real* warm() { return S.rec + UR5_REC_WARM; }
+  UR5_FN real* ctrl() { return S.rec + UR5_REC_CTRL; }
+  UR5_FN real* target() { return S.rec + UR5_REC_TARGET; }
+  UR5_FN real* pid_in() { return S.rec + UR5_REC_PIDIN; }
+  UR5_FN real* pid_out() { return S.rec + UR5_REC_PIDOUT; }
+  UR5_FN real* kp() { return S.rec + UR5_REC_KP; }
+  UR5_FN int nb() const { return M.nrd + M.nobj; }
+
+  UR5_FN void load(const double* rec) {
+    PAR(i, UR5_REC_STRIDE) S.rec[i] = (real)rec[i];
+    if (UR5_LANE == 0) { S.status = 0; S.solver_iters = 0; S.ncon_max = 0; S.ncon = 0; S.nsr = 0; }
+    SYNC();
+    S.status = (int)S.rec[UR5_REC_MISC + 3];
+  }
+  UR5_FN void save(double* rec) {
+    SYNC();
+    if (UR5_LANE == 0) {
+      S.rec[UR5_REC_MISC + 0] += (real)total_steps;
+      S.rec[UR5_REC_MISC + 1] = (real)last_steps;
+      S.rec[UR5_REC_MISC + 3] = (real)S.status;
+      S.rec[UR5_REC_MISC + 4] += (real)S.solver_iters;
+      S.rec[UR5_REC_MISC + 5] = maxv(S.rec[UR5_REC_MISC + 5], (real)S.ncon_max);
+    }
+    SYNC();
+    PAR(i, UR5_REC_STRIDE) rec[i] = (double)S.rec[i];
+  }
+
+  // ------------------------------------------------------------------ kinematics (mj_kinematics + mj_comPos [3P])
+  UR5_BIG void kinematics() {
+    PAR(d, M.nrd) {
+      real a = (real)0.5 * (qpos()[d] - (real)M.rd_qpos0[d]);
+      real s = sin(a), c = cos(a);
+      S.jq[d][0] = c; S.jq[d][1] = (real)M.rd_jaxis[d][0] * s; S.jq[d][2] = (real)M.rd_jaxis[d][1] * s; S.jq[d][3] = (real)M.rd_jaxis[d][2] * s;
+    }
+    PAR(k, M.nobj) {
+      int b = M.nrd + k, qa = M.nrd + 7 * k;
+      v3 p(qpos()[qa], qpos()[qa + 1], qpos()[qa + 2]);
+      if (M.obj_kind[k] == 0) p = p + v3(M.obj_pos0[k]);
+      q4 q = qnormalize(q4{qpos()[qa + 3], qpos()[qa + 4], qpos()[qa + 5], qpos()[qa + 6]});
+      p.store(S.bpos[b]);
+      qmat(q).store(S.bmat[b]);
+    }
+    SYNC();
+    // the robot chain is sequential: every lane walks it redundantly (wave-uniform), results land in LDS
+    for (int d = 0; d < M.nrd; d++) {
+      int p = M.rd_parent[d];
+      v3 ppos;
+      q4 pq{1, 0, 0, 0};
+      if (p >= 0) { ppos = v3(S.bpos[p]); pq = q4{S.bquat[p][0], S.bquat[p][1], S.bquat[p][2], S.bquat[p][3]}; }
+      v3 pos = ppos + mul(qmat(pq), v3(M.rd_pos[d]));
+      q4 quat = qmul(pq, q4{(real)M.rd_quat[d][0], (real)M.rd_quat[d][1], (real)M.rd_quat[d][2], (real)M.rd_quat[d][3]});
+      m3 Rb = qmat(quat);
+      v3 anc = pos + mul(Rb, v3(M.rd_jpos[d]));
+      v3 ax = mul(Rb, v3(M.rd_jaxis[d]));
+      quat = qnormalize(qmul(quat, q4{S.jq[d][0], S.jq[d][1], S.jq[d][2], S.jq[d][3]}));
+      m3 R = qmat(quat);
+      pos = anc - mul(R, v3(M.rd_jpos[d]));
+      pos.store(S.bpos[d]); R.store(S.bmat[d]); anc.store(S.anchor[d]); ax.store(S.axis[d]);
+      S.bquat[d][0] = quat.w; S.bquat[d][1] = quat.x; S.bquat[d][2] = quat.y; S.bquat[d][3] = quat.z;
+      SYNC();
+    }
+    v3 o(M.ref_point);
+    PAR(d, M.nrd) {
+      v3 ax(S.axis[d]);
+      v3 lin = cross(ax, o - v3(S.anchor[d]));
+      ax.store(S.cdof[d]); lin.store(S.cdof[d] + 3);
+      // spatial inertia of the weld group about o, world axes: I(6) h(3) m
+      m3 R; R.load(S.bmat[d]);
+      const double* bi = M.rd_inertia[d];
+      m3 Ib;
+      Ib.m[0] = (real)bi[0]; Ib.m[4] = (real)bi[1]; Ib.m[8] = (real)bi[2];
+      Ib.m[1] = Ib.m[3] = (real)bi[3]; Ib.m[2] = Ib.m[6] = (real)bi[4]; Ib.m[5] = Ib.m[7] = (real)bi[5];
+      m3 Rt;
+      for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Rt.m[3 * i + j] = R.m[3 * j + i];
+      m3 Iw = matmul(matmul(R, Ib), Rt);
+      real m = (real)M.rd_mass[d];
+      v3 c = v3(S.bpos[d]) + mul(R, v3(M.rd_ipos[d])) - o;
+      real* ci = S.cinert[d];
+      ci[0] = Iw.m[0] + m * (c.y * c.y + c.z * c.z); ci[1] = Iw.m[4] + m * (c.x * c.x + c.z * c.z); ci[2] = Iw.m[8] + m * (c.x * c.x + c.y * c.y);
+      ci[3] = Iw.m[1] - m * c.x * c.y; ci[4] = Iw.m[2] - m * c.x * c.z; ci[5] = Iw.m[5] - m * c.y * c.z;
+      ci[6] = m * c.x; ci[7] = m * c.y; ci[8] = m * c.z; ci[9] = m;
+    }
+    PAR(i, M.ndg) {
+      int g = M.dg_geom[i], ow = M.g_owner[g];
+      if (M.g_kind[g] == UR5_KIND_ROBOT) {
+        m3 R; R.load(S.bmat[ow]);
+        (v3(S.bpos[ow]) + mul(R, v3(M.g_pos[g]))).store(S.dgpos[i]);
+        m3 G; G.load(M.g_mat[g]);
+        matmul(R, G).store(S.dgmat[i]);
+      } else {
+        int b = M.nrd + ow;
+        for (int k = 0; k < 3; k++) S.dgpos[i][k] = S.bpos[b][k];
+        for (int k = 0; k < 9; k++) S.dgmat[i][k] = S.bmat[b][k];
+      }
+    }
+    SYNC();
+  }
+
+  // inertia (10 numbers: I6 h3 m) times spatial vector [rot; lin] -> [rot; lin]
+  UR5_FN static void mul_inert(const real* ci, const real* v, real* out) {
+    v3 w(v), l(v + 3), h(ci + 6);
+    v3 r(ci[0] * w.x + ci[3] * w.y + ci[4] * w.z, ci[3] * w.x + ci[1] * w.y + ci[5] * w.z, ci[4] * w.x + ci[5] * w.y + ci[2] * w.z);
+    r = r + cross(h, l);
+    v3 f = l * ci[9] - cross(h, w);
+    r.store(out); f.store(out + 3);
+  }
+
+  // ------------------------------------------------------------------ CRBA (robot block) + object diagonals + factors
+  UR5_BIG void crb_and_factor() {
+    PAR(d, M.nrd) {
+      real crb[10];
+      for (int i = 0; i < 10; i++) crb[i] = 0;
+      for (int b = 0; b < M.nrd; b++) if (M.rd_desc[d] >> b & 1u) for (int i = 0; i < 10; i++) crb[i] += S.cinert[b][i];
+      mul_inert(crb, S.cdof[d], S.buf[d]);
+    }
+    PAR(i, 6 * M.nobj) {
+      int k = i / 6, j = i % 6;
+      S.Mobj[i] = j < 3 ? (real)(M.obj_mass[k] + M.obj_arm[k][0]) : (real)(M.obj_inertia[k][j - 3] + M.obj_arm[k][1]);
+    }
+    SYNC();
+    PAR(idx, M.nrd * M.nrd) {
+      int d = idx / M.nrd, e = idx % M.nrd;
+      if (e <= d) {
+        real v = 0;
+        if (M.rd_anc[d] >> e & 1u) for (int i = 0; i < 6; i++) v += S.cdof[e][i] * S.buf[d][i];
+        if (e == d) v += (real)M.rd_armature[d];
+        S.Mr[d][e] = v; S.Mr[e][d] = v;
+      }
+    }
+    SYNC();
+    real h = (real)M.timestep;
+    PAR(idx, M.nrd * M.nrd) {
+      int d = idx / M.nrd, e = idx % M.nrd;
+      S.Lr[d][e] = S.Mr[d][e];
+      S.Ld[d][e] = S.Mr[d][e] + (d == e ? h * (real)M.rd_damping[d] : (real)0);
+    }
+    SYNC();
+    cholesky(&S.Lr[0][0], M.nrd, UR5_MAXRD + 1);
+    cholesky(&S.Ld[0][0], M.nrd, UR5_MAXRD + 1);
+  }
+
+  // in-place lower Cholesky of the n x n matrix A (leading dimension ld) -- left-looking, one column per step
+  UR5_BIG void cholesky(real* A, int n, int ld) {
+    for (int j = 0; j < n; j++) {
+      PAR(ii, n - j) {
+        int i = j + ii;
+        real s = A[i * ld + j];
+        for (int k = 0; k < j; k++) s -= A[i * ld + k] * A[j * ld + k];
+        S.tmpv[i] = s;
+      }
+      SYNC();
+      real d = S.tmpv[j];
+      d = sqrt(d < (real)1e-15 ? (real)1e-15 : d);
+      real inv = (real)1 / d;
+      PAR(ii, n - j) {
+        int i = j + ii;
+        A[i * ld + j] = (i == j) ? d : S.tmpv[i] * inv;
+      }
+      SYNC();
+    }
+  }
+  // b <- (L L^T)^-1 b
+  UR5_BIG void chol_solve(const real* A, int n, int ld, real* b) {
+    for (int k = 0; k < n; k++) {
+      real yk = b[k] / A[k * ld + k];
+      SYNC();
+      PAR(ii, n - k) {
+        int i = k + ii;
+        if (i == k) b[k] = yk; else b[i] -= A[i * ld + k] * yk;
+      }
+      SYNC();
+    }
+    for (int k = n - 1; k >= 0; k--) {
+      real xk = b[k] / A[k * ld + k];
+      SYNC();
+      PAR(i, k + 1) {
+        if (i == k) b[k] = xk; else b[i] -= A[k * ld + i] * xk;
+      }
+      SYNC();
+    }
+  }
+
+  // ------------------------------------------------------------------ velocity stage: body twists, bias, passive (mj_comVel + mj_rne)
+  UR5_BIG void velocity_stage() {
+    PAR(b, M.nrd) {
+      real v[6] = {0, 0, 0, 0, 0, 0};
+      for (int e = 0; e < M.nrd; e++) if (M.rd_anc[b] >> e & 1u) { real q = qvel()[e]; for (int i = 0; i < 6; i++) v[i] += S.cdof[e][i] * q; }
+      for (int i = 0; i < 6; i++) S.cvel[b][i] = v[i];
+      // cdof_dot = crossMotion(cvel, cdof): own joint's contribution to cvel is parallel to cdof and drops out
+      v3 w(v), l(v + 3), cr(S.cdof[b]), cl(S.cdof[b] + 3);
+      cross(w, cr).store(S.cdd[b]);
+      (cross(w, cl) + cross(l, cr)).store(S.cdd[b] + 3);
+    }
+    PAR(k, M.nobj) {
+      int b = M.nrd + k, va = M.nrd + 6 * k;
+      m3 R; R.load(S.bmat[b]);
+      mul(R, v3(qvel()[va + 3], qvel()[va + 4], qvel()[va + 5])).store(S.cvel[b]);
+      v3(qvel()[va], qvel()[va + 1], qvel()[va + 2]).store(S.cvel[b] + 3);
+    }
+    SYNC();
+    PAR(b, M.nrd) {
+      real a[6] = {0, 0, 0, -(real)M.gravity[0], -(real)M.gravity[1], -(real)M.gravity[2]};
+      for (int e = 0; e < M.nrd; e++) if (M.rd_anc[b] >> e & 1u) { real q = qvel()[e]; for (int i = 0; i < 6; i++) a[i] += S.cdd[e][i] * q; }
+      real f[6], mv[6];
+      mul_inert(S.cinert[b], a, f);
+      mul_inert(S.cinert[b], S.cvel[b], mv);
+      v3 w(S.cvel[b]), l(S.cvel[b] + 3), mr(mv), ml(mv + 3);
+      v3 fr = v3(f) + cross(w, mr) + cross(l, ml), fl = v3(f + 3) + cross(w, ml);
+      fr.store(S.cfrc[b]); fl.store(S.cfrc[b] + 3);
+    }
+    SYNC();
+    PAR(d, M.nrd) {
+      real bias = 0;
+      for (int b = 0; b < M.nrd; b++) if (M.rd_desc[d] >> b & 1u) for (int i = 0; i < 6; i++) bias += S.cdof[d][i] * S.cfrc[b][i];
+      S.fs[d] = -(real)M.rd_damping[d] * qvel()[d] - bias;
+    }
+    PAR(k, M.nobj) {
+      int va = M.nrd + 6 * k;
+      real m = (real)M.obj_mass[k];
+      for (int j = 0; j < 3; j++) S.fs[va + j] = -(real)M.obj_damp[k][0] * qvel()[va + j] + m * (real)M.gravity[j];
+      v3 w(qvel()[va + 3], qvel()[va + 4], qvel()[va + 5]);
+      v3 Iw(w.x * (real)M.obj_inertia[k][0], w.y * (real)M.obj_inertia[k][1], w.z * (real)M.obj_inertia[k][2]);
+      v3 gy = cross(w, Iw);
+      for (int j = 0; j < 3; j++) S.fs[va + 3 + j] = -(real)M.obj_damp[k][1] * w[j] - gy[j];
+    }
+    SYNC();
+    PAR(a, M.nu) {  // mj_fwdActuation: clamp to ctrlrange, gear
+      real c = clampv(ctrl()[a], (real)M.act_lo[a], (real)M.act_hi[a]);
+      S.fs[M.act_dof[a]] += (real)M.act_gear[a] * c;
+    }
+    SYNC();
+    PAR(i, M.nv) S.as[i] = i < M.nrd ? S.fs[i] : S.fs[i] / S.Mobj[i - M.nrd];
+    SYNC();
+    chol_solve(&S.Lr[0][0], M.nrd, UR5_MAXRD + 1, S.as);
+  }
+
+  // ------------------------------------------------------------------ collision
+  struct GeomPose { v3 pos; m3 mat; };
+  UR5_FN GeomPose geom_pose(int g) const {
+    GeomPose r;
+    int dg = M.g_dg[g];
+    if (dg < 0) { r.pos = v3(M.g_pos[g]); r.mat.load(M.g_mat[g]); }
+    else { r.pos = v3(S.dgpos[dg]); r.mat.load(S.dgmat[dg]); }
+    return r;
+  }
+  UR5_FN static real dist_point_box(v3 p, const GeomPose& B, v3 s) {
+    v3 l = mulT(B.mat, p - B.pos);
+    v3 d(maxv(fabs(l.x) - s.x, (real)0), maxv(fabs(l.y) - s.y, (real)0), maxv(fabs(l.z) - s.z, (real)0));
+    return norm(d);
+  }
+  struct Shape { int type, vadr, vnum; v3 pos, size, center; m3 mat; real margin; };
+  UR5_FN Shape make_shape(int g, real margin) const {
+    Shape s;
+    GeomPose P = geom_pose(g);
+    s.type = M.g_type[g]; s.pos = P.pos; s.mat = P.mat; s.size = v3(M.g_size[g]);
+    s.vadr = M.g_vadr[g]; s.vnum = M.g_vnum[g];
+    s.center = P.pos + mul(P.mat, v3(M.g_center[g]));
+    s.margin = margin;
+    return s;
+  }
+  UR5_BIG v3 support(const Shape& s, v3 dir) const {
+    v3 d = mulT(s.mat, dir), l;
+    if (s.type == UR5_GEOM_SPHERE) l = d * s.size.x;
+    else if (s.type == UR5_GEOM_BOX) l = v3(d.x >= 0 ? s.size.x : -s.size.x, d.y >= 0 ? s.size.y : -s.size.y, d.z >= 0 ? s.size.z : -s.size.z);
+    else if (s.type == UR5_GEOM_CAPSULE) l = d * s.size.x + v3(0, 0, d.z >= 0 ? s.size.y : -s.size.y);
+    else if (s.type == UR5_GEOM_CYLINDER) {
+      real n = sqrt(d.x * d.x + d.y * d.y);
+      l = n > (real)1e-12 ? v3(d.x / n * s.size.x, d.y / n * s.size.x, 0) : v3();
+      l.z = d.z >= 0 ? s.size.y : -s.size.y;
+    } else if (s.type == UR5_GEOM_MESH) {
+      real best = -1e300;
+      int bi = 0;
+      for (int i = 0; i < s.vnum; i++) {
+        const double* p = M.hullvert[s.vadr + i];
+        real v = (real)p[0] * d.x + (real)p[1] * d.y + (real)p[2] * d.z;
+        if (v > best) { best = v; bi = i; }
+      }
+      l = v3(M.hullvert[s.vadr + bi]);
+    }
+    return s.pos + mul(s.mat, l) + dir * ((real)0.5 * s.margin);
+  }
+  struct MV { v3 v, a, b; };
+  UR5_FN MV msupport(const Shape& A, const Shape& B, v3 dir) const {
+    MV r;
+    r.a = support(A, dir); r.b = support(B, -dir); r.v = r.a - r.b;
+    return r;
+  }
+  // Minkowski portal refinement; same scheme, tolerances and result definition as oracle mpr_penetration()
+  UR5_BIG bool mpr(const Shape& A, const Shape& B, real* depth, v3* dir_out, v3* pos_out) const {
+    const real tol = (real)1e-6;
+    const int maxit = 50;
+    MV v0, v1, v2, v3_, v4;
+    v0.a = A.center; v0.b = B.center; v0.v = v0.a - v0.b;
+    if (norm(v0.v) < (real)1e-12) v0.v = v3((real)1e-5, 0, 0);
+    v3 dir = normalized(-v0.v);
+    v1 = msupport(A, B, dir);
+    if (dot(v1.v, dir) <= 0) return false;
+    dir = cross(v0.v, v1.v);
+    if (norm(dir) < (real)1e-12 * maxv((real)1, norm(v0.v) * norm(v1.v))) {
+      v3 d = normalized(-v0.v);
+      *depth = dot(v1.v, d); *dir_out = d; *pos_out = (v1.a + v1.b) * (real)0.5;
+      return true;
+    }
+    dir = normalized(dir);
+    v2 = msupport(A, B, dir);
+    if (dot(v2.v, dir) <= 0) return false;
+    dir = normalized(cross(v1.v - v0.v, v2.v - v0.v));
+    if (dot(dir, v0.v) > 0) { MV t = v1; v1 = v2; v2 = t; dir = -dir; }
+    for (int it = 0;; it++) {
+      if (it > maxit) return false;
+      v3_ = msupport(A, B, dir);
+      if (dot(v3_.v, dir) <= 0) return false;
+      bool cont = false;
+      if (dot(cross(v1.v, v3_.v), v0.v) < 0) { v2 = v3_; cont = true; }
+      else if (dot(cross(v3_.v, v2.v), v0.v) < 0) { v1 = v3_; cont = true; }
+      if (!cont) break;
+      dir = normalized(cross(v1.v - v0.v, v2.v - v0.v));
+    }
+    bool hit = false;
+    for (int it = 0;; it++) {
+      dir = normalized(cross(v2.v - v1.v, v3_.v - v1.v));
+      if (dot(dir, v0.v) > 0) dir = -dir;
+      real d1 = dot(v1.v, dir);
+      if (d1 >= 0) hit = true;
+      v4 = msupport(A, B, dir);
+      real d4 = dot(v4.v, dir);
+      if (!hit && d4 < 0) return false;
+      if (d4 - d1 <= tol || it >= maxit) {
+        if (!hit) return false;
+        v3 p = dir * d1;
+        v3 e1 = v2.v - v1.v, e2 = v3_.v - v1.v, ep = p - v1.v;
+        real a11 = dot(e1, e1), a12 = dot(e1, e2), a22 = dot(e2, e2), b1 = dot(ep, e1), b2 = dot(ep, e2);
+        real det = a11 * a22 - a12 * a12;
+        real w2 = (real)1 / 3, w3 = (real)1 / 3;
+        if (fabs(det) > (real)1e-30) { w2 = (a22 * b1 - a12 * b2) / det; w3 = (a11 * b2 - a12 * b1) / det; }
+        real w1 = (real)1 - w2 - w3;
+        w1 = maxv(w1, (real)0); w2 = maxv(w2, (real)0); w3 = maxv(w3, (real)0);
+        real ws = w1 + w2 + w3;
+        if (ws < (real)1e-30) { w1 = w2 = w3 = (real)1 / 3; ws = 1; }
+        w1 /= ws; w2 /= ws; w3 /= ws;
+        v3 pa = v1.a * w1 + v2.a * w2 + v3_.a * w3, pb = v1.b * w1 + v2.b * w2 + v3_.b * w3;
+        *depth = d1; *dir_out = dir; *pos_out = (pa + pb) * (real)0.5;
+        return true;
+      }
+      v3 c = cross(v4.v, v0.v);
+      if (dot(v1.v, c) > 0) { if (dot(v2.v, c) > 0) v1 = v4; else v3_ = v4; }
+      else { if (dot(v3_.v, c) > 0) v2 = v4; else v1 = v4; }
+    }
+  }
+
+  // narrow phase for one candidate pair: up to 8 points sharing one normal (from geom1 towards geom2)
+  struct PairOut { int n; v3 normal; v3 pos[8]; real dist[8]; };
+  UR5_BIG void box_box(const GeomPose& A, v3 a, const GeomPose& B, v3 b, real margin, PairOut& out) const {
+    v3 t = B.pos - A.pos;
+    real R[3][3], Q[3][3];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { R[i][j] = dot(A.mat.col(i), B.mat.col(j)); Q[i][j] = fabs(R[i][j]); }
+    v3 ta(dot(t, A.mat.col(0)), dot(t, A.mat.col(1)), dot(t, A.mat.col(2)));
+    real best = -1e300; int code = -1; v3 bestn; bool flip = false;
+    for (int i = 0; i < 3; i++) {
+      real s = fabs(ta[i]) - (a[i] + b.x * Q[i][0] + b.y * Q[i][1] + b.z * Q[i][2]);
+      if (s > margin) return;
+      if (s > best) { best = s; code = i; bestn = A.mat.col(i); flip = ta[i] < 0; }
+    }
+    for (int j = 0; j < 3; j++) {
+      real tb = dot(t, B.mat.col(j));
+      real s = fabs(tb) - (b[j] + a.x * Q[0][j] + a.y * Q[1][j] + a.z * Q[2][j]);
+      if (s > margin) return;
+      if (s > best) { best = s; code = 3 + j; bestn = B.mat.col(j); flip = tb < 0; }
+    }
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+      v3 Lx = cross(A.mat.col(i), B.mat.col(j));
+      real l = norm(Lx);
+      if (l < (real)1e-6) continue;
+      Lx = Lx * ((real)1 / l);
+      real tl = dot(t, Lx), ra = 0, rb = 0;
+      for (int k = 0; k < 3; k++) { ra += a[k] * fabs(dot(A.mat.col(k), Lx)); rb += b[k] * fabs(dot(B.mat.col(k), Lx)); }
+      real s = fabs(tl) - (ra + rb);
+      if (s > margin) return;
+      if (s > best + (real)1e-6 + (real)0.05 * fabs(best)) { best = s; code = 6 + 3 * i + j; bestn = Lx; flip = tl < 0; }
+    }
+    v3 n = flip ? -bestn : bestn;
+    out.normal = n;
+    if (code >= 6) {
+      int i = (code - 6) / 3, j = (code - 6) % 3;
+      v3 ea = A.pos, eb = B.pos;
+      for (int k = 0; k < 3; k++) if (k != i) ea = ea + A.mat.col(k) * ((dot(n, A.mat.col(k)) > 0 ? (real)1 : (real)-1) * a[k]);
+      for (int k = 0; k < 3; k++) if (k != j) eb = eb - B.mat.col(k) * ((dot(n, B.mat.col(k)) > 0 ? (real)1 : (real)-1) * b[k]);
+      v3 ua = A.mat.col(i), ub = B.mat.col(j), w = ea - eb;
+      real uaub = dot(ua, ub), q1 = dot(ua, w), q2 = dot(ub, w), den = (real)1 - uaub * uaub;
+      real sa = 0, sb = 0;
+      if (den > (real)1e-12) { sa = (uaub * q2 - q1) / den; sb = (q2 - uaub * q1) / den; }
+      sa = clampv(sa, -a[i], a[i]); sb = clampv(sb, -b[j], b[j]);
+      out.pos[0] = ((ea + ua * sa) + (eb + ub * sb)) * (real)0.5;
+      out.dist[0] = best;
+      out.n = 1;
+      return;
+    }
+    bool refA = code < 3;
+    int ax = refA ? code : code - 3;
+    const GeomPose &Rr = refA ? A : B, &Ri = refA ? B : A;
+    v3 r = refA ? a : b, in = refA ? b : a;
+    v3 nref = refA ? n : -n;
+    int iax = 0; real bd = -1;
+    for (int k = 0; k < 3; k++) { real d = fabs(dot(Ri.mat.col(k), nref)); if (d > bd) { bd = d; iax = k; } }
+    real isgn = dot(Ri.mat.col(iax), nref) > 0 ? (real)-1 : (real)1;
+    v3 ic = Ri.pos + Ri.mat.col(iax) * (isgn * in[iax]);
+    int u = (iax + 1) % 3, v = (iax + 2) % 3;
+    v3 poly[16], tmp[16];
+    int np = 4;
+    v3 cu = Ri.mat.col(u) * in[u], cv = Ri.mat.col(v) * in[v];
+    poly[0] = ic + cu + cv; poly[1] = ic - cu + cv; poly[2] = ic - cu - cv; poly[3] = ic + cu - cv;
+    int ru = (ax + 1) % 3, rv = (ax + 2) % 3;
+    real rsgn = dot(Rr.mat.col(ax), nref) > 0 ? (real)1 : (real)-1;
+    v3 rc = Rr.pos + Rr.mat.col(ax) * (rsgn * r[ax]);
+    for (int side = 0; side < 4 && np > 0; side++) {
+      v3 pn = (side < 2 ? Rr.mat.col(ru) : Rr.mat.col(rv)) * ((side & 1) ? (real)-1 : (real)1);
+      real lim = side < 2 ? r[ru] : r[rv];
+      int nn = 0;
+      for (int k = 0; k < np; k++) {
+        v3 p0 = poly[k], p1 = poly[(k + 1) % np];
+        real d0 = dot(p0 - rc, pn) - lim, d1 = dot(p1 - rc, pn) - lim;
+        if (d0 <= 0) tmp[nn++] = p0;
+        if ((d0 < 0 && d1 > 0) || (d0 > 0 && d1 < 0)) tmp[nn++] = p0 + (p1 - p0) * (d0 / (d0 - d1));
+      }
+      np = nn < 8 ? nn : 8;
+      for (int k = 0; k < np; k++) poly[k] = tmp[k];
+    }
+    int cnt = 0;
+    for (int k = 0; k < np; k++) {
+      real d = dot(poly[k] - rc, nref);
+      if (d < margin) { out.pos[cnt] = poly[k] - nref * ((real)0.5 * d); out.dist[cnt] = d; cnt++; }
+    }
+    out.n = cnt;
+  }
+  UR5_BIG void narrow(int g1, int g2, real margin, PairOut& out) const {
+    out.n = 0;
+    int t1 = M.g_type[g1], t2 = M.g_type[g2];
+    GeomPose A = geom_pose(g1), B = geom_pose(g2);
+    if (t1 == UR5_GEOM_PLANE) {
+      v3 n = A.mat.col(2);
+      out.normal = n;
+      if (t2 == UR5_GEOM_SPHERE) {
+        real r = (real)M.g_size[g2][0];
+        real d = dot(B.pos - A.pos, n) - r;
+        if (d < margin) { out.pos[0] = B.pos - n * (r + (real)0.5 * d); out.dist[0] = d; out.n = 1; }
+      } else if (t2 == UR5_GEOM_BOX) {
+        v3 s(M.g_size[g2]);
+        int cnt = 0;
+        for (int k = 0; k < 8 && cnt < 4; k++) {
+          v3 l((k & 1) ? s.x : -s.x, (k & 2) ? s.y : -s.y, (k & 4) ? s.z : -s.z);
+          v3 v = B.pos + mul(B.mat, l);
+          real d = dot(v - A.pos, n);
+          if (d < margin) { out.pos[cnt] = v - n * ((real)0.5 * d); out.dist[cnt] = d; cnt++; }
+        }
+        out.n = cnt;
+      } else {
+        Shape s = make_shape(g2, 0);
+        v3 v = support(s, -n);
+        real d = dot(v - A.pos, n);
+        if (d < margin) { out.pos[0] = v - n * ((real)0.5 * d); out.dist[0] = d; out.n = 1; }
+      }
+    } else if (t1 == UR5_GEOM_SPHERE && t2 == UR5_GEOM_SPHERE) {
+      v3 d = B.pos - A.pos;
+      real len = norm(d), r1 = (real)M.g_size[g1][0], r2 = (real)M.g_size[g2][0];
+      real dist = len - r1 - r2;
+      if (dist < margin) {
+        v3 n = len > (real)1e-12 ? d * ((real)1 / len) : v3(1, 0, 0);
+        out.normal = n; out.pos[0] = A.pos + n * (r1 + (real)0.5 * dist); out.dist[0] = dist; out.n = 1;
+      }
+    } else if (t1 == UR5_GEOM_SPHERE && t2 == UR5_GEOM_BOX) {
+      real r = (real)M.g_size[g1][0];
+      v3 s(M.g_size[g2]);
+      v3 cl = mulT(B.mat, A.pos - B.pos);
+      v3 p(clampv(cl.x, -s.x, s.x), clampv(cl.y, -s.y, s.y), clampv(cl.z, -s.z, s.z));
+      v3 d = p - cl;
+      real len = norm(d);
+      if (len > (real)1e-12) {
+        real dist = len - r;
+        if (dist < margin) {
+          v3 n = mul(B.mat, d * ((real)1 / len));
+          out.normal = n; out.pos[0] = A.pos + n * (r + (real)0.5 * dist); out.dist[0] = dist; out.n = 1;
+        }
+      } else {
+        int ax = 0; real best = 1e300;
+        for (int i = 0; i < 3; i++) { real g = s[i] - fabs(cl[i]); if (g < best) { best = g; ax = i; } }
+        v3 el; el.set(ax, cl[ax] >= 0 ? (real)1 : (real)-1);
+        v3 e = mul(B.mat, el);
+        out.normal = -e; out.pos[0] = A.pos + e * ((real)0.5 * (best - r)); out.dist[0] = -best - r; out.n = 1;
+      }
+    } else if (t1 == UR5_GEOM_BOX && t2 == UR5_GEOM_BOX) {
+      box_box(A, v3(M.g_size[g1]), B, v3(M.g_size[g2]), margin, out);
+    } else {
+      Shape sa = make_shape(g1, margin), sb = make_shape(g2, margin);
+      real depth; v3 dir, pos;
+      if (mpr(sa, sb, &depth, &dir, &pos)) {
+        real dist = margin - depth;
+        if (dist < margin) { out.normal = dir; out.pos[0] = pos; out.dist[0] = dist; out.n = 1; }
+      }
+    }
+  }
+  UR5_BIG bool cull(int g1, int g2, real margin) const {  // true = cannot touch
+    GeomPose A = geom_pose(g1), B = geom_pose(g2);
+    int t1 = M.g_type[g1], t2 = M.g_type[g2];
+    real r1 = (real)M.g_rbound[g1], r2 = (real)M.g_rbound[g2];
+    if (t1 == UR5_GEOM_PLANE) return dot(B.pos - A.pos, A.mat.col(2)) > r2 + margin;
+    v3 d = B.pos - A.pos;
+    real rr = r1 + r2 + margin;
+    if (dot(d, d) > rr * rr) return true;
+    // conservative OBB refinement (keeps the finger/plate pair out of the narrow phase while the gripper is high above it)
+    if (t2 == UR5_GEOM_BOX && dist_point_box(A.pos, B, v3(M.g_size[g2])) > r1 + margin) return true;
+    if (t1 == UR5_GEOM_BOX && dist_point_box(B.pos, A, v3(M.g_size[g1])) > r2 + margin) return true;
+    return false;
+  }
+  UR5_FN static void make_frame(v3 n, real* fr) {
+    v3 y = fabs(n.y) < (real)0.5 ? v3(0, 1, 0) : v3(0, 0, 1);
+    y = normalized(y - n * dot(n, y));
+    v3 z = cross(n, y);
+    n.store(fr); y.store(fr + 3); z.store(fr + 6);
+  }
+  UR5_FN int body_of_geom(int g) const {  // cbody index (robot dof or nrd + object) or -1 for static
+    int k = M.g_kind[g];
+    return k == UR5_KIND_STATIC ? -1 : (k == UR5_KIND_ROBOT ? M.g_owner[g] : M.nrd + M.g_owner[g]);
+  }
+
+  UR5_BIG void collision() {
+    if (UR5_LANE == 0) { S.ncon = 0; S.ncand = 0; }
+    SYNC();
+    if (!contacts_enabled) return;
+    // broad phase: ordered compaction of the surviving pairs
+    int ncand = 0;
+    for (int p0 = 0; p0 < M.npair; p0 += 64) {
+#ifdef UR5_EMUL
+      for (int p = p0; p < p0 + 64 && p < M.npair; p++) {
+        int g1 = M.pair_g1[p], g2 = M.pair_g2[p];
+        real margin = maxv((real)M.g_margin[g1], (real)M.g_margin[g2]);
+        if (!cull(g1, g2, margin) && ncand < UR5_MAXCAND) S.cand[ncand++] = p;
+      }
+#else
+      int p = p0 + UR5_LANE;
+      bool keep = false;
+      if (p < M.npair) {
+        int g1 = M.pair_g1[p], g2 = M.pair_g2[p];
+        real margin = maxv((real)M.g_margin[g1], (real)M.g_margin[g2]);
+        keep = !cull(g1, g2, margin);
+      }
+      unsigned long long mask = __ballot(keep);
+      int slot = ncand + __popcll(mask & ((1ull << UR5_LANE) - 1ull));
+      if (keep && slot < UR5_MAXCAND) S.cand[slot] = p;
+      ncand += __popcll(mask);
+      if (ncand > UR5_MAXCAND) ncand = UR5_MAXCAND;
+#endif
+    }
+    SYNC();
+    // narrow phase: one candidate per lane; contact slots are handed out in candidate order
+    int base = 0;
+    {
+#ifdef UR5_EMUL
+      for (int ci = 0; ci < ncand; ci++) {
+#else
+      int ci = UR5_LANE;
+      {
+#endif
+        PairOut out;
+        out.n = 0;
+        int g1 = 0, g2 = 0;
+        real margin = 0;
+        if (ci < ncand) {
+          int p = S.cand[ci];
+          g1 = M.pair_g1[p]; g2 = M.pair_g2[p];
+          margin = maxv((real)M.g_margin[g1], (real)M.g_margin[g2]);
+          narrow(g1, g2, margin, out);
+        }
+#ifdef UR5_EMUL
+        int slot = base;
+        base += out.n;
+#else
+        int incl = out.n;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o, 64); if (UR5_LANE >= o) incl += t; }
+        int slot = incl - out.n;
+        base = __shfl(incl, 63, 64);
+#endif
+        for (int k = 0; k < 8; k++) {
+          if (k < out.n && slot + k < UR5_MAXCON) {
+            int c = slot + k;
+            out.pos[k].store(S.cpos[c]);
+            make_frame(out.normal, S.cframe[c]);
+            S.cdist[c] = out.dist[k];
+            S.cg1[c] = g1; S.cg2[c] = g2;
+            S.cA[c] = body_of_geom(g1); S.cB[c] = body_of_geom(g2);
+            int dim = M.g_condim[g1] > M.g_condim[g2] ? M.g_condim[g1] : M.g_condim[g2];
+            S.cdim[c] = dim;
+            for (int j = 0; j < 3; j++) S.cfri[c][j] = maxv((real)M.g_friction[g1][j], (real)M.g_friction[g2][j]);
+          }
+        }
+      }
+    }
+    SYNC();
+    if (UR5_LANE == 0) {
+      int n = base;
+      if (n > UR5_MAXCON) { n = UR5_MAXCON; S.status |= UR5_ST_CONTACT_OVERFLOW; }
+      S.ncon = n;
+      if (n > S.ncon_max) S.ncon_max = n;
+    }
+    SYNC();
+  }
+
+  // ------------------------------------------------------------------ constraint rows (mj_makeConstraint + mj_makeImpedance [3P])
+  UR5_FN static real impedance(const double* solimp, real x_abs) {
+    real dmin = clampv((real)solimp[0], (real)0.0001, (real)0.9999), dmax = clampv((real)solimp[1], (real)0.0001, (real)0.9999);
+    real width = (real)solimp[2], mid = (real)solimp[3], power = (real)solimp[4];
+    if (dmin == dmax || width <= (real)1e-15) return (real)0.5 * (dmin + dmax);
+    real x = x_abs / width;
+    if (x >= 1) return dmax;
+    if (x <= 0) return dmin;
+    real y;
+    if (power == 1) y = x;
+    else if (x <= mid) y = pow(x / mid, power) * mid;
+    else y = 1 - pow((1 - x) / (1 - mid), power) * (1 - mid);
+    return dmin + y * (dmax - dmin);
+  }
+  UR5_FN void kbi(const double* solref, const double* solimp, real imp, real* K, real* B) const {
+    real tc = maxv((real)solref[0], 2 * (real)M.timestep), dr = (real)solref[1];
+    real dmax = clampv((real)solimp[1], (real)0.0001, (real)0.9999);
+    *K = (real)1 / (dmax * dmax * tc * tc * dr * dr);
+    *B = (real)2 / (dmax * tc);
+  }
+  UR5_FN v3 body_ref(int b) const { return b < M.nrd ? v3(M.ref_point) : v3(S.bpos[b]); }
+  // relative twist-space image of a contact: e[k] for the NB base directions given the two body twists (B minus A)
+  UR5_FN void contact_image(int c, const real twA[6], const real twB[6], bool hasA, bool hasB, real* e) const {
+    v3 p(S.cpos[c]);
+    v3 u, w;
+    if (hasB) { v3 r = p - body_ref(S.cB[c]); v3 om(twB), vl(twB + 3); u = vl + cross(om, r); w = om; }
+    if (hasA) { v3 r = p - body_ref(S.cA[c]); v3 om(twA), vl(twA + 3); u = u - (vl + cross(om, r)); w = w - om; }
+    v3 n(S.cframe[c]), t1(S.cframe[c] + 3), t2(S.cframe[c] + 6);
+    e[0] = dot(n, u); e[1] = dot(t1, u); e[2] = dot(t2, u); e[3] = dot(n, w); e[4] = dot(t1, w); e[5] = dot(t2, w);
+  }
+  UR5_BIG void make_constraints() {
+    // special rows are few and depend on wave-uniform data only: lane 0 builds them
+    if (UR5_LANE == 0) {
+      int ns = 0;
+      for (int e = 0; e < M.neq; e++) {
+        int d1 = M.eq_d1[e], d2 = M.eq_d2[e];
+        const double* pc = M.eq_poly[e];
+        real xq = qpos()[d2] - (real)M.rd_qpos0[d2];
+        real poly = (real)pc[0] + xq * ((real)pc[1] + xq * ((real)pc[2] + xq * ((real)pc[3] + xq * (real)pc[4])));
+        real dpoly = (real)pc[1] + xq * (2 * (real)pc[2] + xq * (3 * (real)pc[3] + xq * 4 * (real)pc[4]));
+        real pos = (qpos()[d1] - (real)M.rd_qpos0[d1]) - poly;
+        real imp = impedance(M.eq_solimp[e], fabs(pos)), K, B;
+        kbi(M.eq_solref[e], M.eq_solimp[e], imp, &K, &B);
+        real dA = (real)M.rd_invweight[d1] + (real)M.rd_invweight[d2];
+        real R = maxv((real)1e-15, (1 - imp) * dA / imp);
+        real vel = qvel()[d1] - dpoly * qvel()[d2];
+        S.sr_d1[ns] = d1; S.sr_d2[ns] = d2; S.sr_c1[ns] = 1; S.sr_c2[ns] = -dpoly; S.sr_uni[ns] = 0;
+        S.sr_D[ns] = (real)1 / R; S.sr_aref[ns] = -B * vel - K * imp * pos;
+        ns++;
+      }
+      for (int d = 0; d < M.nrd; d++) {
+        if (!M.rd_limited[d]) continue;
+        for (int side = 0; side < 2; side++) {
+          real dist = side == 0 ? qpos()[d] - (real)M.rd_lo[d] : (real)M.rd_hi[d] - qpos()[d];
+          if (dist >= 0 || ns >= UR5_MAXSR) continue;
+          real sg = side == 0 ? (real)1 : (real)-1;
+          real imp = impedance(M.jnt_solimp, fabs(dist)), K, B;
+          kbi(M.jnt_solref, M.jnt_solimp, imp, &K, &B);
+          real R = maxv((real)1e-15, (1 - imp) * (real)M.rd_invweight[d] / imp);
+          S.sr_d1[ns] = d; S.sr_d2[ns] = -1; S.sr_c1[ns] = sg; S.sr_c2[ns] = 0; S.sr_uni[ns] = 1;
+          S.sr_D[ns] = (real)1 / R; S.sr_aref[ns] = -B * sg * qvel()[d] - K * imp * dist;
+          ns++;
+        }
+      }
+      for (int k = 0; k < M.nobj; k++) {
+        if (M.obj_kind[k] != 0) continue;
+        for (int j = 0; j < 3; j++) {
+          if (!M.obj_limited[k][j]) continue;
+          int qa = M.nrd + 7 * k + j, d = M.nrd + 6 * k + j;
+          for (int side = 0; side < 2; side++) {
+            real dist = side == 0 ? qpos()[qa] - (real)M.obj_lo[k][j] : (real)M.obj_hi[k][j] - qpos()[qa];
+            if (dist >= 0 || ns >= UR5_MAXSR) continue;
+            real sg = side == 0 ? (real)1 : (real)-1;
+            real imp = impedance(M.jnt_solimp, fabs(dist)), K, B;
+            kbi(M.jnt_solref, M.jnt_solimp, imp, &K, &B);
+            real R = maxv((real)1e-15, (1 - imp) * (real)M.obj_invweight[k][0] / imp);
+            S.sr_d1[ns] = d; S.sr_d2[ns] = -1; S.sr_c1[ns] = sg; S.sr_c2[ns] = 0; S.sr_uni[ns] = 1;
+            S.sr_D[ns] = (real)1 / R; S.sr_aref[ns] = -B * sg * qvel()[d] - K * imp * dist;
+            ns++;
+          }
+        }
+      }
+      S.nsr = ns;
+      int nc = 0;
+      for (int c = 0; c < S.ncon; c++) if (S.cA[c] >= 0 && S.cB[c] >= 0) S.couple[nc++] = c;
+      S.ncouple = nc;
+    }
+    PAR(c, S.ncon) {
+      int g1 = S.cg1[c], g2 = S.cg2[c];
+      real margin = maxv((real)M.g_margin[g1], (real)M.g_margin[g2]);
+      real pos = S.cdist[c];
+      double solref[2], solimp[5];
+      for (int i = 0; i < 2; i++) solref[i] = 0.5 * (M.g_solref[g1][i] + M.g_solref[g2][i]);
+      for (int i = 0; i < 5; i++) solimp[i] = 0.5 * (M.g_solimp[g1][i] + M.g_solimp[g2][i]);
+      real imp = impedance(solimp, fabs(pos - margin)), K, B;
+      kbi(solref, solimp, imp, &K, &B);
+      real tran = (real)(M.g_invw[g1][0] + M.g_invw[g2][0]);
+      real fri0 = S.cfri[c][0];
+      real R0 = maxv((real)1e-15, (1 - imp) * (tran + fri0 * fri0 * tran) / imp);
+      real R;
+      if (S.cdim[c] == 1) R = maxv((real)1e-15, (1 - imp) * tran / imp);
+      else { real mu = fri0 * sqrt((real)1 / maxv((real)1e-15, (real)M.impratio)); R = 2 * mu * mu * R0; }
+      S.cD[c] = (real)1 / R;
+      S.cbv[c] = B;
+      S.ckr[c] = K * imp * (pos - margin);
+      bool hasA = S.cA[c] >= 0, hasB = S.cB[c] >= 0;
+      contact_image(c, hasA ? S.cvel[S.cA[c]] : S.cvel[0], hasB ? S.cvel[S.cB[c]] : S.cvel[0], hasA, hasB, S.cvb[c]);
+    }
+    SYNC();
+  }
+
+  // ------------------------------------------------------------------ Newton solver pieces
+  UR5_FN real row_mu(int c, int k) const { return k <= 2 ? S.cfri[c][0] : (k == 3 ? S.cfri[c][1] : S.cfri[c][2]); }
+  // twists of every body for a dof-space vector, then base images (with or without the aref offsets)
+  UR5_BIG void images(const real* vec, bool offset, real (*out)[NB], real* srout) {
+    PAR(b, nb()) {
+      if (b < M.nrd) {
+        real v[6] = {0, 0, 0, 0, 0, 0};
+        for (int e = 0; e < M.nrd; e++) if (M.rd_anc[b] >> e & 1u) { real q = vec[e]; for (int i = 0; i < 6; i++) v[i] += S.cdof[e][i] * q; }
+        for (int i = 0; i < 6; i++) S.tw[b][i] = v[i];
+      } else {
+        int va = M.nrd + 6 * (b - M.nrd);
+        m3 R; R.load(S.bmat[b]);
+        mul(R, v3(vec[va + 3], vec[va + 4], vec[va + 5])).store(S.tw[b]);
+        v3(vec[va], vec[va + 1], vec[va + 2]).store(S.tw[b] + 3);
+      }
+    }
+    SYNC();
+    PAR(c, S.ncon) {
+      bool hasA = S.cA[c] >= 0, hasB = S.cB[c] >= 0;
+      real e[NB];
+      contact_image(c, hasA ? S.tw[S.cA[c]] : S.tw[0], hasB ? S.tw[S.cB[c]] : S.tw[0], hasA, hasB, e);
+      if (offset) { for (int k = 0; k < NB; k++) e[k] += S.cbv[c] * S.cvb[c][k]; e[0] += S.ckr[c]; }
+      for (int k = 0; k < NB; k++) out[c][k] = e[k];
+    }
+    PAR(s, S.nsr) {
+      real v = S.sr_c1[s] * vec[S.sr_d1[s]];
+      if (S.sr_d2[s] >= 0) v += S.sr_c2[s] * vec[S.sr_d2[s]];
+      srout[s] = offset ? v - S.sr_aref[s] : v;
+    }
+    SYNC();
+  }
+  UR5_BIG void mat_vec_M(const real* vec, real* out) {
+    PAR(i, M.nv) {
+      if (i < M.nrd) { real s = 0; for (int e = 0; e < M.nrd; e++) s += S.Mr[i][e] * vec[e]; out[i] = s; }
+      else out[i] = S.Mobj[i - M.nrd] * vec[i];
+    }
+    SYNC();
+  }
+  // constraint cost of the current images (ce, sr_jar) shifted by alpha along (cde, sr_jv); also first/second derivative
+  UR5_BIG void constraint_cost(real alpha, real* cost, real* d1, real* d2) {
+    real c0 = 0, g1 = 0, g2 = 0;
+    PAR(c, S.ncon) {
+      real D = S.cD[c];
+      real e0 = S.ce[c][0] + alpha * S.cde[c][0], j0 = S.cde[c][0];
+      if (S.cdim[c] == 1) {
+        if (e0 < 0) { c0 += (real)0.5 * D * e0 * e0; g1 += D * e0 * j0; g2 += D * j0 * j0; }
+      } else {
+        for (int k = 1; k < S.cdim[c]; k++) {
+          real mu = row_mu(c, k);
+          real ek = mu * (S.ce[c][k] + alpha * S.cde[c][k]), jk = mu * S.cde[c][k];
+          real rp = e0 + ek, rm = e0 - ek;
+          if (rp < 0) { c0 += (real)0.5 * D * rp * rp; g1 += D * rp * (j0 + jk); g2 += D * (j0 + jk) * (j0 + jk); }
+          if (rm < 0) { c0 += (real)0.5 * D * rm * rm; g1 += D * rm * (j0 - jk); g2 += D * (j0 - jk) * (j0 - jk); }
+        }
+      }
+    }
+    PAR(s, S.nsr) {
+      real r = S.sr_jar[s] + alpha * S.sr_jv[s], j = S.sr_jv[s];
+      if (!S.sr_uni[s] || r < 0) { c0 += (real)0.5 * S.sr_D[s] * r * r; g1 += S.sr_D[s] * r * j; g2 += S.sr_D[s] * j * j; }
+    }
+    *cost = WAVE_SUM(c0); *d1 = WAVE_SUM(g1); *d2 = WAVE_SUM(g2);
+  }
+  UR5_FN real gauss_cost(const real* xv, const real* Ma) {
+    real g = 0;
+    PAR(i, M.nv) g += (real)0.5 * (Ma[i] - S.fs[i]) * (xv[i] - S.as[i]);
+    return WAVE_SUM(g);
+  }
+  // unit twist [rot; lin] of dof-local index i of cbody b (zero when the dof does not move the body)
+  UR5_FN bool unit_twist(int b, int i, real* tw) const {
+    for (int k = 0; k < 6; k++) tw[k] = 0;
+    if (b < M.nrd) {
+      if (!(M.rd_anc[b] >> i & 1u)) return false;
+      for (int k = 0; k < 6; k++) tw[k] = S.cdof[i][k];
+    } else if (i < 3) tw[3 + i] = 1;
+    else { m3 R; R.load(S.bmat[b]); v3 cc = R.col(i - 3); tw[0] = cc.x; tw[1] = cc.y; tw[2] = cc.z; }
+    return true;
+  }
+  // (J e_ia)^T W (J e_ib) for side-A dof ia and side-B dof ib of contact c
+  UR5_BIG real couple_term(int c, int A, int ia, int B, int ib) const {
+    real twA[6], twB[6], zero[6] = {0, 0, 0, 0, 0, 0}, ea[NB], eb[NB];
+    if (!unit_twist(A, ia, twA) || !unit_twist(B, ib, twB)) return 0;
+    contact_image(c, twA, zero, true, false, ea);  // carries the minus sign of side A
+    contact_image(c, zero, twB, false, true, eb);
+    const real* w = S.cW[c];
+    real v = w[0] * ea[0] * eb[0];
+    for (int k = 1; k < NB; k++) v += w[k] * (ea[0] * eb[k] + ea[k] * eb[0]) + w[NB - 1 + k] * ea[k] * eb[k];
+    return v;
+  }
+  // gradient and Newton direction at S.x (images in S.ce / S.sr_jar must be current): S.search = -H^-1 grad
+  UR5_BIG void newton_direction() {
+    const int nbod = nb();
+    PAR(c, S.ncon) {  // base forces and the "arrow" weight matrix of each contact
+      real D = S.cD[c], e0 = S.ce[c][0];
+      real fb[NB], w[2 * NB - 1];
+      for (int k = 0; k < NB; k++) fb[k] = 0;
+      for (int k = 0; k < 2 * NB - 1; k++) w[k] = 0;
+      if (S.cdim[c] == 1) {
+        if (e0 < 0) { fb[0] = -D * e0; w[0] = D; }
+      } else {
+        for (int k = 1; k < S.cdim[c]; k++) {
+          real mu = row_mu(c, k), ek = mu * S.ce[c][k];
+          real rp = e0 + ek, rm = e0 - ek;
+          real ap = rp < 0 ? (real)1 : (real)0, am = rm < 0 ? (real)1 : (real)0;
+          real fp = -D * rp * ap, fm = -D * rm * am;
+          fb[0] += fp + fm; fb[k] += mu * (fp - fm);
+          w[0] += D * (ap + am); w[k] = D * mu * (ap - am); w[NB - 1 + k] = D * mu * mu * (ap + am);
+        }
+      }
+      for (int k = 0; k < NB; k++) S.cfb[c][k] = fb[k];
+      for (int k = 0; k < 2 * NB - 1; k++) S.cW[c][k] = w[k];
+    }
+    SYNC();
+    // per-body wrench (gradient) and 6x6 twist-space Hessian accumulators: gather over contacts in index order
+    PAR(idx, nbod * 27) {
+      int b = idx / 27, ent = idx % 27;
+      real acc = 0;
+      v3 ref = body_ref(b);
+      int gi = 0, gj = 0;
+      if (ent >= 6) { int e = ent - 6; while ((gi + 1) * (gi + 2) / 2 <= e) gi++; gj = e - gi * (gi + 1) / 2; }
+      for (int c = 0; c < S.ncon; c++) {
+        bool isA = S.cA[c] == b, isB = S.cB[c] == b;
+        if (!isA && !isB) continue;
+        v3 r = v3(S.cpos[c]) - ref;
+        v3 ax[3] = {v3(S.cframe[c]), v3(S.cframe[c] + 3), v3(S.cframe[c] + 6)};
+        if (ent < 6) {
+          // wrench on this body: force F = sum fb_k a_k, moment r x F + fb_3 n + fb_4 t1 + fb_5 t2  (negated on side A)
+          v3 F = ax[0] * S.cfb[c][0] + ax[1] * S.cfb[c][1] + ax[2] * S.cfb[c][2];
+          v3 Mo = cross(r, F) + ax[0] * S.cfb[c][3] + ax[1] * S.cfb[c][4] + ax[2] * S.cfb[c][5];
+          real v = ent < 3 ? Mo[ent] : F[ent - 3];
+          acc += isB ? v : -v;
+        } else {
+          // F_k (6-vector [rot; lin]) : k<3 -> [r x a_k ; a_k], k>=3 -> [a_{k-3} ; 0];  G += sum_kl W_kl F_k F_l^T (arrow W)
+          real fi[NB], fj[NB];
+          for (int k = 0; k < 3; k++) {
+            v3 ra = cross(r, ax[k]);
+            fi[k] = gi < 3 ? ra[gi] : ax[k][gi - 3];
+            fj[k] = gj < 3 ? ra[gj] : ax[k][gj - 3];
+            fi[3 + k] = gi < 3 ? ax[k][gi] : (real)0;
+            fj[3 + k] = gj < 3 ? ax[k][gj] : (real)0;
+          }
+          const real* w = S.cW[c];
+          real v = w[0] * fi[0] * fj[0];
+          for (int k = 1; k < NB; k++) v += w[k] * (fi[0] * fj[k] + fi[k] * fj[0]) + w[NB - 1 + k] * fi[k] * fj[k];
+          acc += v;
+        }
+      }
+      if (ent < 6) S.WB[b][ent] = acc; else S.G[b][ent - 6] = acc;
+    }
+    SYNC();
+    // gradient = Ma - fs - J^T f
+    PAR(i, M.nv) {
+      real jf = 0;
+      if (i < M.nrd) {
+        for (int b = 0; b < M.nrd; b++) if (M.rd_desc[i] >> b & 1u) for (int k = 0; k < 6; k++) jf += S.cdof[i][k] * S.WB[b][k];
+      } else {
+        int k = (i - M.nrd) / 6, j = (i - M.nrd) % 6, b = M.nrd + k;
+        if (j < 3) jf = S.WB[b][3 + j];
+        else { m3 R; R.load(S.bmat[b]); jf = dot(R.col(j - 3), v3(S.WB[b])); }
+      }
+      for (int s = 0; s < S.nsr; s++) {
+        real r = S.sr_jar[s];
+        if (S.sr_uni[s] && r >= 0) continue;
+        real f = -S.sr_D[s] * r;
+        if (S.sr_d1[s] == i) jf += S.sr_c1[s] * f;
+        if (S.sr_d2[s] == i) jf += S.sr_c2[s] * f;
+      }
+      S.grad[i] = S.Ma[i] - S.fs[i] - jf;
+      S.search[i] = S.grad[i];
+    }
+    // Hessian, lower triangle
+    const int nv = M.nv, LD = L::LD;
+    PAR(idx, nv * nv) { int i = idx / nv, j = idx % nv; if (j <= i) S.H[i * LD + j] = 0; }
+    SYNC();
+    PAR(idx, M.nrd * M.nrd) {
+      int d = idx / M.nrd, e = idx % M.nrd;
+      if (e > d) continue;
+      real v = S.Mr[d][e];
+      unsigned common = M.rd_desc[d] & M.rd_desc[e];
+      for (int b = 0; b < M.nrd; b++) {
+        if (!(common >> b & 1u)) continue;
+        for (int i = 0; i < 6; i++) {
+          real t = 0;
+          for (int j = 0; j < 6; j++) t += S.G[b][sym6(i, j)] * S.cdof[e][j];
+          v += S.cdof[d][i] * t;
+        }
+      }
+      for (int s = 0; s < S.nsr; s++) {
+        if (S.sr_uni[s] && S.sr_jar[s] >= 0) continue;
+        real cd = (S.sr_d1[s] == d ? S.sr_c1[s] : (real)0) + (S.sr_d2[s] == d ? S.sr_c2[s] : (real)0);
+        real ce = (S.sr_d1[s] == e ? S.sr_c1[s] : (real)0) + (S.sr_d2[s] == e ? S.sr_c2[s] : (real)0);
+        v += S.sr_D[s] * cd * ce;
+      }
+      S.H[d * LD + e] = v;
+    }
+    PAR(idx, M.nobj * 21) {
+      int k = idx / 21, ent = idx % 21, b = M.nrd + k;
+      int i = 0;
+      while ((i + 1) * (i + 2) / 2 <= ent) i++;
+      int j = ent - i * (i + 1) / 2;  // dof-local indices, i >= j; 0-2 lin, 3-5 rot
+      m3 R; R.load(S.bmat[b]);
+      // twist per unit dof: lin j -> [0; e_j], rot j -> [R col_j; 0]
+      real ti[6] = {0, 0, 0, 0, 0, 0}, tj[6] = {0, 0, 0, 0, 0, 0};
+      if (i < 3) ti[3 + i] = 1; else { v3 cI = R.col(i - 3); ti[0] = cI.x; ti[1] = cI.y; ti[2] = cI.z; }
+      if (j < 3) tj[3 + j] = 1; else { v3 cJ = R.col(j - 3); tj[0] = cJ.x; tj[1] = cJ.y; tj[2] = cJ.z; }
+      real v = 0;
+      for (int a = 0; a < 6; a++) { real t = 0; for (int bb = 0; bb < 6; bb++) t += S.G[b][sym6(a, bb)] * tj[bb]; v += ti[a] * t; }
+      int di = M.nrd + 6 * k + i, dj = M.nrd + 6 * k + j;
+      if (i == j) {
+        v += S.Mobj[6 * k + i];
+        for (int s = 0; s < S.nsr; s++) if (S.sr_d1[s] == di && !(S.sr_uni[s] && S.sr_jar[s] >= 0)) v += S.sr_D[s] * S.sr_c1[s] * S.sr_c1[s];
+      }
+      S.H[di * LD + dj] = v;
+    }
+    SYNC();
+    // coupling blocks: contacts between two movable bodies, one contact at a time (entries may collide across contacts)
+    for (int q = 0; q < S.ncouple; q++) {
+      int c = S.couple[q], A = S.cA[c], B = S.cB[c];
+      int nA = A < M.nrd ? M.nrd : 6, nBd = B < M.nrd ? M.nrd : 6;
+      bool both_robot = A < M.nrd && B < M.nrd;
+      PAR(idx, nA * nBd) {
+        int ia = idx / nBd, ib = idx % nBd;
+        if (both_robot && ia < ib) continue;  // (ia, ib) and (ib, ia) land on one entry: the ia > ib lane adds both
+        int da = A < M.nrd ? ia : M.nrd + 6 * (A - M.nrd) + ia;
+        int db = B < M.nrd ? ib : M.nrd + 6 * (B - M.nrd) + ib;
+        real v = couple_term(c, A, ia, B, ib);
+        if (both_robot) v = ia == ib ? 2 * v : v + couple_term(c, A, ib, B, ia);
+        if (v != 0) {
+          if (da >= db) S.H[da * LD + db] += v; else S.H[db * LD + da] += v;
+        }
+      }
+      SYNC();
+    }
+    cholesky(S.H, nv, LD);
+    chol_solve(S.H, nv, LD, S.search);
+    PAR(i, nv) S.search[i] = -S.search[i];
+    SYNC();
+  }
+
+  UR5_BIG void solve_newton() {
+    const int nv = M.nv;
+    if (S.ncon == 0 && S.nsr == 0) {
+      PAR(i, nv) S.x[i] = S.as[i];
+      SYNC();
+      return;
+    }
+    // warm start: cheaper of qacc_warmstart and qacc_smooth
+    real dummy1, dummy2, ccw, ccs;
+    PAR(i, nv) S.x[i] = warm()[i];
+    SYNC();
+    mat_vec_M(S.x, S.Ma);
+    images(S.x, true, S.ce, S.sr_jar);
+    PAR(c, S.ncon) for (int k = 0; k < NB; k++) S.cde[c][k] = 0;
+    PAR(s, S.nsr) S.sr_jv[s] = 0;
+    SYNC();
+    constraint_cost(0, &ccw, &dummy1, &dummy2);
+    real cw = gauss_cost(S.x, S.Ma) + ccw;
+    SYNC();
+    mat_vec_M(S.as, S.Mv);
+    images(S.as, true, S.cfb, S.tmpv);  // scratch: cfb / tmpv hold the images at qacc_smooth
+    // cost at qacc_smooth: Gauss term vanishes
+    real cs;
+    {
+      real c0 = 0;
+      PAR(c, S.ncon) {
+        real D = S.cD[c], e0 = S.cfb[c][0];
+        if (S.cdim[c] == 1) { if (e0 < 0) c0 += (real)0.5 * D * e0 * e0; }
+        else for (int k = 1; k < S.cdim[c]; k++) {
+          real ek = row_mu(c, k) * S.cfb[c][k], rp = e0 + ek, rm = e0 - ek;
+          if (rp < 0) c0 += (real)0.5 * D * rp * rp;
+          if (rm < 0) c0 += (real)0.5 * D * rm * rm;
+        }
+      }
+      PAR(s, S.nsr) { real r = S.tmpv[s]; if (!S.sr_uni[s] || r < 0) c0 += (real)0.5 * S.sr_D[s] * r * r; }
+      cs = WAVE_SUM(c0);
+    }
+    SYNC();
+    real cost;
+    if (cw < cs) cost = cw;
+    else {
+      cost = cs;
+      PAR(i, nv) { S.x[i] = S.as[i]; S.Ma[i] = S.Mv[i]; }
+      PAR(c, S.ncon) for (int k = 0; k < NB; k++) S.ce[c][k] = S.cfb[c][k];
+      PAR(s, S.nsr) S.sr_jar[s] = S.tmpv[s];
+      SYNC();
+    }
+    const real scale = (real)1 / ((real)M.meaninertia * (real)(nv > 1 ? nv : 1));
+    const real tolerance = (real)M.tolerance;
+    newton_direction();
+    int iters = 0;
+    for (int it = 0; it < M.iterations; it++) {
+      iters = it + 1;
+      mat_vec_M(S.search, S.Mv);
+      images(S.search, false, S.cde, S.sr_jv);
+      real q1 = 0, q2 = 0, sn = 0;
+      PAR(i, nv) { q1 += S.search[i] * (S.Ma[i] - S.fs[i]); q2 += S.search[i] * S.Mv[i]; sn += S.search[i] * S.search[i]; }
+      q1 = WAVE_SUM(q1); q2 = WAVE_SUM(q2); sn = sqrt(WAVE_SUM(sn));
+      if (sn < (real)1e-15) break;
+      real gtol = tolerance * (real)0.01 * sn / scale;
+      real lo = 0, hi = -1, a = 0, cc, d1, d2;
+      constraint_cost(0, &cc, &d1, &d2);
+      d1 += q1; d2 += q2;
+      if (d1 < 0) {
+        for (int ls = 0; ls < 50; ls++) {
+          real an = a - d1 / d2;
+          if (hi > 0 && (an <= lo || an >= hi)) an = (real)0.5 * (lo + hi);
+          if (hi < 0 && an <= lo) an = 2 * lo + (real)1e-12;
+          a = an;
+          constraint_cost(a, &cc, &d1, &d2);
+          d1 += q1 + a * q2; d2 += q2;
+          if (fabs(d1) <= gtol) break;
+          if (d1 < 0) lo = a; else hi = a;
+        }
+      }
+      if (a <= 0) break;
+      SYNC();
+      PAR(i, nv) { S.x[i] += a * S.search[i]; S.Ma[i] += a * S.Mv[i]; }
+      PAR(c, S.ncon) for (int k = 0; k < NB; k++) S.ce[c][k] += a * S.cde[c][k];
+      PAR(s, S.nsr) S.sr_jar[s] += a * S.sr_jv[s];
+      SYNC();
+      real ccn, t1, t2;
+      PAR(c, S.ncon) for (int k = 0; k < NB; k++) S.cde[c][k] = 0;
+      PAR(s, S.nsr) S.sr_jv[s] = 0;
+      SYNC();
+      constraint_cost(0, &ccn, &t1, &t2);
+      real newcost = gauss_cost(S.x, S.Ma) + ccn;
+      real improvement = scale * (cost - newcost);
+      cost = newcost;
+      SYNC();
+      newton_direction();
+      real gn = 0;
+      PAR(i, nv) gn += S.grad[i] * S.grad[i];
+      gn = WAVE_SUM(gn);
+      if (improvement < tolerance || scale * sqrt(gn) < tolerance) break;
+    }
+    if (UR5_LANE == 0) S.solver_iters += iters;
+    SYNC();
+  }
+
+  // ------------------------------------------------------------------ mj_Euler with implicit joint damping, then the clock [3P, C.5]
+  UR5_BIG void integrate() {
+    const real h = (real)M.timestep;
+    PAR(i, M.nv) {
+      warm()[i] = S.x[i];
+      if (i < M.nrd) { real s = 0; for (int e = 0; e < M.nrd; e++) s += S.Mr[i][e] * S.x[e]; S.tmpv[i] = s; }
+    }
+    SYNC();
+    chol_solve(&S.Ld[0][0], M.nrd, UR5_MAXRD + 1, S.tmpv);
+    PAR(i, M.nv) {
+      if (i < M.nrd) { qvel()[i] += h * S.tmpv[i]; qpos()[i] += h * qvel()[i]; }
+      else {
+        int k = (i - M.nrd) / 6, j = (i - M.nrd) % 6;
+        real md = S.Mobj[i - M.nrd], damp = (real)M.obj_damp[k][j < 3 ? 0 : 1];
+        real acc = damp > 0 ? md * S.x[i] / (md + h * damp) : S.x[i];
+        qvel()[i] += h * acc;
+        if (j < 3) qpos()[M.nrd + 7 * k + j] += h * qvel()[i];
+      }
+    }
+    SYNC();
+    PAR(k, M.nobj) {
+      int va = M.nrd + 6 * k + 3, qa = M.nrd + 7 * k + 3;
+      v3 w(qvel()[va], qvel()[va + 1], qvel()[va + 2]);
+      real ang = norm(w) * h;
+      q4 q{qpos()[qa], qpos()[qa + 1], qpos()[qa + 2], qpos()[qa + 3]};
+      if (ang > 0) {
+        v3 ax = normalized(w);
+        real s = sin((real)0.5 * ang);
+        q = qmul(q, q4{cos((real)0.5 * ang), ax.x * s, ax.y * s, ax.z * s});
+      }
+      q = qnormalize(q);
+      qpos()[qa] = q.w; qpos()[qa + 1] = q.x; qpos()[qa + 2] = q.y; qpos()[qa + 3] = q.z;
+    }
+    if (UR5_LANE == 0) S.rec[UR5_REC_MISC + 2] += h;
+    SYNC();
+  }
+
+  UR5_FN void forward() {
+    kinematics();
+    crb_and_factor();
+    velocity_stage();
+    collision();
+    make_constraints();
+    solve_newton();
+  }
+  UR5_BIG void step() {  // sim.step(), MujocoController.py:379
+    forward();
+    integrate();
+    total_steps++;
+  }
+
+  // ------------------------------------------------------------------ controller layer (MujocoController.py)
+  // :325-329 -- all 7 PIDs are evaluated every iteration; returns max |target - q| over the group
+  UR5_BIG real pid_and_deltas(unsigned mask) {
+    real md = 0;
+    PAR(a, M.nu) {
+      real q = qpos()[M.act_dof[a]];
+      real err = target()[a] - q;
+      real dterm = -(real)M.pid_kd[a] * (q - pid_in()[a]) / pid_dt;
+      real out = clampv(kp()[a] * err + dterm, (real)M.pid_lo[a], (real)M.pid_hi[a]);
+      pid_in()[a] = q; pid_out()[a] = out; ctrl()[a] = out;
+      if (mask >> a & 1u) md = maxv(md, fabs(err));
+    }
+    md = WAVE_MAX(md);
+    SYNC();
+    return md;
+  }
+  UR5_BIG int move_group(unsigned mask, real tol, int max_steps) {  // :269-393; targets already written
+    int steps = 1, result = RES_NONE;
+    bool reached = false;
+    while (!reached) {
+      real md = pid_and_deltas(mask);
+      if (md < tol) { result = RES_SUCCESS; reached = true; }  // no break: one more sim.step() follows (:351-363)
+      if (steps > max_steps) { result = RES_MAX_STEPS; break; }
+      step();
+      steps++;
+    }
+    last_steps = steps;
+    return result;
+  }
+  UR5_FN unsigned mask_all() const { return (1u << M.nu) - 1u; }
+  UR5_FN void set_target(int a, real v) { SYNC(); if (UR5_LANE == 0) target()[a] = v; SYNC(); }
+  UR5_FN void stay_chunks(int chunks) { for (int c = 0; c < chunks; c++) move_group(mask_all(), (real)1e-7, 10); }  // :621-636
+  UR5_FN void stay_ms(real ms) { stay_chunks((int)ceil(ms / (real)1000 / (real)M.timestep / (real)10 - (real)1e-9)); }
+  UR5_FN int open_gripper(bool half) { set_target(6, half ? (real)0 : (real)0.4); return move_group(1u << 6, (real)0.05, 1000); }
+  UR5_FN int close_gripper(int max_steps) { set_target(6, (real)-0.4); return move_group(1u << 6, (real)0.01, max_steps); }
+
+  // ee_link pose for the 6 arm angles; every lane computes it (wave-uniform)
+  UR5_BIG void arm_fk(const real* q6, v3* p, m3* Rout, v3* axes, v3* anchors) const {
+    v3 pos;
+    q4 quat{1, 0, 0, 0};
+    for (int d = 0; d <= M.ee_cbody; d++) {
+      pos = pos + mul(qmat(quat), v3(M.rd_pos[d]));
+      quat = qmul(quat, q4{(real)M.rd_quat[d][0], (real)M.rd_quat[d][1], (real)M.rd_quat[d][2], (real)M.rd_quat[d][3]});
+      m3 Rb = qmat(quat);
+      v3 anchor = pos + mul(Rb, v3(M.rd_jpos[d]));
+      axes[d] = mul(Rb, v3(M.rd_jaxis[d]));
+      anchors[d] = anchor;
+      real a = (real)0.5 * (q6[d] - (real)M.rd_qpos0[d]);
+      real s = sin(a), c = cos(a);
+      quat = qmul(quat, q4{c, (real)M.rd_jaxis[d][0] * s, (real)M.rd_jaxis[d][1] * s, (real)M.rd_jaxis[d][2] * s});
+      pos = anchor - mul(qmat(quat), v3(M.rd_jpos[d]));
+    }
+    m3 R = qmat(qnormalize(quat));
+    *p = pos + mul(R, v3(M.ee_pos));
+    m3 E; E.load(M.ee_mat);
+    *Rout = matmul(R, E);
+  }
+  // :467-517 -- fixed-iteration Levenberg-Marquardt from the home pose, identical to oracle Sim::ik()
+  UR5_BIG bool ik(v3 ee_position, real* out5) const {
+    v3 tgt = ee_position + v3(0, (real)-0.005, (real)0.16);
+    real q[6] = {0, (real)-1.57, (real)1.57, (real)-1.57, (real)-1.57, 0};
+    const real lambda = (real)1e-4;
+    for (int it = 0; it < 60; it++) {
+      v3 p; m3 R; v3 ax[6], an[6];
+      arm_fk(q, &p, &R, ax, an);
+      v3 xe = R.col(0);
+      real r[6] = {p.x - tgt.x, p.y - tgt.y, p.z - tgt.z, xe.x, xe.y, xe.z + 1};
+      real J[6][5];
+      for (int j = 0; j < 5; j++) {
+        v3 dp = cross(ax[j], p - an[j]), dx = cross(ax[j], xe);
+        J[0][j] = dp.x; J[1][j] = dp.y; J[2][j] = dp.z; J[3][j] = dx.x; J[4][j] = dx.y; J[5][j] = dx.z;
+      }
+      real A[5][6];
+      for (int i = 0; i < 5; i++) {
+        for (int j = 0; j < 5; j++) { real s = 0; for (int k = 0; k < 6; k++) s += J[k][i] * J[k][j]; A[i][j] = s; }
+        A[i][i] += lambda;
+        real s = 0; for (int k = 0; k < 6; k++) s += J[k][i] * r[k];
+        A[i][5] = -s;
+      }
+      for (int c = 0; c < 5; c++) {
+        int piv = c;
+        for (int i = c + 1; i < 5; i++) if (fabs(A[i][c]) > fabs(A[piv][c])) piv = i;
+        for (int k = 0; k < 6; k++) { real t = A[c][k]; A[c][k] = A[piv][k]; A[piv][k] = t; }
+        for (int i = c + 1; i < 5; i++) { real f = A[i][c] / A[c][c]; for (int k = c; k < 6; k++) A[i][k] -= f * A[c][k]; }
+      }
+      real dq[5];
+      for (int i = 4; i >= 0; i--) { real s = A[i][5]; for (int k = i + 1; k < 5; k++) s -= A[i][k] * dq[k]; dq[i] = s / A[i][i]; }
+      for (int j = 0; j < 5; j++) q[j] = clampv(q[j] + clampv(dq[j], (real)-0.5, (real)0.5), (real)M.rd_lo[j], (real)M.rd_hi[j]);
+    }
+    v3 p; m3 R; v3 ax[6], an[6];
+    arm_fk(q, &p, &R, ax, an);
+    for (int j = 0; j < 5; j++) out5[j] = q[j];
+    return norm(p - tgt) <= (real)0.02;
+  }
+  UR5_BIG int move_ee(v3 xyz, real tol, int max_steps) {  // :446-465
+    real q5[5];
+    if (!ik(xyz, q5)) { last_steps = 0; return RES_IK_FAIL; }
+    SYNC();
+    if (UR5_LANE == 0) for (int j = 0; j < 5; j++) target()[j] = q5[j];
+    SYNC();
+    return move_group(0x1fu, tol, max_steps);
+  }
+  UR5_FN int rotate_wrist3(real degrees) {  // GraspingEnv.py:193-197
+    set_target(5, degrees * (real)3.14159265358979323846 / (real)180);
+    return move_group(mask_all(), (real)0.05, 500);
+  }
+  UR5_FN void set_kp0(real v) { SYNC(); if (UR5_LANE == 0) kp()[0] = v; SYNC(); }
+
+  // GraspingEnv.py:205-386 (check_mode 1: the IT1 variant of README.md:20); mirrors oracle Sim::grasp_attempt()
+  UR5_BIG int grasp_attempt(v3 coord, int rotation, int check_mode, real table_height, int* ps, int* pr) {
+    const real rot_deg[6] = {0, 30, 60, 90, -30, -60};
+    for (int i = 0; i < 12; i++) { ps[i] = 0; pr[i] = -1; }
+    int result1 = move_ee(v3(coord.x, coord.y, (real)1.1), (real)0.05, 1000);
+    ps[0] = last_steps; pr[0] = result1;
+    if (result1 == RES_IK_FAIL) {
+      result1 = move_ee(v3(0, (real)-0.6, (real)1.1), (real)0.05, 1000);
+      ps[0] = last_steps; pr[0] = result1;
+    }
+    bool result_grasp = false;
+    if (result1 != RES_MAX_STEPS) {
+      pr[1] = rotate_wrist3(rot_deg[rotation]); ps[1] = last_steps;
+      pr[2] = open_gripper(true); ps[2] = last_steps;
+      int result2 = move_ee(v3(coord.x, coord.y, maxv(table_height, coord.z - (real)0.01)), (real)0.01, 300);
+      ps[3] = last_steps; pr[3] = result2;
+      if (result2 != RES_MAX_STEPS) {
+        stay_ms(100);
+        result_grasp = close_gripper(300) != RES_SUCCESS;
+        ps[5] = last_steps; pr[5] = result_grasp ? RES_MAX_STEPS : RES_SUCCESS;
+      }
+    }
+    set_kp0(10);
+    int result_final = -1;
+    if (check_mode == 1) {
+      pr[6] = move_ee(v3(coord.x, coord.y, (real)1.1), (real)0.05, 1000); ps[6] = last_steps;
+      if (result_grasp) { result_final = close_gripper(500); ps[9] = last_steps; pr[9] = result_final; }
+    }
+    pr[7] = move_ee(v3(0, (real)-0.6, (real)1.1), (real)0.05, 1000); ps[7] = last_steps;
+    pr[8] = move_ee(v3((real)0.6, 0, (real)1.15), (real)0.01, 1200); ps[8] = last_steps;
+    if (check_mode == 0 && result_grasp) { result_final = close_gripper(1000); ps[9] = last_steps; pr[9] = result_final; }
+    bool grasped = (result_final == RES_MAX_STEPS) && result_grasp;
+    pr[10] = open_gripper(false); ps[10] = last_steps;
+    if (grasped) stay_ms(200);
+    pr[11] = rotate_wrist3(0); ps[11] = last_steps;
+    set_kp0(20);
+    return grasped ? 1 : 0;
+  }
+
+  // ------------------------------------------------------------------ one launch = one scripted operation per scene
+  UR5_FN void run(const Ur5Launch& P, int env) {
+    int result = RES_NONE;
+    if (P.op == UR5_OP_MOVE) {
+      unsigned mask = P.group_mask[env];
+      SYNC();
+      if (UR5_LANE == 0 && P.target) {
+        int k = 0;
+        for (int a = 0; a < M.nu; a++) if (mask >> a & 1u) { double t = P.target[8 * env + k++]; if (t == t) target()[a] = (real)t; }
+      }
+      SYNC();
+      result = move_group(mask, (real)P.tol[env], P.max_steps[env]);
+    } else if (P.op == UR5_OP_STAY) {
+      stay_chunks(P.max_steps[env]);
+      result = RES_SUCCESS;
+    } else if (P.op == UR5_OP_MOVE_EE) {
+      result = move_ee(v3((real)P.target[8 * env], (real)P.target[8 * env + 1], (real)P.target[8 * env + 2]), (real)P.tol[env], P.max_steps[env]);
+    } else if (P.op == UR5_OP_GRASP) {
+      int ps[12], pr[12];
+      result = grasp_attempt(v3((real)P.target[8 * env], (real)P.target[8 * env + 1], (real)P.target[8 * env + 2]), (int)P.target[8 * env + 3],
+                             P.check_mode, (real)P.table_height, ps, pr);
+      if (UR5_LANE == 0) for (int i = 0; i < 12; i++) { if (P.phase_steps) P.phase_steps[12 * env + i] = ps[i]; if (P.phase_result) P.phase_result[12 * env + i] = pr[i]; }
+    } else if (P.op == UR5_OP_STEP) {
+      int n = P.max_steps[env];
+      for (int i = 0; i < n; i++) step();
+      last_steps = n;
+      result = RES_SUCCESS;
+    } else if (P.op == UR5_OP_FORWARD) {
+      forward();
+      if (P.debug) dump(P.debug + (size_t)UR5_DEBUG_STRIDE * env);
+      result = RES_SUCCESS;
+    }
+    if (UR5_LANE == 0) {
+      if (P.result) P.result[env] = result;
+      if (P.steps) P.steps[env] = last_steps;
+    }
+  }
+
+  // introspection for the parity tests: [0] ncon, [1] nsr, [2..] fixed sections (see tests/test_parity_forward.py)
+  UR5_BIG void dump(double* out) {
+    SYNC();
+    if (UR5_LANE != 0) return;
+    int o = 0;
+    out[o++] = S.ncon; out[o++] = S.nsr; out[o++] = S.solver_iters; out[o++] = S.status;
+    o = 8;
+    for (int b = 0; b < UR5_MAXB; b++) for (int k = 0; k < 3; k++) out[o++] = b < nb() ? (double)S.bpos[b][k] : 0;      // 8   .. 50
+    for (int d = 0; d < UR5_MAXRD; d++) for (int e = 0; e < UR5_MAXRD; e++) out[o++] = (double)S.Mr[d][e];               // 50  .. 114
+    for (int i = 0; i < UR5_MAXNV; i++) out[o++] = i < M.nv ? (double)S.fs[i] : 0;                                      // 114 .. 158
+    for (int i = 0; i < UR5_MAXNV; i++) out[o++] = i < M.nv ? (double)S.as[i] : 0;                                      // 158 .. 202
+    for (int i = 0; i < UR5_MAXNV; i++) out[o++] = i < M.nv ? (double)S.x[i] : 0;                                       // 202 .. 246
+    for (int c = 0; c < UR5_MAXCON; c++) {                                                                             // 246 .. 246+32*10
+      bool ok = c < S.ncon;
+      out[o++] = ok ? (double)S.cdist[c] : 0;
+      for (int k = 0; k < 3; k++) out[o++] = ok ? (double)S.cpos[c][k] : 0;
+      for (int k = 0; k < 3; k++) out[o++] = ok ? (double)S.cframe[c][k] : 0;
+      out[o++] = ok ? S.cg1[c] : -1; out[o++] = ok ? S.cg2[c] : -1;
+      out[o++] = ok ? (double)S.cfb[c][0] : 0;
+    }
+  }
+};
+
+}  // namespace ur5

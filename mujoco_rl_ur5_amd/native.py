@@ -1,0 +1,213 @@
+"""ctypes binding of the C ABI in include/ur5sim.h (libur5sim.so, built from csrc/ by __graft_entry__.build()).
+
+The loader opens ONLY ``mujoco_rl_ur5_amd/csrc/libur5sim.so`` and raises when it is missing or when no GPU answers:
+there is no CPU fallback in the product path. (Tests may hand an explicit library path to :class:`BatchSim` to run the
+lane-emulation build of the same engine source; nothing in this package does.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "csrc", "libur5sim.so")
+
+RES_NONE, RES_SUCCESS, RES_MAX_STEPS, RES_IK_FAIL = -1, 0, 1, 2
+DEBUG_STRIDE, REC_STRIDE, MAXB = 2048, 192, 14
+EXPORTS = ["ur5_last_error", "ur5_create", "ur5_destroy", "ur5_num_envs", "ur5_nq", "ur5_nv", "ur5_nu", "ur5_reset",
+           "ur5_set_state", "ur5_get_state", "ur5_set_ctrl", "ur5_get_ctrl", "ur5_step", "ur5_move_group", "ur5_stay",
+           "ur5_move_ee", "ur5_grasp_attempt", "ur5_grasp_attempt_dev", "ur5_sync", "ur5_last_launch_ms",
+           "ur5_get_counters", "ur5_body_xpos", "ur5_state_device_ptr", "ur5_forward_debug"]
+
+
+class Config(C.Structure):
+    _fields_ = [("ee_body", C.c_int), ("contacts_enabled", C.c_int), ("pid_dt", C.c_double)]
+
+
+_libs = {}
+
+
+def load(path=None):
+    path = path or DEFAULT_LIB
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; "
+                           "g.build()'). There is no CPU fallback.")
+    L = C.CDLL(path)
+    dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p
+    L.ur5_last_error.restype = C.c_char_p
+    L.ur5_create.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(Config), C.POINTER(vp)]
+    L.ur5_destroy.argtypes = [vp]
+    L.ur5_destroy.restype = None
+    for f in ("ur5_num_envs", "ur5_nq", "ur5_nv", "ur5_nu", "ur5_sync"):
+        getattr(L, f).argtypes = [vp]
+    L.ur5_reset.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int, C.c_double]
+    L.ur5_set_state.argtypes = [vp, dp, dp, dp, dp]
+    L.ur5_get_state.argtypes = [vp, dp, dp, dp, dp]
+    L.ur5_set_ctrl.argtypes = [vp, dp]
+    L.ur5_get_ctrl.argtypes = [vp, dp]
+    L.ur5_step.argtypes = [vp, C.c_int]
+    L.ur5_move_group.argtypes = [vp, C.POINTER(C.c_uint32), dp, dp, ip, ip, ip]
+    L.ur5_stay.argtypes = [vp, C.c_double]
+    L.ur5_move_ee.argtypes = [vp, dp, dp, ip, ip, ip]
+    L.ur5_grasp_attempt.argtypes = [vp, dp, C.c_int, C.c_double, ip, ip, ip]
+    L.ur5_grasp_attempt_dev.argtypes = [vp, vp, C.c_int, C.c_double, vp]
+    L.ur5_last_launch_ms.argtypes = [vp]
+    L.ur5_last_launch_ms.restype = C.c_double
+    L.ur5_get_counters.argtypes = [vp, C.POINTER(C.c_int64)]
+    L.ur5_body_xpos.argtypes = [vp, dp]
+    L.ur5_state_device_ptr.argtypes = [vp]
+    L.ur5_state_device_ptr.restype = vp
+    L.ur5_forward_debug.argtypes = [vp, dp]
+    _libs[path] = L
+    return L
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+class BatchSim:
+    """N independent scenes on one GPU. Thin, array-in/array-out mirror of the C ABI."""
+
+    def __init__(self, model, n_env, device_id=0, contacts_enabled=True, pid_dt=0.0, lib_path=None):
+        self.lib = load(lib_path)
+        self.model = model
+        self.n = int(n_env)
+        blob = model.to_blob()
+        cfg = Config(model.body_name2id("ee_link"), int(bool(contacts_enabled)), float(pid_dt))
+        h = C.c_void_p()
+        rc = self.lib.ur5_create(blob, len(blob), self.n, int(device_id), C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"ur5_create failed ({rc}): {self.lib.ur5_last_error().decode()}")
+        self._h = h
+        self.nq, self.nv, self.nu = model.nq, model.nv, model.nu
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.ur5_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed ({rc}): {self.lib.ur5_last_error().decode()}")
+
+    def _full(self, v, dtype):
+        a = np.asarray(v, dtype=dtype)
+        return np.ascontiguousarray(np.broadcast_to(a, (self.n,) + a.shape[1:] if a.ndim else (self.n,)).copy()) if a.ndim == 0 or a.shape[0] != self.n \
+            else np.ascontiguousarray(a)
+
+    # ---- state
+    def reset(self, seeds, mode=1, settle_ms=1000.0):
+        s = np.ascontiguousarray(np.broadcast_to(np.asarray(seeds, dtype=np.uint64), (self.n,)).copy())
+        self._check(self.lib.ur5_reset(self._h, s.ctypes.data_as(C.POINTER(C.c_uint64)), mode, float(settle_ms)), "ur5_reset")
+
+    def get_state(self):
+        qpos, qvel, warm = np.zeros((self.n, self.nq)), np.zeros((self.n, self.nv)), np.zeros((self.n, self.nv))
+        pid = np.zeros((self.n, self.nu, 4))
+        self._check(self.lib.ur5_get_state(self._h, _dp(qpos), _dp(qvel), _dp(warm), _dp(pid)), "ur5_get_state")
+        return dict(qpos=qpos, qvel=qvel, warmstart=warm, pid=pid)
+
+    def set_state(self, qpos=None, qvel=None, warmstart=None, pid=None):
+        def prep(a, shape):
+            if a is None:
+                return None
+            a = np.asarray(a, dtype=np.float64)
+            return np.ascontiguousarray(np.broadcast_to(a, shape).copy())
+        arrs = [prep(qpos, (self.n, self.nq)), prep(qvel, (self.n, self.nv)), prep(warmstart, (self.n, self.nv)),
+                prep(pid, (self.n, self.nu, 4))]
+        self._check(self.lib.ur5_set_state(self._h, *[_dp(a) for a in arrs]), "ur5_set_state")
+
+    def set_ctrl(self, ctrl):
+        c = np.ascontiguousarray(np.broadcast_to(np.asarray(ctrl, dtype=np.float64), (self.n, self.nu)).copy())
+        self._check(self.lib.ur5_set_ctrl(self._h, _dp(c)), "ur5_set_ctrl")
+
+    def get_ctrl(self):
+        c = np.zeros((self.n, self.nu))
+        self._check(self.lib.ur5_get_ctrl(self._h, _dp(c)), "ur5_get_ctrl")
+        return c
+
+    def counters(self):
+        c = np.zeros((self.n, 4), dtype=np.int64)
+        self._check(self.lib.ur5_get_counters(self._h, c.ctypes.data_as(C.POINTER(C.c_int64))), "ur5_get_counters")
+        return dict(total_steps=c[:, 0], last_steps=c[:, 1], status=c[:, 2], solver_iters=c[:, 3])
+
+    # ---- dynamics
+    def step(self, nsteps=1):
+        self._check(self.lib.ur5_step(self._h, int(nsteps)), "ur5_step")
+
+    def move_group(self, mask, target, tol, max_steps):
+        mask = np.ascontiguousarray(np.broadcast_to(np.asarray(mask, dtype=np.uint32), (self.n,)).copy())
+        tgt = None
+        if target is not None:
+            t = np.asarray(target, dtype=np.float64)
+            t = np.broadcast_to(t, (self.n, t.shape[-1]))
+            tgt = np.full((self.n, 8), np.nan)
+            tgt[:, :t.shape[1]] = t
+        tol = np.ascontiguousarray(np.broadcast_to(np.asarray(tol, dtype=np.float64), (self.n,)).copy())
+        mx = np.ascontiguousarray(np.broadcast_to(np.asarray(max_steps, dtype=np.int32), (self.n,)).copy())
+        res, steps = np.zeros(self.n, dtype=np.int32), np.zeros(self.n, dtype=np.int32)
+        self._check(self.lib.ur5_move_group(self._h, mask.ctypes.data_as(C.POINTER(C.c_uint32)), _dp(tgt), _dp(tol), _ip(mx),
+                                            _ip(res), _ip(steps)), "ur5_move_group")
+        return res, steps
+
+    def stay(self, ms):
+        self._check(self.lib.ur5_stay(self._h, float(ms)), "ur5_stay")
+
+    def move_ee(self, xyz, tol, max_steps):
+        x = np.ascontiguousarray(np.broadcast_to(np.asarray(xyz, dtype=np.float64), (self.n, 3)).copy())
+        tol = np.ascontiguousarray(np.broadcast_to(np.asarray(tol, dtype=np.float64), (self.n,)).copy())
+        mx = np.ascontiguousarray(np.broadcast_to(np.asarray(max_steps, dtype=np.int32), (self.n,)).copy())
+        res, steps = np.zeros(self.n, dtype=np.int32), np.zeros(self.n, dtype=np.int32)
+        self._check(self.lib.ur5_move_ee(self._h, _dp(x), _dp(tol), _ip(mx), _ip(res), _ip(steps)), "ur5_move_ee")
+        return res, steps
+
+    def grasp_attempt(self, xyz, rot=0, check_mode=0, table_height=0.91):
+        a = np.zeros((self.n, 4))
+        a[:, :3] = np.broadcast_to(np.asarray(xyz, dtype=np.float64), (self.n, 3))
+        a[:, 3] = np.broadcast_to(np.asarray(rot, dtype=np.float64), (self.n,))
+        rew = np.zeros(self.n, dtype=np.int32)
+        ps, pr = np.zeros((self.n, 12), dtype=np.int32), np.zeros((self.n, 12), dtype=np.int32)
+        self._check(self.lib.ur5_grasp_attempt(self._h, _dp(a), int(check_mode), float(table_height), _ip(rew), _ip(ps), _ip(pr)),
+                    "ur5_grasp_attempt")
+        return rew, ps, pr
+
+    def grasp_attempt_dev(self, action_ptr, reward_ptr, check_mode=0, table_height=0.91):
+        """Asynchronous; action_ptr -> [n][8] float64, reward_ptr -> [n] int32, both HIP device pointers."""
+        self._check(self.lib.ur5_grasp_attempt_dev(self._h, C.c_void_p(action_ptr), int(check_mode), float(table_height),
+                                                   C.c_void_p(reward_ptr)), "ur5_grasp_attempt_dev")
+
+    def sync(self):
+        self._check(self.lib.ur5_sync(self._h), "ur5_sync")
+
+    def last_launch_ms(self):
+        return float(self.lib.ur5_last_launch_ms(self._h))
+
+    def state_device_ptr(self):
+        return self.lib.ur5_state_device_ptr(self._h)
+
+    def body_xpos(self):
+        out = np.zeros((self.n, MAXB, 3))
+        self._check(self.lib.ur5_body_xpos(self._h, _dp(out)), "ur5_body_xpos")
+        return out
+
+    def forward_debug(self):
+        out = np.zeros((self.n, DEBUG_STRIDE))
+        self._check(self.lib.ur5_forward_debug(self._h, _dp(out)), "ur5_forward_debug")
+        d = dict(ncon=out[:, 0].astype(int), nsr=out[:, 1].astype(int), bpos=out[:, 8:50].reshape(self.n, 14, 3),
+                 Mr=out[:, 50:114].reshape(self.n, 8, 8), qfrc_smooth=out[:, 114:158], qacc_smooth=out[:, 158:202],
+                 qacc=out[:, 202:246], contacts=out[:, 246:246 + 320].reshape(self.n, 32, 10))
+        return d

@@ -1,0 +1,33 @@
+// ur5sim_emul.cpp -- TEST-ONLY build of the engine: compiles csrc/ur5_engine.h with -DUR5_EMUL so that the 64 lanes of
+// each wavefront run sequentially on the host. Lets `pytest -m "not gpu"` exercise the kernel source against the oracle
+// without a GPU. Built into tests/emul/_build/ by tests/conftest.py; the package loader (mujoco_rl_ur5_amd/native.py)
+// only ever opens csrc/libur5sim.so, so this can never stand in for the HIP path.
+#define UR5_EMUL 1
+#include <cstdlib>
+#include "../../mujoco_rl_ur5_amd/csrc/ur5_engine.h"
+#include "../../mujoco_rl_ur5_amd/csrc/ur5sim_host.h"
+
+static int be_open(ur5_sim*, int) { return 0; }
+static void be_close(ur5_sim*) {}
+static void* be_alloc(ur5_sim*, size_t bytes) { return calloc(1, bytes); }
+static void be_free(ur5_sim*, void* p) { free(p); }
+static int be_h2d(ur5_sim*, void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); return 0; }
+static int be_d2h(ur5_sim*, void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); return 0; }
+static int be_sync(ur5_sim*) { return 0; }
+
+template <int NV> static void run_all(ur5_sim* h, const Ur5Launch& P) {
+  typedef ur5::Lds<double, NV> L;
+  L* lds = new L();
+  for (int e = 0; e < h->n; e++) {
+    memset((void*)lds, 0, sizeof(L));
+    ur5::Engine<double, NV> eng(*lds, *h->dm, P.pid_dt, P.contacts_enabled);
+    eng.load(h->d_rec + (size_t)e * UR5_REC_STRIDE);
+    eng.run(P, e);
+    eng.save(h->d_rec + (size_t)e * UR5_REC_STRIDE);
+  }
+  delete lds;
+}
+static int be_launch(ur5_sim* h, const Ur5Launch& P) {
+  if (h->nvt == 32) run_all<32>(h, P); else run_all<UR5_MAXNV>(h, P);
+  return 0;
+}
