@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json config 2): 4096 batched IT1 scenes per MI355X, physics only, fixed-z grasp attempts
+with the 500-step closing check (README.md:20 of the reference). A "step" is one grasp-attempt round over the whole batch
+= one launch of the hot path (GraspEnv.step -> move_and_grasp, GraspingEnv.py:62-156,205-386) on every scene.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0. value = env-steps/s of the whole job (2 ms physics steps actually executed, summed over all
+scenes and ranks, / max-over-ranks wall time of the K timed rounds); grasp-attempts/s is reported next to it.
+Inputs (actions) are resident in HBM before the timed region; rewards stay on the device. N > 1: scenes shard over ranks
+(4096 per GPU, weak scaling, seeds keyed by global scene id) and every round ends with ONE RCCL all_gather of the 16-byte
+outcome records (mujoco_rl_ur5_amd/sharding.py), inside the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def aimed_actions(qpos, first_id, round_idx, nobj=4):
+    """Synthetic input: scene g aims at the settled position of object (g + round) % nobj, z = 0.91."""
+    n = qpos.shape[0]
+    a = np.zeros((n, 8))
+    for e in range(n):
+        objs = qpos[e][8:].reshape(-1, 7)
+        k = (first_id + e + round_idx) % nobj
+        a[e, :3] = [objs[k, 0], -0.6 + objs[k, 1], 0.91]
+        a[e, 3] = ((first_id + e) // nobj + round_idx) % 6
+    return a
+
+
+def cpu_baseline(model, budget_s=12.0):
+    """The fp64 oracle (a port: the reference's own MuJoCo binary cannot exist here) on ONE host core, same scenes/actions."""
+    from oracle.oracle import Oracle
+    t_used, steps, attempts = 0.0, 0, 0
+    g = 0
+    while t_used < budget_s:
+        o = Oracle(model)
+        o.reset(20 + g, 1, True)
+        a = aimed_actions(o.get_state()["qpos"][None, :], g, 0)[0]
+        n0 = o.total_steps
+        t0 = time.perf_counter()
+        o.grasp_attempt(a[:3], int(a[3]), 1)
+        t_used += time.perf_counter() - t0
+        steps += o.total_steps - n0
+        attempts += 1
+        g += 1
+    return dict(value=steps / t_used, unit="env-steps/s", cores=1, kind="port",
+                sample=f"{attempts} IT1 grasp attempts ({steps} physics steps) of scenes 0..{attempts - 1}, oracle/ur5_oracle.cpp, "
+                       f"{t_used:.1f} s on one core of {os.cpu_count()}",
+                grasp_attempts_per_s=attempts / t_used)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--envs", type=int, default=4096, help="scenes per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from mujoco_rl_ur5_amd import sharding
+    from mujoco_rl_ur5_amd.model import load_model
+    from mujoco_rl_ur5_amd.native import BatchSim
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    model = load_model("it1_4box")
+    n_local = args.envs
+    n_total = n_local * world
+    lo, hi = sharding.shard_range(n_total, rank, world)
+    sim = BatchSim(model, n_local, device_id=local_rank)
+    sim.reset(sharding.global_seeds(20, n_total, rank, world), 1, 1000.0)          # GraspingEnv.py:409-477, untimed
+    settled = sim.get_state()["qpos"]
+    rounds = args.warmup + args.steps
+    actions = torch.from_numpy(np.stack([aimed_actions(settled, lo, r) for r in range(rounds)])).to(dev)   # [rounds, n, 8] f64 in HBM
+    reward = torch.zeros((rounds, n_local), dtype=torch.int32, device=dev)
+    ids = torch.arange(lo, hi, dtype=torch.int32, device=dev)
+
+    def one_round(r):
+        sim.grasp_attempt_dev(actions[r].data_ptr(), reward[r].data_ptr(), check_mode=1, table_height=0.91)
+        sim.sync()                                                             # handle stream -> host; rewards now valid
+        rec = torch.stack([ids, torch.zeros_like(ids), actions[r, :, 3].to(torch.int32), reward[r]], dim=1)
+        return sharding.gather_outcomes(rec), sim.last_launch_ms()
+
+    for r in range(args.warmup):
+        one_round(r)
+    c0 = sim.counters()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kernel_ms = []
+    for r in range(args.warmup, rounds):
+        _, ms = one_round(r)
+        kernel_ms.append(ms)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    c1 = sim.counters()
+    steps_local = int((c1["total_steps"] - c0["total_steps"]).sum())
+    stats = torch.tensor([elapsed, float(steps_local), float(reward[args.warmup:].sum().item())], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = stats[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tot = stats[1:].clone()
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        elapsed, steps_all, succ_all = float(tmax[0]), float(tot[0]), float(tot[1])
+    else:
+        steps_all, succ_all = float(steps_local), float(stats[2])
+    if rank == 0:
+        attempts = args.steps * n_total
+        # algorithmic HBM bytes per env-step: (nq + 2 nv + 5 nu + 8) words, read + written, fp64
+        words = model.nq + 2 * model.nv + 5 * model.nu + 8
+        bytes_per_step = 2 * words * 8
+        k_s = sum(kernel_ms) * 1e-3
+        achieved = steps_local * bytes_per_step / k_s / 1e9
+        out = {
+            "metric": "env-steps/sec (+ grasp-attempts/sec), 4096 parallel UR5 scenes per MI355X",
+            "value": steps_all / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "grasp_attempts_per_s": attempts / elapsed, "grasp_success_rate": succ_all / attempts,
+            "env_steps_per_attempt": steps_all / attempts,
+            "newton_iters_per_step": float((c1["solver_iters"] - c0["solver_iters"]).sum()) / max(1, steps_local),
+            "status_bits": int(np.bitwise_or.reduce(c1["status"])),
+            "config": {"workload": "BASELINE.json configs[1]: IT1 (UR5gripper_2_finger.xml robot + bins, 4 equal 4 cm boxes), physics only, "
+                                   "fixed z = 0.91, lift + 500-step closing check, one grasp-attempt round per step",
+                       "scenes_per_gpu": n_local, "scenes_total": n_total, "solver": "Newton (MuJoCo default), tol 1e-10",
+                       "timestep_s": model.opt["timestep"], "parallelism": f"scenes sharded x{world}, 1 all_gather of 16 B outcome records per round"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                         "kernel": "ur5_run_kernel<32>", "bytes_per_env_step": bytes_per_step,
+                         "avg_launch_ms": float(np.mean(kernel_ms)), "env_steps_per_launch": steps_local / args.steps,
+                         "note": "algorithmic state bytes x env-steps / HIP-event kernel time on the handle's stream (rank 0). The kernel keeps a "
+                                 "scene in LDS for a whole grasp attempt, so real HBM traffic is far below the algorithmic figure; the step is "
+                                 "latency/VALU bound (DESIGN.md)"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -13,6 +13,7 @@
  *   ur5_move_group        MJ_Controller.move_group_to_joint_target  MujocoController.py:269-393
  *   ur5_stay              MJ_Controller.stay                        MujocoController.py:621-636 (deterministic: 10-step chunks)
  *   ur5_move_ee           MJ_Controller.move_ee + ik                MujocoController.py:446-517
+ *   ur5_ik                MJ_Controller.ik                          MujocoController.py:467-517
  *   ur5_grasp_attempt     GraspEnv.move_and_grasp                   GraspingEnv.py:205-386
  *   ur5_body_xpos         sim.data.body_xpos[...]                   MujocoController.py:341,488
  *
@@ -62,6 +63,8 @@ int ur5_move_group(ur5_sim* h, const uint32_t* mask, const double* target, const
                    int* result, int* steps);
 int ur5_stay(ur5_sim* h, double ms);
 int ur5_move_ee(ur5_sim* h, const double* xyz /* [n][3] */, const double* tol, const int* max_steps, int* result, int* steps);
+/* q5[n][5] arm joint angles; result[n] = UR5_RES_SUCCESS or UR5_RES_IK_FAIL (FK(IK) further than 2 cm from the target) */
+int ur5_ik(ur5_sim* h, const double* xyz /* [n][3] */, double* q5, int* result);
 /* action[n][4] = world x, y, z, rotation index 0..5 (GraspingEnv.py:40). check_mode 0 = in-tree script, 1 = IT1. */
 int ur5_grasp_attempt(ur5_sim* h, const double* action, int check_mode, double table_height, int* reward,
                       int* phase_steps /* [n][12] or NULL */, int* phase_result /* [n][12] or NULL */);

@@ -78,7 +78,7 @@ struct Ur5DevModel {
 };
 
 // run-time parameters of one launch (wave-uniform unless per-env arrays are given)
-enum { UR5_OP_MOVE = 0, UR5_OP_STAY = 1, UR5_OP_MOVE_EE = 2, UR5_OP_GRASP = 3, UR5_OP_STEP = 4, UR5_OP_FORWARD = 5 };
+enum { UR5_OP_MOVE = 0, UR5_OP_STAY = 1, UR5_OP_MOVE_EE = 2, UR5_OP_GRASP = 3, UR5_OP_STEP = 4, UR5_OP_FORWARD = 5, UR5_OP_IK = 6 };
 struct Ur5Launch {
   int op, n_env, contacts_enabled, check_mode;
   double pid_dt, table_height;
@@ -92,6 +92,7 @@ struct Ur5Launch {
   int* steps;                   // [n]
   int* phase_steps;             // [n][12] (GRASP)
   int* phase_result;            // [n][12]
+  double* out;                  // [n][8] (IK: 5 joint angles)
   double* debug;                // optional [n][UR5_DEBUG_STRIDE] introspection dump (FORWARD)
 };
 #define UR5_DEBUG_STRIDE 2048

@@ -53,6 +53,19 @@ template <class T> __device__ __forceinline__ T ur5_wave_max(T v) {
 #define WAVE_MAX(v) ur5_wave_max(v)
 #endif
 
+// optional per-phase cycle accounting (-DUR5_PROFILE builds libur5sim_prof.so; never defined for the product library)
+#if defined(UR5_PROFILE) && !defined(UR5_EMUL)
+#define PROF_T0() unsigned long long prof_t_ = __builtin_readcyclecounter()
+#define PROF_RE() prof_t_ = __builtin_readcyclecounter()
+#define PROF(id) do { unsigned long long n_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) S.prof[id] += (double)(n_ - prof_t_); prof_t_ = n_; } while (0)
+#else
+#define PROF_T0() ((void)0)
+#define PROF_RE() ((void)0)
+#define PROF(id) ((void)0)
+#endif
+enum { PF_KIN = 0, PF_CRB, PF_VEL, PF_BROAD, PF_NARROW, PF_ROWS, PF_NEWTON_INIT, PF_IMAGES, PF_LINESEARCH, PF_GRADG, PF_HASM, PF_CHOL, PF_SOLVE,
+       PF_INTEGRATE, PF_PID, PF_IK, PF_COUNT };
+
 namespace ur5 {
 
 enum { RES_NONE = -1, RES_SUCCESS = 0, RES_MAX_STEPS = 1, RES_IK_FAIL = 2 };
@@ -150,6 +163,7 @@ template <class real, int NV_> struct Lds {
   real tw[UR5_MAXB][6], WB[UR5_MAXB][6], G[UR5_MAXB][21];
   real H[NV_ * (NV_ + 1)];
   real scal[16];
+  double prof[PF_COUNT];
   int status, solver_iters, ncon_max;
 };
 
@@ -181,7 +195,7 @@ template <class real, int NV_> struct Engine {
 
   UR5_FN void load(const double* rec) {
     PAR(i, UR5_REC_STRIDE) S.rec[i] = (real)rec[i];
-    if (UR5_LANE == 0) { S.status = 0; S.solver_iters = 0; S.ncon_max = 0; S.ncon = 0; S.nsr = 0; }
+    if (UR5_LANE == 0) { S.status = 0; S.solver_iters = 0; S.ncon_max = 0; S.ncon = 0; S.nsr = 0; for (int i = 0; i < PF_COUNT; i++) S.prof[i] = 0; }
     SYNC();
     S.status = (int)S.rec[UR5_REC_MISC + 3];
   }
@@ -699,6 +713,7 @@ template <class real, int NV_> struct Engine {
     if (UR5_LANE == 0) { S.ncon = 0; S.ncand = 0; }
     SYNC();
     if (!contacts_enabled) return;
+    PROF_T0();
     // broad phase: ordered compaction of the surviving pairs
     int ncand = 0;
     for (int p0 = 0; p0 < M.npair; p0 += 64) {
@@ -724,6 +739,7 @@ template <class real, int NV_> struct Engine {
 #endif
     }
     SYNC();
+    PROF(PF_BROAD);
     // narrow phase: one candidate per lane; contact slots are handed out in candidate order
     int base = 0;
     {
@@ -776,6 +792,7 @@ template <class real, int NV_> struct Engine {
       if (n > S.ncon_max) S.ncon_max = n;
     }
     SYNC();
+    PROF(PF_NARROW);
   }
 
   // ------------------------------------------------------------------ constraint rows (mj_makeConstraint + mj_makeImpedance [3P])
@@ -979,6 +996,7 @@ template <class real, int NV_> struct Engine {
   }
   // gradient and Newton direction at S.x (images in S.ce / S.sr_jar must be current): S.search = -H^-1 grad
   UR5_BIG void newton_direction() {
+    PROF_T0();
     const int nbod = nb();
     PAR(c, S.ncon) {  // base forces and the "arrow" weight matrix of each contact
       real D = S.cD[c], e0 = S.ce[c][0];
@@ -1058,6 +1076,7 @@ template <class real, int NV_> struct Engine {
       S.grad[i] = S.Ma[i] - S.fs[i] - jf;
       S.search[i] = S.grad[i];
     }
+    PROF(PF_GRADG);
     // Hessian, lower triangle
     const int nv = M.nv, LD = L::LD;
     PAR(idx, nv * nv) { int i = idx / nv, j = idx % nv; if (j <= i) S.H[i * LD + j] = 0; }
@@ -1121,10 +1140,12 @@ template <class real, int NV_> struct Engine {
       }
       SYNC();
     }
-    cholesky(S.H, nv, LD);
+    PROF(PF_HASM);
+    cholesky(S.H, nv, LD); PROF(PF_CHOL);
     chol_solve(S.H, nv, LD, S.search);
     PAR(i, nv) S.search[i] = -S.search[i];
     SYNC();
+    PROF(PF_SOLVE);
   }
 
   UR5_BIG void solve_newton() {
@@ -1134,8 +1155,9 @@ template <class real, int NV_> struct Engine {
       SYNC();
       return;
     }
+    PROF_T0();
     // warm start: cheaper of qacc_warmstart and qacc_smooth
-    real dummy1, dummy2, ccw, ccs;
+    real dummy1, dummy2, ccw;
     PAR(i, nv) S.x[i] = warm()[i];
     SYNC();
     mat_vec_M(S.x, S.Ma);
@@ -1176,12 +1198,15 @@ template <class real, int NV_> struct Engine {
     }
     const real scale = (real)1 / ((real)M.meaninertia * (real)(nv > 1 ? nv : 1));
     const real tolerance = (real)M.tolerance;
+    PROF(PF_NEWTON_INIT);
     newton_direction();
     int iters = 0;
     for (int it = 0; it < M.iterations; it++) {
       iters = it + 1;
+      PROF_T0();
       mat_vec_M(S.search, S.Mv);
       images(S.search, false, S.cde, S.sr_jv);
+      PROF(PF_IMAGES);
       real q1 = 0, q2 = 0, sn = 0;
       PAR(i, nv) { q1 += S.search[i] * (S.Ma[i] - S.fs[i]); q2 += S.search[i] * S.Mv[i]; sn += S.search[i] * S.search[i]; }
       q1 = WAVE_SUM(q1); q2 = WAVE_SUM(q2); sn = sqrt(WAVE_SUM(sn));
@@ -1217,6 +1242,7 @@ template <class real, int NV_> struct Engine {
       real improvement = scale * (cost - newcost);
       cost = newcost;
       SYNC();
+      PROF(PF_LINESEARCH);
       newton_direction();
       real gn = 0;
       PAR(i, nv) gn += S.grad[i] * S.grad[i];
@@ -1265,22 +1291,26 @@ template <class real, int NV_> struct Engine {
   }
 
   UR5_FN void forward() {
-    kinematics();
-    crb_and_factor();
-    velocity_stage();
+    PROF_T0();
+    kinematics(); PROF(PF_KIN);
+    crb_and_factor(); PROF(PF_CRB);
+    velocity_stage(); PROF(PF_VEL);
     collision();
-    make_constraints();
+    PROF_RE();
+    make_constraints(); PROF(PF_ROWS);
     solve_newton();
   }
   UR5_BIG void step() {  // sim.step(), MujocoController.py:379
     forward();
-    integrate();
+    PROF_T0();
+    integrate(); PROF(PF_INTEGRATE);
     total_steps++;
   }
 
   // ------------------------------------------------------------------ controller layer (MujocoController.py)
   // :325-329 -- all 7 PIDs are evaluated every iteration; returns max |target - q| over the group
   UR5_BIG real pid_and_deltas(unsigned mask) {
+    PROF_T0();
     real md = 0;
     PAR(a, M.nu) {
       real q = qpos()[M.act_dof[a]];
@@ -1292,6 +1322,7 @@ template <class real, int NV_> struct Engine {
     }
     md = WAVE_MAX(md);
     SYNC();
+    PROF(PF_PID);
     return md;
   }
   UR5_BIG int move_group(unsigned mask, real tol, int max_steps) {  // :269-393; targets already written
@@ -1452,6 +1483,11 @@ template <class real, int NV_> struct Engine {
       for (int i = 0; i < n; i++) step();
       last_steps = n;
       result = RES_SUCCESS;
+    } else if (P.op == UR5_OP_IK) {
+      real q5[5];
+      bool ok = ik(v3((real)P.target[8 * env], (real)P.target[8 * env + 1], (real)P.target[8 * env + 2]), q5);
+      if (UR5_LANE == 0 && P.out) for (int j = 0; j < 5; j++) P.out[8 * env + j] = (double)q5[j];
+      result = ok ? RES_SUCCESS : RES_IK_FAIL;
     } else if (P.op == UR5_OP_FORWARD) {
       forward();
       if (P.debug) dump(P.debug + (size_t)UR5_DEBUG_STRIDE * env);
@@ -1460,6 +1496,9 @@ template <class real, int NV_> struct Engine {
     if (UR5_LANE == 0) {
       if (P.result) P.result[env] = result;
       if (P.steps) P.steps[env] = last_steps;
+#if defined(UR5_PROFILE) && !defined(UR5_EMUL)
+      if (P.debug && P.op != UR5_OP_FORWARD) for (int i = 0; i < PF_COUNT; i++) P.debug[(size_t)UR5_DEBUG_STRIDE * env + i] = S.prof[i];
+#endif
     }
   }
 

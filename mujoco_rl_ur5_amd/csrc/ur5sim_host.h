@@ -375,6 +375,10 @@ static Ur5Launch base_launch(ur5_sim* h, int op) {
   Ur5Launch P;
   memset(&P, 0, sizeof P);
   P.op = op; P.n_env = h->n; P.contacts_enabled = h->contacts_enabled; P.pid_dt = h->pid_dt; P.table_height = 0.91;
+#ifdef UR5_PROFILE
+  if (!h->d_debug) h->d_debug = (double*)be_alloc(h, (size_t)h->n * UR5_DEBUG_STRIDE * 8);
+  P.debug = h->d_debug;
+#endif
   return P;
 }
 template <class T> static int upload(ur5_sim* h, T* dst, const T* src, size_t count) { return be_h2d(h, dst, src, count * sizeof(T)); }
@@ -611,6 +615,22 @@ int ur5_grasp_attempt(ur5_sim* h, const double* action, int check_mode, double t
   if (!rc && phase_result) rc = be_d2h(h, phase_result, h->d_pr, (size_t)h->n * 48);
   return rc;
 }
+int ur5_ik(ur5_sim* h, const double* xyz, double* q5, int* result) {
+  using namespace ur5host;
+  if (!xyz || !q5) return fail(UR5_ERR_ARG, "ur5_ik: xyz/q5 are required");
+  std::vector<double> t((size_t)h->n * 8, 0.0);
+  for (int e = 0; e < h->n; e++) for (int k = 0; k < 3; k++) t[8 * e + k] = xyz[3 * e + k];
+  int rc = upload(h, h->d_target, t.data(), t.size());
+  if (rc) return rc;
+  Ur5Launch P = base_launch(h, UR5_OP_IK);
+  P.target = h->d_target; P.out = h->d_target; P.result = h->d_result;
+  rc = be_launch(h, P);
+  if (!rc) rc = be_sync(h);
+  if (!rc) rc = be_d2h(h, t.data(), h->d_target, t.size() * 8);
+  if (!rc && result) rc = be_d2h(h, result, h->d_result, (size_t)h->n * 4);
+  if (!rc) for (int e = 0; e < h->n; e++) for (int k = 0; k < 5; k++) q5[5 * e + k] = t[8 * e + k];
+  return rc;
+}
 int ur5_sync(ur5_sim* h) { return be_sync(h); }
 double ur5_last_launch_ms(ur5_sim* h) { return h->last_ms; }
 void* ur5_state_device_ptr(ur5_sim* h) { return h->d_rec; }
@@ -626,6 +646,16 @@ int ur5_forward_debug(ur5_sim* h, double* out) {
   if (!rc) rc = be_d2h(h, out, h->d_debug, (size_t)h->n * UR5_DEBUG_STRIDE * 8);
   return rc;
 }
+#ifdef UR5_PROFILE
+// profile build only: per-env, per-phase cycle totals of the last launch ([n][16] host)
+int ur5_profile_read(ur5_sim* h, double* out) {
+  std::vector<double> dbg((size_t)h->n * UR5_DEBUG_STRIDE);
+  int rc = be_d2h(h, dbg.data(), h->d_debug, dbg.size() * 8);
+  if (rc) return rc;
+  for (int e = 0; e < h->n; e++) memcpy(out + (size_t)e * 16, dbg.data() + (size_t)e * UR5_DEBUG_STRIDE, 16 * 8);
+  return 0;
+}
+#endif
 int ur5_body_xpos(ur5_sim* h, double* out) {
   std::vector<double> dbg((size_t)h->n * UR5_DEBUG_STRIDE);
   int rc = ur5_forward_debug(h, dbg.data());

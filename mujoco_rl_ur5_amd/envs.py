@@ -1,0 +1,170 @@
+"""Batched ``GraspEnv``: the reference's gym environment surface on top of the HIP engine.
+
+Mirrors ``gym_grasper/envs/GraspingEnv.py`` (class ``GraspEnv``, :25): ``step(action, record_grasps, markers,
+action_info) -> (obs, reward, done, info)``, ``reset() -> obs``, ``action_space = MultiDiscrete([H*W, 6])``,
+``rotations``, ``TABLE_HEIGHT``, ``IMAGE_WIDTH/HEIGHT``, ``current_observation``, ``model``, ``controller``.
+With ``n_envs == 1`` shapes equal the reference's; otherwise actions are ``int[N, 2]``, observations and rewards gain a
+leading N. The whole 12-phase ``move_and_grasp`` script (:205-386) of every scene runs inside ONE kernel launch.
+
+Observation: this round ships ``observation="flat"`` -- the IT1 setting of README.md:20 ("fixed z-coordinate for
+grasping"): depth = camera height - TABLE_HEIGHT everywhere, rgb zeros. ``observation="render"`` (the 200x200 HIP RGB-D
+rasteriser) is a later row of the scope table and raises until it lands.
+"""
+from __future__ import annotations
+
+from collections import defaultdict
+
+import numpy as np
+
+from .controller import MJ_Controller
+from .model import CompiledModel, load_model
+from .native import BatchSim
+
+
+class MultiDiscrete:
+    """Minimal stand-in for ``gym.spaces.MultiDiscrete`` (gym is not a dependency of the engine)."""
+
+    def __init__(self, nvec, seed=None):
+        self.nvec = np.asarray(nvec, dtype=np.int64)
+        self._rng = np.random.default_rng(seed)
+
+    def sample(self):
+        return (self._rng.random(self.nvec.shape) * self.nvec).astype(np.int64)
+
+    def contains(self, x):
+        x = np.asarray(x)
+        return x.shape == self.nvec.shape and bool(np.all(x >= 0) and np.all(x < self.nvec))
+
+    def __repr__(self):
+        return "MultiDiscrete({})".format(self.nvec.tolist())
+
+
+class GraspEnv(object):
+    metadata = {"render.modes": ["human", "rgb_array"], "video.frames_per_second": 500}
+
+    def __init__(self, file="/UR5+gripper/UR5gripper_2_finger_many_objects.xml", image_width=200, image_height=200, show_obs=True,
+                 demo=False, render=False, n_envs=1, device_id=0, observation="flat", check_mode=0, base_seed=20, _lib_path=None):
+        self.initialized = False
+        self.IMAGE_WIDTH = image_width
+        self.IMAGE_HEIGHT = image_height
+        self.rotations = {0: 0, 1: 30, 2: 60, 3: 90, 4: -30, 5: -60}       # GraspingEnv.py:40
+        self.action_space_type = "multidiscrete"
+        self.step_called = 0
+        self.n_envs = int(n_envs)
+        self.model = file if isinstance(file, CompiledModel) else load_model(file)
+        self.frame_skip = 1                                                  # MujocoEnv.__init__(full_path, 1), :47
+        self.sim = BatchSim(self.model, self.n_envs, device_id=device_id, lib_path=_lib_path)
+        self.viewer = None
+        self._set_action_space()
+        self.controller = MJ_Controller(self.model, self.sim, self.viewer)   # :51
+        self.initialized = True
+        self.grasp_counter = 0
+        self.show_observations = show_obs
+        self.demo_mode = demo
+        self.TABLE_HEIGHT = 0.91                                             # :56
+        self.render = render
+        if observation not in ("flat", "render"):
+            raise ValueError("observation must be 'flat' or 'render'")
+        if observation == "render":
+            raise NotImplementedError("observation='render' needs the HIP RGB-D rasteriser (SURVEY.md K10), not part of this round")
+        self.observation_mode = observation
+        self.check_mode = check_mode                                         # 0 = in-tree script, 1 = IT1 (README.md:20)
+        self.base_seed = base_seed                                           # Grasping_Agent_multidiscrete.py:64
+        self._episode = 0
+        self.last_phase_steps = None
+        self.last_phase_result = None
+        self.current_observation = self.get_observation(show=False)
+
+    def __repr__(self):
+        return f"GraspEnv(obs height={self.IMAGE_HEIGHT}, obs_width={self.IMAGE_WIDTH}, AS={self.action_space_type})"
+
+    @property
+    def dt(self):
+        return self.model.opt["timestep"] * self.frame_skip
+
+    def _one(self, v):
+        return v[0] if self.n_envs == 1 else v
+
+    def _set_action_space(self):                                             # :158-167
+        self.action_space = MultiDiscrete([self.IMAGE_HEIGHT * self.IMAGE_WIDTH, len(self.rotations)])
+        return self.action_space
+
+    # ------------------------------------------------------------------ step / reset
+    def step(self, action, record_grasps=False, markers=False, action_info="no info"):   # :62-156
+        done = False
+        info = {}
+        if self.step_called == 1:
+            self.current_observation = self.get_observation(show=False)      # :87-88
+        a = np.atleast_2d(np.asarray(action, dtype=np.int64))
+        if a.shape != (self.n_envs, 2):
+            raise ValueError(f"action must have shape ({self.n_envs}, 2) = [pixel index, rotation index]")
+        x = a[:, 0] % self.IMAGE_WIDTH                                       # :95
+        y = a[:, 0] // self.IMAGE_WIDTH                                      # :96
+        rotation = a[:, 1]                                                   # :97
+        depth_img = np.asarray(self.current_observation["depth"]).reshape(self.n_envs, self.IMAGE_HEIGHT, self.IMAGE_WIDTH)
+        depth = depth_img[np.arange(self.n_envs), y, x]                      # :100
+        coords = np.stack([self.controller.pixel_2_world(pixel_x=x[e], pixel_y=y[e], depth=depth[e], height=self.IMAGE_HEIGHT,
+                                                         width=self.IMAGE_WIDTH) for e in range(self.n_envs)])   # :102-104
+        skip = (coords[:, 2] < 0.8) | (coords[:, 1] > -0.3)                  # :124
+        reward = self.move_and_grasp(coords, rotation, skip=skip)
+        self.current_observation = self.get_observation(show=self.show_observations)   # :152
+        self.step_called += 1
+        info["phase_steps"] = self._one(self.last_phase_steps)
+        info["skipped"] = self._one(skip)
+        return self.current_observation, self._one(reward), done, info
+
+    def move_and_grasp(self, coordinates, rotation, render=False, record_grasps=False, markers=False, plot=False, skip=None):
+        """GraspingEnv.py:205-386 for every scene at once; scenes flagged in ``skip`` (:124-131) sit the launch out."""
+        coords = np.atleast_2d(np.asarray(coordinates, dtype=np.float64))
+        rot = np.broadcast_to(np.asarray(rotation, dtype=np.int64), (self.n_envs,))
+        if skip is not None and np.any(skip):
+            # a skipped scene must not move: park it by saving / restoring its record around the launch
+            saved = self.sim.get_state()
+        rew, ps, pr = self.sim.grasp_attempt(coords, rot, check_mode=self.check_mode, table_height=self.TABLE_HEIGHT)
+        if skip is not None and np.any(skip):
+            now = self.sim.get_state()
+            for k in now:
+                now[k][skip] = saved[k][skip]
+            self.sim.set_state(qpos=now["qpos"], qvel=now["qvel"], warmstart=now["warmstart"], pid=now["pid"])
+            rew = np.where(skip, 0, rew)
+            ps = np.where(skip[:, None], 0, ps)
+        self.last_phase_steps, self.last_phase_result = ps, pr
+        self.controller.last_movement_steps = self._one(ps[:, 11])
+        return rew.astype(np.int64)
+
+    def reset(self):
+        """MujocoEnv.reset() [3P] -> reset_model() (GraspingEnv.py:409-477)."""
+        return self.reset_model()
+
+    def reset_model(self, show_obs=True):                                    # :409-477
+        seeds = np.uint64(self.base_seed) + np.arange(self.n_envs, dtype=np.uint64) + np.uint64(self._episode * self.n_envs)
+        self._episode += 1
+        self.sim.reset(seeds, mode=1, settle_ms=1000.0 + (5000.0 if self.demo_mode else 0.0))   # :473-475
+        self.current_observation = self.get_observation(show=self.show_observations)
+        return self.current_observation
+
+    def get_observation(self, show=True):                                    # :390-406
+        cam_z = self.model.cam_pos0[self.model.camera_name2id("top_down")][2]
+        depth = np.full((self.n_envs, self.IMAGE_HEIGHT, self.IMAGE_WIDTH), cam_z - 0.91, dtype=np.float32)
+        rgb = np.zeros((self.n_envs, self.IMAGE_HEIGHT, self.IMAGE_WIDTH, 3), dtype=np.uint8)
+        observation = defaultdict()
+        observation["rgb"] = self._one(rgb)
+        observation["depth"] = self._one(depth)
+        return observation
+
+    def close(self):
+        self.sim.close()
+
+    def print_info(self):                                                    # :483-489
+        print("Model timestep:", self.model.opt["timestep"])
+        print("Set number of frames skipped: ", self.frame_skip)
+        print("dt = timestep * frame_skip: ", self.dt)
+        print("Frames per second = 1/dt: ", self.metadata["video.frames_per_second"])
+        print("Actionspace: ", self.action_space)
+
+
+def make(id="gym_grasper:Grasper-v0", **kwargs):
+    """``gym.make("gym_grasper:Grasper-v0", ...)`` without gym (gym_grasper/__init__.py:4-7)."""
+    if id not in ("gym_grasper:Grasper-v0", "Grasper-v0"):
+        raise ValueError(f"unknown environment id {id!r}")
+    return GraspEnv(**kwargs)

@@ -18,7 +18,7 @@ RES_NONE, RES_SUCCESS, RES_MAX_STEPS, RES_IK_FAIL = -1, 0, 1, 2
 DEBUG_STRIDE, REC_STRIDE, MAXB = 2048, 192, 14
 EXPORTS = ["ur5_last_error", "ur5_create", "ur5_destroy", "ur5_num_envs", "ur5_nq", "ur5_nv", "ur5_nu", "ur5_reset",
            "ur5_set_state", "ur5_get_state", "ur5_set_ctrl", "ur5_get_ctrl", "ur5_step", "ur5_move_group", "ur5_stay",
-           "ur5_move_ee", "ur5_grasp_attempt", "ur5_grasp_attempt_dev", "ur5_sync", "ur5_last_launch_ms",
+           "ur5_move_ee", "ur5_ik", "ur5_grasp_attempt", "ur5_grasp_attempt_dev", "ur5_sync", "ur5_last_launch_ms",
            "ur5_get_counters", "ur5_body_xpos", "ur5_state_device_ptr", "ur5_forward_debug"]
 
 
@@ -53,6 +53,7 @@ def load(path=None):
     L.ur5_move_group.argtypes = [vp, C.POINTER(C.c_uint32), dp, dp, ip, ip, ip]
     L.ur5_stay.argtypes = [vp, C.c_double]
     L.ur5_move_ee.argtypes = [vp, dp, dp, ip, ip, ip]
+    L.ur5_ik.argtypes = [vp, dp, dp, ip]
     L.ur5_grasp_attempt.argtypes = [vp, dp, C.c_int, C.c_double, ip, ip, ip]
     L.ur5_grasp_attempt_dev.argtypes = [vp, vp, C.c_int, C.c_double, vp]
     L.ur5_last_launch_ms.argtypes = [vp]
@@ -174,6 +175,12 @@ class BatchSim:
         res, steps = np.zeros(self.n, dtype=np.int32), np.zeros(self.n, dtype=np.int32)
         self._check(self.lib.ur5_move_ee(self._h, _dp(x), _dp(tol), _ip(mx), _ip(res), _ip(steps)), "ur5_move_ee")
         return res, steps
+
+    def ik(self, xyz):
+        x = np.ascontiguousarray(np.broadcast_to(np.asarray(xyz, dtype=np.float64), (self.n, 3)).copy())
+        q5, res = np.zeros((self.n, 5)), np.zeros(self.n, dtype=np.int32)
+        self._check(self.lib.ur5_ik(self._h, _dp(x), _dp(q5), _ip(res)), "ur5_ik")
+        return q5, res
 
     def grasp_attempt(self, xyz, rot=0, check_mode=0, table_height=0.91):
         a = np.zeros((self.n, 4))

@@ -1,0 +1,55 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+EMUL_DIR = os.path.join(ROOT, "tests", "emul")
+EMUL_LIB = os.path.join(EMUL_DIR, "_build", "libur5sim_emul.so")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def build_emul():
+    """Test-only lane-emulation build of the engine source (see tests/emul/ur5sim_emul.cpp)."""
+    srcs = [os.path.join(EMUL_DIR, "ur5sim_emul.cpp")] + [os.path.join(ROOT, "mujoco_rl_ur5_amd", "csrc", f)
+                                                            for f in ("ur5_engine.h", "ur5sim_host.h", "ur5_devmodel.h")]
+    if not os.path.exists(EMUL_LIB) or os.path.getmtime(EMUL_LIB) < max(os.path.getmtime(s) for s in srcs):
+        os.makedirs(os.path.dirname(EMUL_LIB), exist_ok=True)
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", EMUL_LIB, srcs[0]])
+    return EMUL_LIB
+
+
+@pytest.fixture(scope="session")
+def emul_lib():
+    return build_emul()
+
+
+@pytest.fixture(scope="session")
+def model_it1():
+    from mujoco_rl_ur5_amd.model import load_model
+    return load_model("it1_4box")
+
+
+@pytest.fixture(scope="session")
+def model_2f():
+    from mujoco_rl_ur5_amd.model import load_model
+    return load_model("/UR5+gripper/UR5gripper_2_finger.xml")
+
+
+def aimed_actions(qpos, nobj, table_z=0.91, first_id=0):
+    """World xyz above object (env % nobj) for every env: the synthetic action rule of SURVEY.md section 8d, config 2."""
+    import numpy as np
+    n = qpos.shape[0]
+    acts = np.zeros((n, 3))
+    for e in range(n):
+        objs = qpos[e][8:].reshape(-1, 7)
+        k = (first_id + e) % nobj
+        acts[e] = [objs[k, 0], -0.6 + objs[k, 1], table_z]
+    return acts

@@ -1,0 +1,138 @@
+"""The engine SOURCE (csrc/ur5_engine.h) run under the test-only lane emulation vs the oracle -- no GPU needed.
+
+This checks the kernel logic (twist-space Newton, collision, phase machine) on the CPU box; the `-m gpu` tests repeat the
+comparison through the real libur5sim.so on an MI355X.
+"""
+import numpy as np
+import pytest
+
+from conftest import aimed_actions
+from mujoco_rl_ur5_amd.native import BatchSim
+from oracle.oracle import Oracle
+
+
+@pytest.fixture(scope="module")
+def sim3(model_it1, emul_lib):
+    return BatchSim(model_it1, 3, lib_path=emul_lib)
+
+
+def _random_state(m, seed):
+    rng = np.random.default_rng(seed)
+    q = m.qpos0.copy()
+    q[:8] = [0.3, -1.2, 1.1, -0.7, -1.0, 0.4, 0.2, 0.2]
+    for k in range((m.nq - 8) // 7):
+        qa = 8 + 7 * k
+        quat = rng.normal(size=4)
+        q[qa + 3:qa + 7] = quat / np.linalg.norm(quat)
+        q[qa:qa + 3] = rng.uniform(-0.1, 0.1, size=3)
+    return q, rng.normal(size=m.nv) * 0.3
+
+
+def test_forward_quantities(model_it1, sim3):
+    m = model_it1
+    q, v = _random_state(m, 0)
+    ctrl = np.array([0.5, -1, 0.3, 0.2, -0.1, 0.7, -0.4])
+    o = Oracle(m)
+    o.set_state(qpos=q, qvel=v)
+    o.set_ctrl(ctrl)
+    sim3.set_state(qpos=q, qvel=v, warmstart=np.zeros(m.nv))
+    sim3.set_ctrl(ctrl)
+    o.forward()
+    d = sim3.forward_debug()
+    assert np.abs(d["Mr"][0] - o.mass_matrix()[:8, :8]).max() < 1e-12
+    fs = o.vec("qfrc_passive") - o.vec("qfrc_bias") + o.vec("qfrc_actuator")
+    assert np.abs(d["qfrc_smooth"][0][:m.nv] - fs).max() < 1e-10
+    assert np.abs(d["qacc_smooth"][0][:m.nv] - o.vec("qacc_smooth")).max() < 1e-8
+    assert np.abs(d["qacc"][0][:m.nv] - o.vec("qacc")).max() < 1e-8
+
+
+def test_contact_set_matches_oracle(model_it1, sim3):
+    m = model_it1
+    o = Oracle(m)
+    o.reset(20, 1, True)
+    sim3.reset([20, 21, 22], 1, 1000.0)
+    s, so = sim3.get_state(), o.get_state()
+    assert np.abs(s["qpos"][0] - so["qpos"]).max() < 1e-12 and np.abs(s["qvel"][0] - so["qvel"]).max() < 1e-12
+    o.forward()
+    d = sim3.forward_debug()
+    oc = o.contacts()
+    assert d["ncon"][0] == len(oc) == 16
+    ec = d["contacts"][0][:16]
+    assert np.abs(np.sort(ec[:, 0]) - np.sort(oc[:, 0])).max() < 1e-12          # distances
+    assert np.abs(ec[:, 9].sum() - oc[:, 10].sum()) < 1e-9                        # total normal force = weight of 4 boxes
+    assert abs(oc[:, 10].sum() - 4 * 0.064 * 9.81) < 1e-8
+
+
+def test_grasp_attempt_trajectories(model_it1, emul_lib):
+    """Identical initial state + identical script => arm trajectories within 1e-4 rel (north_star), here ~1e-12, and the
+    binary grasp outcome and every phase's step count bit-equal."""
+    m = model_it1
+    seeds = [20, 21, 22]
+    sim3 = BatchSim(m, 3, lib_path=emul_lib)
+    sim3.reset(seeds, 1, 1000.0)
+    st = sim3.get_state()
+    acts = aimed_actions(st["qpos"], 4)
+    rots = [0, 1, 3]
+    rew, ps, pr = sim3.grasp_attempt(acts, rot=rots, check_mode=0)
+    s2 = sim3.get_state()
+    outcomes = []
+    for e, seed in enumerate(seeds):
+        o = Oracle(m)
+        o.reset(seed, 1, True)
+        r, pso, pro = o.grasp_attempt(acts[e], rots[e], 0)
+        so = o.get_state()
+        assert r == rew[e] and pso.tolist() == ps[e].tolist() and pro.tolist() == pr[e].tolist()
+        assert np.abs(s2["qpos"][e][:8] - so["qpos"][:8]).max() < 1e-9
+        assert np.abs(s2["qpos"][e] - so["qpos"]).max() < 1e-6
+        outcomes.append(r)
+    assert 1 in outcomes
+
+
+def test_it1_check_mode_and_move_ops(model_it1, emul_lib):
+    m = model_it1
+    sim3 = BatchSim(m, 3, lib_path=emul_lib)   # fresh handle: controller state (Kp[0], last inputs) persists across resets
+    sim3.reset([30, 31, 32], 1, 1000.0)
+    o = Oracle(m)
+    o.reset(30, 1, True)
+    res, steps = sim3.move_ee([0.1, -0.55, 1.0], 0.01, 400)
+    ro, so_ = o.move_ee([0.1, -0.55, 1.0], 0.01, 400)
+    assert res[0] == ro and steps[0] == so_
+    res, steps = sim3.move_group(1 << 6, [[0.4]], 0.05, 1000)
+    ro, so_ = o.move_group(1 << 6, [0.4], 0.05, 1000)
+    assert res[0] == ro and steps[0] == so_
+    sim3.stay(100)
+    o.stay(100)
+    acts = aimed_actions(sim3.get_state()["qpos"], 4)
+    rew, ps, pr = sim3.grasp_attempt(acts, rot=0, check_mode=1)
+    r, pso, pro = o.grasp_attempt(acts[0], 0, 1)
+    assert r == rew[0] and pso.tolist() == ps[0].tolist()
+    assert ps[0][6] > 0                                               # the IT1 "straight up" phase ran
+    assert np.abs(sim3.get_state()["qpos"][0][:8] - o.get_state()["qpos"][:8]).max() < 1e-9
+    q5, ok = sim3.ik([0.0, -0.6, 1.1])
+    oko, q5o = o.ik([0.0, -0.6, 1.1])
+    assert ok[0] == 0 and oko and np.abs(q5[0] - q5o).max() < 1e-12
+
+
+def test_batch_position_does_not_matter(model_it1, emul_lib):
+    """Scene i of a batch == the same scene run alone (pure function of its seed): the shard-invariance the multi-GPU
+    layout relies on."""
+    a = BatchSim(model_it1, 3, lib_path=emul_lib)
+    b = BatchSim(model_it1, 1, lib_path=emul_lib)
+    a.reset([40, 41, 42], 1, 200.0)
+    b.reset([42], 1, 200.0)
+    assert np.array_equal(a.get_state()["qpos"][2], b.get_state()["qpos"][0])
+    assert np.array_equal(a.get_state()["qvel"][2], b.get_state()["qvel"][0])
+
+
+def test_two_finger_six_object_scene_runs(model_2f, emul_lib):
+    """The in-tree UR5gripper_2_finger.xml (3 boxes + 3 spheres, nv = 44) through the NV=44 instantiation."""
+    sim = BatchSim(model_2f, 1, lib_path=emul_lib)
+    o = Oracle(model_2f)
+    sim.reset([20], 1, 300.0)
+    o.reset(20, 1, False)
+    o.stay(300)
+    s, so = sim.get_state(), o.get_state()
+    assert np.abs(s["qpos"][0] - so["qpos"]).max() < 1e-9
+    assert sim.counters()["status"][0] == 0
+    quats = s["qpos"][0][8:].reshape(-1, 7)[:, 3:]
+    assert np.abs(np.linalg.norm(quats, axis=1) - 1).max() < 1e-12

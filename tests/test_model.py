@@ -1,0 +1,123 @@
+"""Model compiler: shipped assets vs the numbers SURVEY.md derived from the reference's MJCF (sections 0.8, Appendix A)."""
+import os
+
+import numpy as np
+import pytest
+
+from mujoco_rl_ur5_amd.model import CompiledModel, load_model, KNOWN_MODELS
+from mujoco_rl_ur5_amd.refdyn import forward_kinematics, mass_matrix
+
+REF = "/root/reference/UR5+gripper"
+
+
+def test_dimensions_match_survey(model_2f):
+    m = model_2f
+    assert (m.nq, m.nv, m.nu, m.nbody, m.ngeom) == (50, 44, 7, 24, 36)
+    many = load_model("/UR5+gripper/UR5gripper_2_finger_many_objects.xml")
+    assert (many.nq, many.nv, many.nu, many.nbody, many.ngeom) == (288, 248, 7, 58, 70)
+    assert many.geom_condim.max() == 6 and m.geom_condim.max() == 4         # xml :27 / many_objects :29
+
+
+def test_options_and_actuators(model_2f):
+    m = model_2f
+    assert m.opt["timestep"] == 2e-3 and m.opt["iterations"] == 100 and m.opt["tolerance"] == 1e-10 and m.opt["impratio"] == 10
+    assert np.allclose(m.act_gear, 101) and np.allclose(m.act_ctrlrange[:3], [-2, 2]) and np.allclose(m.act_ctrlrange[3:], [-1, 1])
+    assert [m.names["joint"][j] for j in m.act_jntid] == ["shoulder_pan_joint", "shoulder_lift_joint", "elbow_joint", "wrist_1_joint",
+                                                          "wrist_2_joint", "wrist_3_joint", "base_to_lik"]
+    assert np.allclose(m.dof_damping[:8], [65, 65, 65, 45, 45, 45, 5, 5]) and np.allclose(m.dof_armature[:8], 0.01)
+    assert m.names["joint"][m.eq_jnt1[0]] == "base_to_rik" and m.names["joint"][m.eq_jnt2[0]] == "base_to_lik"
+
+
+def test_forward_kinematics_known_answers(model_2f):
+    """SURVEY.md Appendix A table (zero pose and the home pose of GraspingEnv.py:418)."""
+    m = model_2f
+    ee, w3 = m.body_name2id("ee_link"), m.body_name2id("wrist_3_link")
+    fk = forward_kinematics(m, m.qpos0)
+    assert np.allclose(fk["xpos"][ee], [0.817250, 0.191450, 0.864509], atol=1e-6)
+    assert np.allclose(fk["xmat"][ee], [[0, 1, 0], [1, 0, 0], [0, 0, -1]], atol=1e-6)
+    assert np.allclose(fk["xpos"][w3], [0.817250, 0.109150, 0.864509], atol=1e-6)
+    q = m.qpos0.copy()
+    q[:7] = [0, -1.57, 1.57, -1.57, -1.57, 0, 0.3]
+    fk = forward_kinematics(m, q)
+    assert np.allclose(fk["xpos"][ee], [0.487173, 0.109216, 1.301784], atol=1e-6)
+    assert np.allclose(fk["xpos"][w3], [0.487238, 0.109150, 1.384083], atol=1e-6)
+    assert np.allclose(fk["xpos"][m.body_name2id("base_link")], [0, 0, 0.87])
+
+
+def test_collision_pair_filter(model_2f):
+    m = model_2f
+    b = m.geom_bodyid
+    pairs = set(zip(m.pair_geom1.tolist(), m.pair_geom2.tolist()))
+    name = lambda g: m.names["body"][b[g]]
+    for g1, g2 in pairs:
+        assert b[g1] != b[g2] and not (m.body_weldid[b[g1]] == 0 and m.body_weldid[b[g2]] == 0)
+        assert {name(g1), name(g2)} != {"left_inner_knuckle", "robotiq_85_base_link"}      # parent-child filter
+    fingers = {g for g in range(m.ngeom) if "finger" in name(g)}
+    assert any(g1 in fingers and g2 in fingers for g1, g2 in pairs)                        # left/right fingers do collide
+    objs = [g for g in range(m.ngeom) if m.body_treeid[b[g]] > 0]
+    assert all((min(a, c), max(a, c)) in pairs for a in objs for c in objs if a != c)      # object-object: 15 pairs
+    assert sum(1 for g1, g2 in pairs if g1 in objs and g2 in objs) == 15
+
+
+def test_masses_and_invweights(model_2f):
+    m = model_2f
+    # de-duplicated mesh volumes x 1000 kg/m3 (mjcf.py docstring): half of the signed volumes SURVEY.md H1 lists
+    want = dict(shoulder_link=3.108 / 2, upper_arm_link=10.766 / 2, forearm_link=5.017 / 2, wrist_1_link=1.031 / 2, wrist_3_link=0.277 / 2)
+    for k, v in want.items():
+        assert abs(m.body_mass[m.body_name2id(k)] - v) < 2e-3, k
+    box = m.body_name2id("box_1")
+    assert abs(m.body_mass[box] - 1000 * 0.04 ** 3) < 1e-12
+    assert np.allclose(m.body_invweight0[box], [1 / 0.064, 1 / (0.064 * (0.04 ** 2) / 6)])
+    M, _ = mass_matrix(m, m.qpos0)
+    assert abs(m.opt["meaninertia"] - np.diag(M).mean()) < 1e-12
+    assert np.all(np.linalg.eigvalsh(M) > 0)
+
+
+def test_blob_roundtrip(model_it1):
+    m2 = CompiledModel.from_blob(model_it1.to_blob())
+    for k in ("body_pos", "geom_size", "mesh_vert", "pair_geom1", "qpos0", "dof_invweight0"):
+        assert np.array_equal(getattr(m2, k), getattr(model_it1, k))
+    assert m2.names == model_it1.names and m2.opt == model_it1.opt
+    assert m2.get_joint_qpos_addr("box_1_rot") == (11, 15) and m2.get_joint_qpos_addr("elbow_joint") == 2
+    assert m2.camera_name2id("top_down") == 1 and np.allclose(m2.cam_pos0[1], [0, -0.6, 2.0])
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present (GPU box)")
+def test_shipped_assets_are_current():
+    from mujoco_rl_ur5_amd.mjcf import compile_mjcf
+    fresh = compile_mjcf(os.path.join(REF, "UR5gripper_2_finger.xml"))
+    shipped = load_model("/UR5+gripper/UR5gripper_2_finger.xml")
+    assert fresh.to_blob() == shipped.to_blob()
+    assert set(KNOWN_MODELS) >= {"/UR5+gripper/UR5gripper_2_finger.xml", "/UR5+gripper/UR5gripper_2_finger_many_objects.xml"}
+
+
+def test_urdf_chain_matches_mjcf(model_2f):
+    """ikpy builds its chain from ur5_gripper.urdf:61-234 [3P]; the engine uses the MJCF tree. Golden origins were extracted
+    from the URDF by tools/gen_golden.py; both chains must give the same ee_link pose."""
+    import json
+    with open(os.path.join(os.path.dirname(__file__), "golden", "urdf_chain.json")) as f:
+        chain = json.load(f)
+
+    def rpy(r, p, y):
+        cr, sr, cp, sp, cy, sy = np.cos(r), np.sin(r), np.cos(p), np.sin(p), np.cos(y), np.sin(y)
+        return np.array([[cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr], [sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr], [-sp, cp * sr, cp * cr]])
+
+    def axis_rot(a, t):
+        a = np.asarray(a, float); K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+        return np.eye(3) + np.sin(t) * K + (1 - np.cos(t)) * K @ K
+
+    m = model_2f
+    ee = m.body_name2id("ee_link")
+    base = forward_kinematics(m, m.qpos0)["xpos"][m.body_name2id("base_link")]
+    rng = np.random.default_rng(1)
+    for _ in range(5):
+        q6 = rng.uniform(-1.5, 1.5, size=6)
+        R, p = np.eye(3), base.copy()
+        k = 0
+        for j in chain:
+            p = p + R @ np.array(j["xyz"]); R = R @ rpy(*j["rpy"])
+            if j["type"] == "revolute":
+                R = R @ axis_rot(j["axis"], q6[k]); k += 1
+        q = m.qpos0.copy(); q[:6] = q6
+        fk = forward_kinematics(m, q)
+        assert np.allclose(fk["xpos"][ee], p, atol=2e-6) and np.allclose(fk["xmat"][ee], R, atol=2e-6)

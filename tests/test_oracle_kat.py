@@ -1,0 +1,191 @@
+"""Known-answer tests that pin the CPU oracle (the reference ships no golden vectors: SURVEY.md section 4, 8c)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from mujoco_rl_ur5_amd.refdyn import forward_kinematics, mass_matrix
+from oracle.oracle import Oracle
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_kinematics_and_mass_matrix_against_independent_numpy(model_2f):
+    m = model_2f
+    o = Oracle(m)
+    rng = np.random.default_rng(3)
+    for _ in range(3):
+        q = m.qpos0.copy()
+        q[:8] = rng.uniform(-1.2, 1.2, 8)
+        for k in range(6):
+            qa = 8 + 7 * k
+            q[qa:qa + 3] = rng.uniform(-0.2, 0.2, 3)
+            quat = rng.normal(size=4)
+            q[qa + 3:qa + 7] = quat / np.linalg.norm(quat)
+        o.set_state(qpos=q)
+        M_ref, fk = mass_matrix(m, q)             # per-body Jacobian assembly, a different algorithm than the oracle's CRBA
+        assert np.abs(o.body_xpos() - fk["xpos"]).max() < 1e-12
+        assert np.abs(o.body_xmat() - fk["xmat"]).max() < 1e-12
+        assert np.abs(o.mass_matrix() - M_ref).max() < 1e-10
+
+
+def test_free_fall_is_exact_semi_implicit_euler(model_2f):
+    m = model_2f
+    o = Oracle(m)
+    o.set_options(contacts_enabled=0)
+    q = m.qpos0.copy()
+    q[10] = 1.0       # box_1 slide z (world z = 0.95 + 1.0)
+    o.set_state(qpos=q, qvel=np.zeros(m.nv))
+    n, h, g = 100, 2e-3, 9.81
+    o.step(n)
+    s = o.get_state()
+    assert abs(s["qvel"][10] + g * h * n) < 1e-12
+    assert abs(s["qpos"][10] - (1.0 - g * h * h * n * (n + 1) / 2)) < 1e-12
+    assert np.abs(np.linalg.norm(s["qpos"][11:15]) - 1) < 1e-15
+
+
+def test_gyroscopic_free_rotation_conserves_energy(model_2f):
+    m = model_2f
+    o = Oracle(m)
+    o.set_options(contacts_enabled=0)
+    v = np.zeros(m.nv)
+    v[8 + 6 * 2 + 3: 8 + 6 * 2 + 6] = [3.0, -2.0, 1.0]       # box_3 (no rotational damping), cube -> isotropic inertia
+    o.set_state(qvel=v)
+    o.step(200)
+    w = o.get_state()["qvel"][8 + 6 * 2 + 3: 8 + 6 * 2 + 6]
+    assert abs(np.linalg.norm(w) - np.linalg.norm([3.0, -2.0, 1.0])) < 1e-9
+
+
+def test_sphere_rests_at_the_soft_constraint_equilibrium(model_2f):
+    """One pyramidal contact (condim 4 -> 6 rows): at rest every row carries m g / 6 and the penetration follows from
+    aref = -k imp r, R = 2 mu~^2 (1-imp)/imp (1+mu^2) tran."""
+    m = model_2f
+    o = Oracle(m)
+    q = m.qpos0.copy()
+    for k in range(6):                    # spread the six objects over the plate so that nothing stacks
+        q[8 + 7 * k] = -0.2 + 0.08 * k
+    ball = 8 + 7 * 3                      # ball_1 (r = 0.03), body z 1.3 -> put it just above the plate (top 0.91)
+    q[ball + 2] = 0.91 + 0.03 + 0.0005 - 1.3
+    o.set_state(qpos=q, qvel=np.zeros(m.nv))
+    o.step(1500)
+    o.forward()
+    con = [c for c in o.contacts() if m.names["geom"][int(c[8])] == "ball_1" or m.names["geom"][int(c[7])] == "ball_1"]
+    assert len(con) == 1
+    mass = m.body_mass[m.body_name2id("ball_1")]
+    assert abs(con[0][10] - mass * 9.81) < 1e-6
+    imp, tc, mu = 0.99, 0.01, 1.0
+    k = 1 / (imp ** 2 * tc ** 2)
+    tran = m.body_invweight0[m.body_name2id("ball_1")][0]
+    R = 2 * (mu ** 2 / 10.0) * (1 - imp) / imp * tran * (1 + mu ** 2)
+    r_expected = -(mass * 9.81 / 6) * R / (k * imp)
+    assert abs((con[0][0] - 1e-3) - r_expected) < 1e-7
+
+
+def test_box_rests_with_equal_corner_forces(model_it1):
+    o = Oracle(model_it1)
+    o.reset(20, 1, True)
+    o.forward()
+    c = o.contacts()
+    assert len(c) == 16
+    assert np.allclose(c[:, 10], 0.064 * 9.81 / 4, rtol=1e-6)            # Newton reaches the unique optimum
+    assert o.solver_iter_last <= 3
+
+
+def test_newton_and_pgs_agree_on_a_single_contact(model_2f):
+    """Both solvers minimise the same strictly convex problem. PGS (named by north_star) is still 5e-4 away from the optimum
+    after MuJoCo's 100-sweep cap even for ONE contact, and fails the grasp (DESIGN.md "Solver"), hence Newton is the default."""
+    m = model_2f
+    acc, iters = [], []
+    for solver in (0, 1):
+        o = Oracle(m)
+        o.set_options(solver=solver)
+        q = m.qpos0.copy()
+        for k in range(6):
+            q[8 + 7 * k] = -0.2 + 0.08 * k
+        q[8 + 7 * 3 + 2] = 0.91 + 0.03 - 0.0005 - 1.3
+        o.set_state(qpos=q, qvel=np.zeros(m.nv))
+        o.forward()
+        acc.append(o.vec("qacc")[8 + 6 * 3: 8 + 6 * 3 + 3].copy())
+        iters.append(o.solver_iter_last)
+    assert np.allclose(acc[0], acc[1], rtol=2e-3, atol=5e-3)
+    assert iters[0] <= 5 and iters[1] == 100
+
+
+def test_pid_follows_simple_pid_semantics(model_it1):
+    """u = clamp(Kp e - Kd (q - q_last)/dt) with Ki = 0, derivative on measurement."""
+    o = Oracle(model_it1)
+    o.set_options(contacts_enabled=0)
+    st = o.get_state()
+    assert np.allclose(st["pid"][:, 3], [21, 30, 15, 21, 15, 15, 7.5])                     # MujocoController.py:166-235
+    assert np.allclose(st["pid"][:, 0], [0, -1.57, 1.57, -1.57, -1.57, 0, 0]) and np.allclose(st["pid"][:, 1], 0)
+    q = model_it1.qpos0.copy()
+    q[:7] = [0.01, -1.56, 1.58, -1.57, -1.57, 0.02, 0.0]
+    pid = st["pid"].copy()
+    pid[:, 1] = q[:7]                      # last_input = current q -> pure P action on the first evaluation
+    o.set_state(qpos=q, qvel=np.zeros(model_it1.nv), pid=pid)
+    o.move_group(0x7f, None, 1e-9, 0)      # max_steps 0: one PID evaluation, no physics step
+    u = o.get_ctrl()
+    kp = np.array([21, 30, 15, 21, 15, 15, 7.5])
+    lim = np.array([2, 2, 2, 1, 1, 1, 1])
+    assert np.allclose(u, np.clip(kp * (pid[:, 0] - q[:7]), -lim, lim))
+
+
+def test_move_loop_counts_like_the_reference(model_it1):
+    """MujocoController.py:318-382: a non-converging call does exactly max_steps physics steps and reports steps = max+1;
+    success does not break, so one more sim.step() follows."""
+    o = Oracle(model_it1)
+    o.reset(20, 1, False)
+    n0 = o.total_steps
+    far = np.array([0.5, -1.0, 1.0, -1.0, -1.0, 0.5, 0.0])
+    r, steps = o.move_group(0x7f, far, 1e-12, 10)
+    assert (r, steps, o.total_steps - n0) == (1, 11, 10)
+    r, steps = o.move_group(0x7f, None, 10.0, 10)
+    assert (r, steps, o.total_steps - n0) == (0, 2, 11)
+
+
+def test_ik_reaches_the_requested_gripper_centre(model_it1):
+    m = model_it1
+    o = Oracle(m)
+    for xyz in ([0.0, -0.6, 1.1], [0.2, -0.7, 0.95], [0.6, 0.0, 1.15]):
+        ok, q5 = o.ik(xyz)
+        assert ok
+        q = m.qpos0.copy()
+        q[:5] = q5
+        fk = forward_kinematics(m, q)
+        ee = m.body_name2id("ee_link")
+        centre = fk["xpos"][ee] - np.array([0, -0.005, 0.16])                 # MujocoController.py:341-345,493
+        assert np.linalg.norm(centre - xyz) < 1e-6
+        assert np.allclose(fk["xmat"][ee][:, 0], [0, 0, -1], atol=1e-5)       # ee x-axis points down
+    ok, _ = o.ik([2.0, 2.0, 2.0])
+    assert not ok                                                             # the reference's 2 cm acceptance test (:502-510)
+
+
+def test_grasp_script_golden(model_it1):
+    """Seeded oracle runs committed by tools/gen_golden.py: detects drift of the oracle itself on the GPU box."""
+    with open(os.path.join(GOLD, "oracle_grasp.json")) as f:
+        rec = json.load(f)
+    for r in rec[:2]:
+        o = Oracle(model_it1)
+        o.reset(r["seed"], 1, True)
+        assert np.abs(o.get_state()["qpos"] - np.array(r["settled_qpos"])).max() < 1e-9
+        rew, ps, pr = o.grasp_attempt(r["action"], r["rot"], 0)
+        assert rew == r["reward"] and ps.tolist() == r["phase_steps"] and pr.tolist() == r["phase_result"]
+        assert np.abs(o.get_state()["qpos"][:8] - np.array(r["final_qpos"])[:8]).max() < 1e-7
+    assert any(r["reward"] == 1 for r in rec) and any(r["reward"] == 0 for r in rec)
+
+
+def test_console_png_vector(model_2f):
+    """The reference's only recorded input/output pair (media/console.png): pixel (136,80), z=0.89 -> world xy."""
+    from mujoco_rl_ur5_amd.controller import MJ_Controller
+    with open(os.path.join(GOLD, "console_png.json")) as f:
+        g = json.load(f)
+
+    class _NoSim:
+        n = 1
+    c = MJ_Controller(model_2f, simulation=_NoSim())
+    depth = 2.0 - g["world"][2]
+    w = c.pixel_2_world(g["pixel"][0], g["pixel"][1], depth)
+    assert np.allclose(w, g["world"], atol=1e-6)
+    px = c.world_2_pixel(w)
+    assert (int(px[0]), int(px[1])) == tuple(g["pixel"])

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Per-phase cycle breakdown of the engine (needs tools/libur5sim_prof.so = csrc/ur5sim.hip built with -DUR5_PROFILE)."""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from mujoco_rl_ur5_amd.model import load_model
+from mujoco_rl_ur5_amd.native import BatchSim
+NAMES = ["kin", "crb", "vel", "broad", "narrow", "rows", "newton_init", "images", "linesearch", "grad+G", "H_asm", "chol", "solve", "integrate", "pid", "ik"]
+m = load_model("it1_4box")
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+sim = BatchSim(m, n, lib_path=os.path.join(os.path.dirname(os.path.abspath(__file__)), "libur5sim_prof.so"))
+sim.lib.ur5_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+def read():
+    out = np.zeros((n, 16)); sim.lib.ur5_profile_read(sim._h, out.ctypes.data_as(C.POINTER(C.c_double))); return out
+seeds = np.arange(n, dtype=np.uint64) + 20
+sim.reset(seeds, 1, 1000.0)
+c0 = sim.counters(); p = read()
+steps = c0["total_steps"].astype(float)
+print("settle: kernel %.1f ms, %d steps/env; cycles per step by phase (mean over envs):" % (sim.last_launch_ms(), steps[0]))
+for k, nm in enumerate(NAMES): print("  %-12s %10.0f" % (nm, (p[:, k] / steps).mean()))
+print("  %-12s %10.0f  (wall: %.0f cycles/step @2.4GHz)" % ("sum", (p.sum(1) / steps).mean(), sim.last_launch_ms() * 1e-3 * 2.4e9 / steps[0]))
+st = sim.get_state(); acts = np.zeros((n, 3))
+for e in range(n):
+    objs = st["qpos"][e][8:].reshape(-1, 7); k = e % 4
+    acts[e] = [objs[k, 0], -0.6 + objs[k, 1], 0.91]
+rew, ps, pr = sim.grasp_attempt(acts, rot=0, check_mode=0)
+c1 = sim.counters(); p = read(); steps = (c1["total_steps"] - c0["total_steps"]).astype(float)
+print("grasp: kernel %.1f ms, mean %d steps/env, success %.2f" % (sim.last_launch_ms(), steps.mean(), rew.mean()))
+for k, nm in enumerate(NAMES): print("  %-12s %10.0f" % (nm, (p[:, k] / steps).mean()))
+print("  %-12s %10.0f" % ("sum", (p.sum(1) / steps).mean()))
