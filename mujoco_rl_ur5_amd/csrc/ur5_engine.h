@@ -27,6 +27,11 @@
 #ifdef UR5_EMUL
 #define UR5_FN inline
 #define UR5_BIG inline
+#define UR5_ATOMIC_ADD(p, v) (*(p) += (v))
+static void* ur5_emul_lds = nullptr;
+static const Ur5DevModel* ur5_emul_model = nullptr;
+#define UR5_LDS_PTR(T) (static_cast<T*>(ur5_emul_lds))
+#define UR5_MODEL (*ur5_emul_model)
 #define PAR(i, n) for (int i = 0; i < (n); ++i)
 #define SYNC() ((void)0)
 #define WAVE_SUM(v) (v)
@@ -36,6 +41,13 @@
 #include <hip/hip_runtime.h>
 #define UR5_FN __device__ __forceinline__
 #define UR5_BIG __device__ __noinline__   // phase-sized routines: one copy in the code object, called from the script
+#define UR5_ATOMIC_ADD(p, v) __hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+// The scene lives in dynamic LDS and the model in constant memory, both reached through these file-scope symbols so that
+// every (non-inlined) phase routine addresses them with ds_* / s_load instead of flat instructions.
+extern __shared__ __attribute__((aligned(16))) double ur5_smem[];
+__constant__ Ur5DevModel ur5_cmodel;
+#define UR5_LDS_PTR(T) (reinterpret_cast<T*>(ur5_smem))
+#define UR5_MODEL ur5_cmodel
 #define PAR(i, n) for (int i = (int)threadIdx.x; i < (n); i += 64)
 #define SYNC() __syncthreads()
 #define UR5_LANE ((int)threadIdx.x)
@@ -69,7 +81,7 @@ enum { PF_KIN = 0, PF_CRB, PF_VEL, PF_BROAD, PF_NARROW, PF_ROWS, PF_NEWTON_INIT,
 namespace ur5 {
 
 enum { RES_NONE = -1, RES_SUCCESS = 0, RES_MAX_STEPS = 1, RES_IK_FAIL = 2 };
-constexpr int NB = 6;  // base directions per contact: normal, 2 tangents, torsion, 2 rolling
+constexpr int NB = 4;  // base directions per contact: normal, 2 tangents, torsion (condim <= 4; condim 6 would add 2 rolling)
 
 // ---------------------------------------------------------------------------------------------- small maths
 template <class T> struct V3 {
@@ -105,8 +117,9 @@ template <class T> UR5_FN Q4<T> qnormalize(Q4<T> q) {
 }
 template <class T> struct M3 {  // row-major
   T m[9];
-  UR5_FN V3<T> col(int j) const { return V3<T>(m[j], m[3 + j], m[6 + j]); }
-  UR5_FN V3<T> row(int i) const { return V3<T>(m[3 * i], m[3 * i + 1], m[3 * i + 2]); }
+  // selects instead of m[j]: a run-time index into a register array would push the matrix into scratch memory
+  UR5_FN V3<T> col(int j) const { return j == 0 ? V3<T>(m[0], m[3], m[6]) : (j == 1 ? V3<T>(m[1], m[4], m[7]) : V3<T>(m[2], m[5], m[8])); }
+  UR5_FN V3<T> row(int i) const { return i == 0 ? V3<T>(m[0], m[1], m[2]) : (i == 1 ? V3<T>(m[3], m[4], m[5]) : V3<T>(m[6], m[7], m[8])); }
   template <class U> UR5_FN void load(const U* p) { for (int i = 0; i < 9; i++) m[i] = (T)p[i]; }
   template <class U> UR5_FN void store(U* p) const { for (int i = 0; i < 9; i++) p[i] = m[i]; }
 };
@@ -165,6 +178,8 @@ template <class real, int NV_> struct Lds {
   real scal[16];
   double prof[PF_COUNT];
   int status, solver_iters, ncon_max;
+  real pid_dt;
+  int contacts_enabled, last_steps, total_steps;
 };
 
 // ---------------------------------------------------------------------------------------------- the engine
@@ -173,14 +188,8 @@ template <class real, int NV_> struct Engine {
   typedef V3<real> v3;
   typedef M3<real> m3;
   typedef Q4<real> q4;
-  L& S;
-  const Ur5DevModel& M;
-  real pid_dt;
-  int contacts_enabled;
-  int last_steps;
-  long total_steps;
-
-  UR5_FN Engine(L& s, const Ur5DevModel& m, real dt, int con) : S(s), M(m), pid_dt(dt), contacts_enabled(con), last_steps(0), total_steps(0) {}
+#define S (*UR5_LDS_PTR(L))
+#define M UR5_MODEL
 
   // views into the persistent record
   UR5_FN real* qpos() { return S.rec + UR5_REC_QPOS; }
@@ -193,8 +202,9 @@ template <class real, int NV_> struct Engine {
   UR5_FN real* kp() { return S.rec + UR5_REC_KP; }
   UR5_FN int nb() const { return M.nrd + M.nobj; }
 
-  UR5_FN void load(const double* rec) {
+  UR5_FN void load(const double* rec, real dt, int con) {
     PAR(i, UR5_REC_STRIDE) S.rec[i] = (real)rec[i];
+    if (UR5_LANE == 0) { S.pid_dt = dt; S.contacts_enabled = con; S.last_steps = 0; S.total_steps = 0; }
     if (UR5_LANE == 0) { S.status = 0; S.solver_iters = 0; S.ncon_max = 0; S.ncon = 0; S.nsr = 0; for (int i = 0; i < PF_COUNT; i++) S.prof[i] = 0; }
     SYNC();
     S.status = (int)S.rec[UR5_REC_MISC + 3];
@@ -202,8 +212,8 @@ template <class real, int NV_> struct Engine {
   UR5_FN void save(double* rec) {
     SYNC();
     if (UR5_LANE == 0) {
-      S.rec[UR5_REC_MISC + 0] += (real)total_steps;
-      S.rec[UR5_REC_MISC + 1] = (real)last_steps;
+      S.rec[UR5_REC_MISC + 0] += (real)S.total_steps;
+      S.rec[UR5_REC_MISC + 1] = (real)S.last_steps;
       S.rec[UR5_REC_MISC + 3] = (real)S.status;
       S.rec[UR5_REC_MISC + 4] += (real)S.solver_iters;
       S.rec[UR5_REC_MISC + 5] = maxv(S.rec[UR5_REC_MISC + 5], (real)S.ncon_max);
@@ -535,51 +545,78 @@ template <class real, int NV_> struct Engine {
     }
   }
 
-  // narrow phase for one candidate pair: up to 8 points sharing one normal (from geom1 towards geom2)
-  struct PairOut { int n; v3 normal; v3 pos[8]; real dist[8]; };
-  UR5_BIG void box_box(const GeomPose& A, v3 a, const GeomPose& B, v3 b, real margin, PairOut& out) const {
+  // ---- narrow phase. Contacts go to a Sink: mode 0 only counts them, mode 1 writes them to their LDS slots. Every candidate
+  // pair is evaluated twice (count -> wave prefix sum -> write) so that no per-lane contact array (= scratch memory) is needed;
+  // the one expensive routine, MPR, produces a single contact that is kept in registers between the two passes.
+  struct Sink { int mode, slot, n, g1, g2; };
+  struct Single { bool hit; v3 pos, normal; real dist; };
+  UR5_BIG void emit(Sink& k, v3 pos, v3 normal, real dist) const {
+    if (k.mode) {
+      int c = k.slot + k.n;
+      if (c < UR5_MAXCON) {
+        pos.store(S.cpos[c]);
+        make_frame(normal, S.cframe[c]);
+        S.cdist[c] = dist;
+        S.cg1[c] = k.g1; S.cg2[c] = k.g2;
+        S.cA[c] = body_of_geom(k.g1); S.cB[c] = body_of_geom(k.g2);
+        S.cdim[c] = M.g_condim[k.g1] > M.g_condim[k.g2] ? M.g_condim[k.g1] : M.g_condim[k.g2];
+        for (int j = 0; j < 3; j++) S.cfri[c][j] = maxv((real)M.g_friction[k.g1][j], (real)M.g_friction[k.g2][j]);
+      }
+    }
+    k.n++;
+  }
+  // box-box: separating-axis test, then the vertices of (incident face) n (reference face) enumerated directly -- incident
+  // corners inside the reference rectangle, reference corners inside the incident rectangle, edge/edge crossings -- which is
+  // the vertex set Sutherland-Hodgman clipping (oracle collide_box_box) produces, without its run-time-indexed polygon arrays.
+  UR5_BIG void box_box(const GeomPose& A, v3 a, const GeomPose& B, v3 b, real margin, Sink& out) const {
     v3 t = B.pos - A.pos;
-    real R[3][3], Q[3][3];
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { R[i][j] = dot(A.mat.col(i), B.mat.col(j)); Q[i][j] = fabs(R[i][j]); }
     v3 ta(dot(t, A.mat.col(0)), dot(t, A.mat.col(1)), dot(t, A.mat.col(2)));
     real best = -1e300; int code = -1; v3 bestn; bool flip = false;
+#pragma unroll
     for (int i = 0; i < 3; i++) {
-      real s = fabs(ta[i]) - (a[i] + b.x * Q[i][0] + b.y * Q[i][1] + b.z * Q[i][2]);
+      v3 ai = A.mat.col(i);
+      real s = fabs(ta[i]) - (a[i] + b.x * fabs(dot(ai, B.mat.col(0))) + b.y * fabs(dot(ai, B.mat.col(1))) + b.z * fabs(dot(ai, B.mat.col(2))));
       if (s > margin) return;
-      if (s > best) { best = s; code = i; bestn = A.mat.col(i); flip = ta[i] < 0; }
+      if (s > best) { best = s; code = i; bestn = ai; flip = ta[i] < 0; }
     }
+#pragma unroll
     for (int j = 0; j < 3; j++) {
-      real tb = dot(t, B.mat.col(j));
-      real s = fabs(tb) - (b[j] + a.x * Q[0][j] + a.y * Q[1][j] + a.z * Q[2][j]);
+      v3 bj = B.mat.col(j);
+      real tb = dot(t, bj);
+      real s = fabs(tb) - (b[j] + a.x * fabs(dot(A.mat.col(0), bj)) + a.y * fabs(dot(A.mat.col(1), bj)) + a.z * fabs(dot(A.mat.col(2), bj)));
       if (s > margin) return;
-      if (s > best) { best = s; code = 3 + j; bestn = B.mat.col(j); flip = tb < 0; }
+      if (s > best) { best = s; code = 3 + j; bestn = bj; flip = tb < 0; }
     }
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
-      v3 Lx = cross(A.mat.col(i), B.mat.col(j));
-      real l = norm(Lx);
-      if (l < (real)1e-6) continue;
-      Lx = Lx * ((real)1 / l);
-      real tl = dot(t, Lx), ra = 0, rb = 0;
-      for (int k = 0; k < 3; k++) { ra += a[k] * fabs(dot(A.mat.col(k), Lx)); rb += b[k] * fabs(dot(B.mat.col(k), Lx)); }
-      real s = fabs(tl) - (ra + rb);
-      if (s > margin) return;
-      if (s > best + (real)1e-6 + (real)0.05 * fabs(best)) { best = s; code = 6 + 3 * i + j; bestn = Lx; flip = tl < 0; }
-    }
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        v3 Lx = cross(A.mat.col(i), B.mat.col(j));
+        real l = norm(Lx);
+        if (l < (real)1e-6) continue;
+        Lx = Lx * ((real)1 / l);
+        real tl = dot(t, Lx), ra = 0, rb = 0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { ra += a[k] * fabs(dot(A.mat.col(k), Lx)); rb += b[k] * fabs(dot(B.mat.col(k), Lx)); }
+        real s = fabs(tl) - (ra + rb);
+        if (s > margin) return;
+        if (s > best + (real)1e-6 + (real)0.05 * fabs(best)) { best = s; code = 6 + 3 * i + j; bestn = Lx; flip = tl < 0; }
+      }
     v3 n = flip ? -bestn : bestn;
-    out.normal = n;
     if (code >= 6) {
       int i = (code - 6) / 3, j = (code - 6) % 3;
       v3 ea = A.pos, eb = B.pos;
-      for (int k = 0; k < 3; k++) if (k != i) ea = ea + A.mat.col(k) * ((dot(n, A.mat.col(k)) > 0 ? (real)1 : (real)-1) * a[k]);
-      for (int k = 0; k < 3; k++) if (k != j) eb = eb - B.mat.col(k) * ((dot(n, B.mat.col(k)) > 0 ? (real)1 : (real)-1) * b[k]);
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        if (k != i) ea = ea + A.mat.col(k) * ((dot(n, A.mat.col(k)) > 0 ? (real)1 : (real)-1) * a[k]);
+        if (k != j) eb = eb - B.mat.col(k) * ((dot(n, B.mat.col(k)) > 0 ? (real)1 : (real)-1) * b[k]);
+      }
       v3 ua = A.mat.col(i), ub = B.mat.col(j), w = ea - eb;
       real uaub = dot(ua, ub), q1 = dot(ua, w), q2 = dot(ub, w), den = (real)1 - uaub * uaub;
       real sa = 0, sb = 0;
       if (den > (real)1e-12) { sa = (uaub * q2 - q1) / den; sb = (q2 - uaub * q1) / den; }
       sa = clampv(sa, -a[i], a[i]); sb = clampv(sb, -b[j], b[j]);
-      out.pos[0] = ((ea + ua * sa) + (eb + ub * sb)) * (real)0.5;
-      out.dist[0] = best;
-      out.n = 1;
+      emit(out, ((ea + ua * sa) + (eb + ub * sb)) * (real)0.5, n, best);
       return;
     }
     bool refA = code < 3;
@@ -588,48 +625,61 @@ template <class real, int NV_> struct Engine {
     v3 r = refA ? a : b, in = refA ? b : a;
     v3 nref = refA ? n : -n;
     int iax = 0; real bd = -1;
+#pragma unroll
     for (int k = 0; k < 3; k++) { real d = fabs(dot(Ri.mat.col(k), nref)); if (d > bd) { bd = d; iax = k; } }
     real isgn = dot(Ri.mat.col(iax), nref) > 0 ? (real)-1 : (real)1;
-    v3 ic = Ri.pos + Ri.mat.col(iax) * (isgn * in[iax]);
-    int u = (iax + 1) % 3, v = (iax + 2) % 3;
-    v3 poly[16], tmp[16];
-    int np = 4;
-    v3 cu = Ri.mat.col(u) * in[u], cv = Ri.mat.col(v) * in[v];
-    poly[0] = ic + cu + cv; poly[1] = ic - cu + cv; poly[2] = ic - cu - cv; poly[3] = ic + cu - cv;
-    int ru = (ax + 1) % 3, rv = (ax + 2) % 3;
+    v3 ninc = Ri.mat.col(iax) * isgn;
+    v3 ic = Ri.pos + ninc * in[iax];
+    int iu = (iax + 1) % 3, iv = (iax + 2) % 3, ru = (ax + 1) % 3, rv = (ax + 2) % 3;
+    v3 Iu = Ri.mat.col(iu), Iv = Ri.mat.col(iv), Ru = Rr.mat.col(ru), Rv = Rr.mat.col(rv);
+    real inu = in[iu], inv_ = in[iv], hu = r[ru], hv = r[rv];
     real rsgn = dot(Rr.mat.col(ax), nref) > 0 ? (real)1 : (real)-1;
     v3 rc = Rr.pos + Rr.mat.col(ax) * (rsgn * r[ax]);
-    for (int side = 0; side < 4 && np > 0; side++) {
-      v3 pn = (side < 2 ? Rr.mat.col(ru) : Rr.mat.col(rv)) * ((side & 1) ? (real)-1 : (real)1);
-      real lim = side < 2 ? r[ru] : r[rv];
-      int nn = 0;
-      for (int k = 0; k < np; k++) {
-        v3 p0 = poly[k], p1 = poly[(k + 1) % np];
-        real d0 = dot(p0 - rc, pn) - lim, d1 = dot(p1 - rc, pn) - lim;
-        if (d0 <= 0) tmp[nn++] = p0;
-        if ((d0 < 0 && d1 > 0) || (d0 > 0 && d1 < 0)) tmp[nn++] = p0 + (p1 - p0) * (d0 / (d0 - d1));
+    // incident corners (same cyclic order as the oracle) and their reference-face coordinates
+    v3 q0 = ic + Iu * inu + Iv * inv_, q1 = ic - Iu * inu + Iv * inv_, q2 = ic - Iu * inu - Iv * inv_, q3 = ic + Iu * inu - Iv * inv_;
+    real u0 = dot(q0 - rc, Ru), u1 = dot(q1 - rc, Ru), u2 = dot(q2 - rc, Ru), u3 = dot(q3 - rc, Ru);
+    real w0 = dot(q0 - rc, Rv), w1 = dot(q1 - rc, Rv), w2 = dot(q2 - rc, Rv), w3 = dot(q3 - rc, Rv);
+#define UR5_INC(q, u, w) if (fabs(u) <= hu && fabs(w) <= hv) { real d = dot(q - rc, nref); if (d < margin) emit(out, q - nref * ((real)0.5 * d), n, d); }
+    UR5_INC(q0, u0, w0) UR5_INC(q1, u1, w1) UR5_INC(q2, u2, w2) UR5_INC(q3, u3, w3)
+#undef UR5_INC
+    real den = dot(nref, ninc);
+    if (fabs(den) > (real)1e-9) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        v3 c0 = rc + Ru * ((k & 1) ? hu : -hu) + Rv * ((k & 2) ? hv : -hv);
+        real d = dot(ic - c0, ninc) / den;
+        v3 pc = c0 + nref * d;
+        if (fabs(dot(pc - ic, Iu)) < inu && fabs(dot(pc - ic, Iv)) < inv_ && d < margin) emit(out, pc - nref * ((real)0.5 * d), n, d);
       }
-      np = nn < 8 ? nn : 8;
-      for (int k = 0; k < np; k++) poly[k] = tmp[k];
     }
-    int cnt = 0;
-    for (int k = 0; k < np; k++) {
-      real d = dot(poly[k] - rc, nref);
-      if (d < margin) { out.pos[cnt] = poly[k] - nref * ((real)0.5 * d); out.dist[cnt] = d; cnt++; }
+    // incident edge (qa -> qb) against the four reference edge lines
+#define UR5_EDGE(qa, ua, wa, qb, ub, wb)                                                                          \
+    {                                                                                                               \
+      _Pragma("unroll") for (int sd = 0; sd < 4; sd++) {                                                            \
+        real La = sd < 2 ? ua : wa, Lb = sd < 2 ? ub : wb, lim = (sd < 2 ? hu : hv) * ((sd & 1) ? (real)-1 : (real)1); \
+        real Oa = sd < 2 ? wa : ua, Ob = sd < 2 ? wb : ub, olim = sd < 2 ? hv : hu;                                 \
+        if ((La - lim) * (Lb - lim) < 0) {                                                                          \
+          real tt = (lim - La) / (Lb - La);                                                                         \
+          if (fabs(Oa + tt * (Ob - Oa)) < olim) {                                                                   \
+            v3 pe = qa + (qb - qa) * tt;                                                                            \
+            real d = dot(pe - rc, nref);                                                                            \
+            if (d < margin) emit(out, pe - nref * ((real)0.5 * d), n, d);                                           \
+          }                                                                                                         \
+        }                                                                                                           \
+      }                                                                                                             \
     }
-    out.n = cnt;
+    UR5_EDGE(q0, u0, w0, q1, u1, w1) UR5_EDGE(q1, u1, w1, q2, u2, w2) UR5_EDGE(q2, u2, w2, q3, u3, w3) UR5_EDGE(q3, u3, w3, q0, u0, w0)
+#undef UR5_EDGE
   }
-  UR5_BIG void narrow(int g1, int g2, real margin, PairOut& out) const {
-    out.n = 0;
+  UR5_BIG void narrow(int g1, int g2, real margin, Sink& out, Single& keep) const {
     int t1 = M.g_type[g1], t2 = M.g_type[g2];
     GeomPose A = geom_pose(g1), B = geom_pose(g2);
     if (t1 == UR5_GEOM_PLANE) {
       v3 n = A.mat.col(2);
-      out.normal = n;
       if (t2 == UR5_GEOM_SPHERE) {
         real r = (real)M.g_size[g2][0];
         real d = dot(B.pos - A.pos, n) - r;
-        if (d < margin) { out.pos[0] = B.pos - n * (r + (real)0.5 * d); out.dist[0] = d; out.n = 1; }
+        if (d < margin) emit(out, B.pos - n * (r + (real)0.5 * d), n, d);
       } else if (t2 == UR5_GEOM_BOX) {
         v3 s(M.g_size[g2]);
         int cnt = 0;
@@ -637,14 +687,13 @@ template <class real, int NV_> struct Engine {
           v3 l((k & 1) ? s.x : -s.x, (k & 2) ? s.y : -s.y, (k & 4) ? s.z : -s.z);
           v3 v = B.pos + mul(B.mat, l);
           real d = dot(v - A.pos, n);
-          if (d < margin) { out.pos[cnt] = v - n * ((real)0.5 * d); out.dist[cnt] = d; cnt++; }
+          if (d < margin) { emit(out, v - n * ((real)0.5 * d), n, d); cnt++; }
         }
-        out.n = cnt;
       } else {
         Shape s = make_shape(g2, 0);
         v3 v = support(s, -n);
         real d = dot(v - A.pos, n);
-        if (d < margin) { out.pos[0] = v - n * ((real)0.5 * d); out.dist[0] = d; out.n = 1; }
+        if (d < margin) emit(out, v - n * ((real)0.5 * d), n, d);
       }
     } else if (t1 == UR5_GEOM_SPHERE && t2 == UR5_GEOM_SPHERE) {
       v3 d = B.pos - A.pos;
@@ -652,7 +701,7 @@ template <class real, int NV_> struct Engine {
       real dist = len - r1 - r2;
       if (dist < margin) {
         v3 n = len > (real)1e-12 ? d * ((real)1 / len) : v3(1, 0, 0);
-        out.normal = n; out.pos[0] = A.pos + n * (r1 + (real)0.5 * dist); out.dist[0] = dist; out.n = 1;
+        emit(out, A.pos + n * (r1 + (real)0.5 * dist), n, dist);
       }
     } else if (t1 == UR5_GEOM_SPHERE && t2 == UR5_GEOM_BOX) {
       real r = (real)M.g_size[g1][0];
@@ -663,26 +712,25 @@ template <class real, int NV_> struct Engine {
       real len = norm(d);
       if (len > (real)1e-12) {
         real dist = len - r;
-        if (dist < margin) {
-          v3 n = mul(B.mat, d * ((real)1 / len));
-          out.normal = n; out.pos[0] = A.pos + n * (r + (real)0.5 * dist); out.dist[0] = dist; out.n = 1;
-        }
+        if (dist < margin) { v3 n = mul(B.mat, d * ((real)1 / len)); emit(out, A.pos + n * (r + (real)0.5 * dist), n, dist); }
       } else {
         int ax = 0; real best = 1e300;
         for (int i = 0; i < 3; i++) { real g = s[i] - fabs(cl[i]); if (g < best) { best = g; ax = i; } }
         v3 el; el.set(ax, cl[ax] >= 0 ? (real)1 : (real)-1);
         v3 e = mul(B.mat, el);
-        out.normal = -e; out.pos[0] = A.pos + e * ((real)0.5 * (best - r)); out.dist[0] = -best - r; out.n = 1;
+        emit(out, A.pos + e * ((real)0.5 * (best - r)), -e, -best - r);
       }
     } else if (t1 == UR5_GEOM_BOX && t2 == UR5_GEOM_BOX) {
       box_box(A, v3(M.g_size[g1]), B, v3(M.g_size[g2]), margin, out);
     } else {
-      Shape sa = make_shape(g1, margin), sb = make_shape(g2, margin);
-      real depth; v3 dir, pos;
-      if (mpr(sa, sb, &depth, &dir, &pos)) {
-        real dist = margin - depth;
-        if (dist < margin) { out.normal = dir; out.pos[0] = pos; out.dist[0] = dist; out.n = 1; }
+      if (out.mode == 0) {
+        Shape sa = make_shape(g1, margin), sb = make_shape(g2, margin);
+        real depth;
+        keep.hit = mpr(sa, sb, &depth, &keep.normal, &keep.pos);
+        keep.dist = margin - depth;
+        if (keep.hit && !(keep.dist < margin)) keep.hit = false;
       }
+      if (keep.hit) emit(out, keep.pos, keep.normal, keep.dist);
     }
   }
   UR5_BIG bool cull(int g1, int g2, real margin) const {  // true = cannot touch
@@ -712,7 +760,7 @@ template <class real, int NV_> struct Engine {
   UR5_BIG void collision() {
     if (UR5_LANE == 0) { S.ncon = 0; S.ncand = 0; }
     SYNC();
-    if (!contacts_enabled) return;
+    if (!S.contacts_enabled) return;
     PROF_T0();
     // broad phase: ordered compaction of the surviving pairs
     int ncand = 0;
@@ -749,38 +797,31 @@ template <class real, int NV_> struct Engine {
       int ci = UR5_LANE;
       {
 #endif
-        PairOut out;
-        out.n = 0;
-        int g1 = 0, g2 = 0;
+        Sink sink;
+        Single keep;
+        keep.hit = false;
+        sink.mode = 0; sink.slot = 0; sink.n = 0; sink.g1 = 0; sink.g2 = 0;
         real margin = 0;
         if (ci < ncand) {
           int p = S.cand[ci];
-          g1 = M.pair_g1[p]; g2 = M.pair_g2[p];
-          margin = maxv((real)M.g_margin[g1], (real)M.g_margin[g2]);
-          narrow(g1, g2, margin, out);
+          sink.g1 = M.pair_g1[p]; sink.g2 = M.pair_g2[p];
+          margin = maxv((real)M.g_margin[sink.g1], (real)M.g_margin[sink.g2]);
+          narrow(sink.g1, sink.g2, margin, sink, keep);
         }
+        int cnt = sink.n;
 #ifdef UR5_EMUL
         int slot = base;
-        base += out.n;
+        base += cnt;
 #else
-        int incl = out.n;
+        int incl = cnt;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o, 64); if (UR5_LANE >= o) incl += t; }
-        int slot = incl - out.n;
+        int slot = incl - cnt;
         base = __shfl(incl, 63, 64);
 #endif
-        for (int k = 0; k < 8; k++) {
-          if (k < out.n && slot + k < UR5_MAXCON) {
-            int c = slot + k;
-            out.pos[k].store(S.cpos[c]);
-            make_frame(out.normal, S.cframe[c]);
-            S.cdist[c] = out.dist[k];
-            S.cg1[c] = g1; S.cg2[c] = g2;
-            S.cA[c] = body_of_geom(g1); S.cB[c] = body_of_geom(g2);
-            int dim = M.g_condim[g1] > M.g_condim[g2] ? M.g_condim[g1] : M.g_condim[g2];
-            S.cdim[c] = dim;
-            for (int j = 0; j < 3; j++) S.cfri[c][j] = maxv((real)M.g_friction[g1][j], (real)M.g_friction[g2][j]);
-          }
+        if (cnt > 0) {
+          sink.mode = 1; sink.slot = slot; sink.n = 0;
+          narrow(sink.g1, sink.g2, margin, sink, keep);
         }
       }
     }
@@ -823,7 +864,8 @@ template <class real, int NV_> struct Engine {
     if (hasB) { v3 r = p - body_ref(S.cB[c]); v3 om(twB), vl(twB + 3); u = vl + cross(om, r); w = om; }
     if (hasA) { v3 r = p - body_ref(S.cA[c]); v3 om(twA), vl(twA + 3); u = u - (vl + cross(om, r)); w = w - om; }
     v3 n(S.cframe[c]), t1(S.cframe[c] + 3), t2(S.cframe[c] + 6);
-    e[0] = dot(n, u); e[1] = dot(t1, u); e[2] = dot(t2, u); e[3] = dot(n, w); e[4] = dot(t1, w); e[5] = dot(t2, w);
+    e[0] = dot(n, u); e[1] = dot(t1, u); e[2] = dot(t2, u); e[3] = dot(n, w);
+    if constexpr (NB > 4) { e[NB - 2] = dot(t1, w); e[NB - 1] = dot(t2, w); }
   }
   UR5_BIG void make_constraints() {
     // special rows are few and depend on wave-uniform data only: lane 0 builds them
@@ -1019,41 +1061,41 @@ template <class real, int NV_> struct Engine {
       for (int k = 0; k < 2 * NB - 1; k++) S.cW[c][k] = w[k];
     }
     SYNC();
-    // per-body wrench (gradient) and 6x6 twist-space Hessian accumulators: gather over contacts in index order
-    PAR(idx, nbod * 27) {
-      int b = idx / 27, ent = idx % 27;
-      real acc = 0;
-      v3 ref = body_ref(b);
-      int gi = 0, gj = 0;
-      if (ent >= 6) { int e = ent - 6; while ((gi + 1) * (gi + 2) / 2 <= e) gi++; gj = e - gi * (gi + 1) / 2; }
-      for (int c = 0; c < S.ncon; c++) {
-        bool isA = S.cA[c] == b, isB = S.cB[c] == b;
-        if (!isA && !isB) continue;
-        v3 r = v3(S.cpos[c]) - ref;
-        v3 ax[3] = {v3(S.cframe[c]), v3(S.cframe[c] + 3), v3(S.cframe[c] + 6)};
-        if (ent < 6) {
-          // wrench on this body: force F = sum fb_k a_k, moment r x F + fb_3 n + fb_4 t1 + fb_5 t2  (negated on side A)
-          v3 F = ax[0] * S.cfb[c][0] + ax[1] * S.cfb[c][1] + ax[2] * S.cfb[c][2];
-          v3 Mo = cross(r, F) + ax[0] * S.cfb[c][3] + ax[1] * S.cfb[c][4] + ax[2] * S.cfb[c][5];
-          real v = ent < 3 ? Mo[ent] : F[ent - 3];
-          acc += isB ? v : -v;
-        } else {
-          // F_k (6-vector [rot; lin]) : k<3 -> [r x a_k ; a_k], k>=3 -> [a_{k-3} ; 0];  G += sum_kl W_kl F_k F_l^T (arrow W)
-          real fi[NB], fj[NB];
-          for (int k = 0; k < 3; k++) {
-            v3 ra = cross(r, ax[k]);
-            fi[k] = gi < 3 ? ra[gi] : ax[k][gi - 3];
-            fj[k] = gj < 3 ? ra[gj] : ax[k][gj - 3];
-            fi[3 + k] = gi < 3 ? ax[k][gi] : (real)0;
-            fj[3 + k] = gj < 3 ? ax[k][gj] : (real)0;
-          }
-          const real* w = S.cW[c];
-          real v = w[0] * fi[0] * fj[0];
-          for (int k = 1; k < NB; k++) v += w[k] * (fi[0] * fj[k] + fi[k] * fj[0]) + w[NB - 1 + k] * fi[k] * fj[k];
-          acc += v;
+    // per-body wrench (gradient) and 6x6 twist-space Hessian accumulators: every contact lane scatters its two sides with
+    // LDS float atomics (ds_add_f64). Only this wavefront touches these words, so the sums are reproducible run to run.
+    PAR(idx, nbod * 27) { int b = idx / 27, ent = idx % 27; if (ent < 6) S.WB[b][ent] = 0; else S.G[b][ent - 6] = 0; }
+    SYNC();
+    PAR(c, S.ncon) {
+      v3 ax[3] = {v3(S.cframe[c]), v3(S.cframe[c] + 3), v3(S.cframe[c] + 6)};
+      real fb[NB], w[2 * NB - 1];
+      for (int k = 0; k < NB; k++) fb[k] = S.cfb[c][k];
+      for (int k = 0; k < 2 * NB - 1; k++) w[k] = S.cW[c][k];
+      v3 F = ax[0] * fb[0] + ax[1] * fb[1] + ax[2] * fb[2];
+      v3 T = ax[0] * fb[3];
+      if constexpr (NB > 4) T = T + ax[1] * fb[NB - 2] + ax[2] * fb[NB - 1];
+      for (int side = 0; side < 2; side++) {
+        int b = side == 0 ? S.cA[c] : S.cB[c];
+        if (b < 0) continue;
+        real sg = side == 0 ? (real)-1 : (real)1;
+        v3 r = v3(S.cpos[c]) - body_ref(b);
+        v3 Mo = cross(r, F) + T;
+        UR5_ATOMIC_ADD(&S.WB[b][0], sg * Mo.x); UR5_ATOMIC_ADD(&S.WB[b][1], sg * Mo.y); UR5_ATOMIC_ADD(&S.WB[b][2], sg * Mo.z);
+        UR5_ATOMIC_ADD(&S.WB[b][3], sg * F.x); UR5_ATOMIC_ADD(&S.WB[b][4], sg * F.y); UR5_ATOMIC_ADD(&S.WB[b][5], sg * F.z);
+        // F_k (6-vector [rot; lin]): k<3 -> [r x a_k ; a_k], k>=3 -> [a_{k-3} ; 0];  G += sum_kl W_kl F_k F_l^T (arrow-shaped W)
+        real Fk[NB][6];
+        for (int k = 0; k < 3; k++) {
+          v3 ra = cross(r, ax[k]);
+          Fk[k][0] = ra.x; Fk[k][1] = ra.y; Fk[k][2] = ra.z; Fk[k][3] = ax[k].x; Fk[k][4] = ax[k].y; Fk[k][5] = ax[k].z;
+          if (3 + k < NB) { Fk[3 + k][0] = ax[k].x; Fk[3 + k][1] = ax[k].y; Fk[3 + k][2] = ax[k].z; Fk[3 + k][3] = 0; Fk[3 + k][4] = 0; Fk[3 + k][5] = 0; }
         }
+        int ent = 0;
+        for (int gi = 0; gi < 6; gi++)
+          for (int gj = 0; gj <= gi; gj++, ent++) {
+            real v = w[0] * Fk[0][gi] * Fk[0][gj];
+            for (int k = 1; k < NB; k++) v += w[k] * (Fk[0][gi] * Fk[k][gj] + Fk[k][gi] * Fk[0][gj]) + w[NB - 1 + k] * Fk[k][gi] * Fk[k][gj];
+            if (v != 0) UR5_ATOMIC_ADD(&S.G[b][ent], v);
+          }
       }
-      if (ent < 6) S.WB[b][ent] = acc; else S.G[b][ent - 6] = acc;
     }
     SYNC();
     // gradient = Ma - fs - J^T f
@@ -1141,12 +1183,72 @@ template <class real, int NV_> struct Engine {
       SYNC();
     }
     PROF(PF_HASM);
-    cholesky(S.H, nv, LD); PROF(PF_CHOL);
+#ifdef UR5_EMUL
+    cholesky(S.H, nv, LD);
     chol_solve(S.H, nv, LD, S.search);
     PAR(i, nv) S.search[i] = -S.search[i];
     SYNC();
+#else
+    if (S.ncouple == 0 && M.nrd == UR5_MAXRD) factor_solve_rows<true>(); else factor_solve_rows<false>();
     PROF(PF_SOLVE);
+#endif
   }
+
+#ifndef UR5_EMUL
+  // broadcast lane `src` (wave-uniform) of a double through two v_readlane
+  static __device__ __forceinline__ real bcast(real v, int src) {
+    double d = (double)v;
+    int lo = __double2loint(d), hi = __double2hiint(d);
+    lo = __builtin_amdgcn_readlane(lo, src);
+    hi = __builtin_amdgcn_readlane(hi, src);
+    return (real)__hiloint2double(hi, lo);
+  }
+  // H (lower triangle in LDS) -> S.search = -H^-1 grad. Row i of the factor lives in the registers of lane i; the pivot row
+  // is broadcast with v_readlane, so the whole factorisation runs without touching LDS. BLOCKDIAG: no contact couples two
+  // movable bodies, H = diag(robot 8x8, object 6x6 ...) and every column only looks back to the start of its own block.
+  template <bool BLOCKDIAG> __device__ __noinline__ void factor_solve_rows() {
+    constexpr int N = NV_, LD = L::LD;
+    const int lane = threadIdx.x, nv = M.nv;
+    real Lrow[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) Lrow[j] = (lane < nv && j <= lane) ? S.H[lane * LD + j] : (j == lane ? (real)1 : (real)0);
+    real myinv = 1;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      const int k0 = BLOCKDIAG ? (j < UR5_MAXRD ? 0 : UR5_MAXRD + 6 * ((j - UR5_MAXRD) / 6)) : 0;
+      real sacc = Lrow[j];
+#pragma unroll
+      for (int k = 0; k < j; k++) if (k >= k0) sacc -= Lrow[k] * bcast(Lrow[k], j);
+      real djj = bcast(sacc, j);
+      real d = sqrt(djj < (real)1e-15 ? (real)1e-15 : djj);
+      real inv = (real)1 / d;
+      Lrow[j] = lane == j ? d : (lane > j ? sacc * inv : (real)0);
+      if (lane == j) myinv = inv;
+    }
+    real b = lane < nv ? S.search[lane] : (real)0;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      real yj = bcast(b * myinv, j);
+      b = lane == j ? yj : (lane > j ? b - Lrow[j] * yj : b);
+    }
+    // transpose the factor through LDS (H is free now): lane j then holds column j, i.e. row j of L^T
+    SYNC();
+    if (lane < nv) {
+#pragma unroll
+      for (int j = 0; j < N; j++) if (j <= lane) S.H[lane * LD + j] = Lrow[j];
+    }
+    SYNC();
+#pragma unroll
+    for (int k = 0; k < N; k++) Lrow[k] = (k >= lane && k < nv && lane < nv) ? S.H[k * LD + lane] : (real)0;
+#pragma unroll
+    for (int k = N - 1; k >= 0; k--) {
+      real xk = bcast(b * myinv, k);
+      b = lane == k ? xk : (lane < k ? b - Lrow[k] * xk : b);
+    }
+    if (lane < nv) S.search[lane] = -b;
+    SYNC();
+  }
+#endif
 
   UR5_BIG void solve_newton() {
     const int nv = M.nv;
@@ -1304,7 +1406,7 @@ template <class real, int NV_> struct Engine {
     forward();
     PROF_T0();
     integrate(); PROF(PF_INTEGRATE);
-    total_steps++;
+    if (UR5_LANE == 0) S.total_steps++;
   }
 
   // ------------------------------------------------------------------ controller layer (MujocoController.py)
@@ -1315,7 +1417,7 @@ template <class real, int NV_> struct Engine {
     PAR(a, M.nu) {
       real q = qpos()[M.act_dof[a]];
       real err = target()[a] - q;
-      real dterm = -(real)M.pid_kd[a] * (q - pid_in()[a]) / pid_dt;
+      real dterm = -(real)M.pid_kd[a] * (q - pid_in()[a]) / S.pid_dt;
       real out = clampv(kp()[a] * err + dterm, (real)M.pid_lo[a], (real)M.pid_hi[a]);
       pid_in()[a] = q; pid_out()[a] = out; ctrl()[a] = out;
       if (mask >> a & 1u) md = maxv(md, fabs(err));
@@ -1335,7 +1437,9 @@ template <class real, int NV_> struct Engine {
       step();
       steps++;
     }
-    last_steps = steps;
+    SYNC();
+    if (UR5_LANE == 0) S.last_steps = steps;
+    SYNC();
     return result;
   }
   UR5_FN unsigned mask_all() const { return (1u << M.nu) - 1u; }
@@ -1405,7 +1509,7 @@ template <class real, int NV_> struct Engine {
   }
   UR5_BIG int move_ee(v3 xyz, real tol, int max_steps) {  // :446-465
     real q5[5];
-    if (!ik(xyz, q5)) { last_steps = 0; return RES_IK_FAIL; }
+    if (!ik(xyz, q5)) { SYNC(); if (UR5_LANE == 0) S.last_steps = 0; SYNC(); return RES_IK_FAIL; }
     SYNC();
     if (UR5_LANE == 0) for (int j = 0; j < 5; j++) target()[j] = q5[j];
     SYNC();
@@ -1422,36 +1526,36 @@ template <class real, int NV_> struct Engine {
     const real rot_deg[6] = {0, 30, 60, 90, -30, -60};
     for (int i = 0; i < 12; i++) { ps[i] = 0; pr[i] = -1; }
     int result1 = move_ee(v3(coord.x, coord.y, (real)1.1), (real)0.05, 1000);
-    ps[0] = last_steps; pr[0] = result1;
+    ps[0] = S.last_steps; pr[0] = result1;
     if (result1 == RES_IK_FAIL) {
       result1 = move_ee(v3(0, (real)-0.6, (real)1.1), (real)0.05, 1000);
-      ps[0] = last_steps; pr[0] = result1;
+      ps[0] = S.last_steps; pr[0] = result1;
     }
     bool result_grasp = false;
     if (result1 != RES_MAX_STEPS) {
-      pr[1] = rotate_wrist3(rot_deg[rotation]); ps[1] = last_steps;
-      pr[2] = open_gripper(true); ps[2] = last_steps;
+      pr[1] = rotate_wrist3(rot_deg[rotation]); ps[1] = S.last_steps;
+      pr[2] = open_gripper(true); ps[2] = S.last_steps;
       int result2 = move_ee(v3(coord.x, coord.y, maxv(table_height, coord.z - (real)0.01)), (real)0.01, 300);
-      ps[3] = last_steps; pr[3] = result2;
+      ps[3] = S.last_steps; pr[3] = result2;
       if (result2 != RES_MAX_STEPS) {
         stay_ms(100);
         result_grasp = close_gripper(300) != RES_SUCCESS;
-        ps[5] = last_steps; pr[5] = result_grasp ? RES_MAX_STEPS : RES_SUCCESS;
+        ps[5] = S.last_steps; pr[5] = result_grasp ? RES_MAX_STEPS : RES_SUCCESS;
       }
     }
     set_kp0(10);
     int result_final = -1;
     if (check_mode == 1) {
-      pr[6] = move_ee(v3(coord.x, coord.y, (real)1.1), (real)0.05, 1000); ps[6] = last_steps;
-      if (result_grasp) { result_final = close_gripper(500); ps[9] = last_steps; pr[9] = result_final; }
+      pr[6] = move_ee(v3(coord.x, coord.y, (real)1.1), (real)0.05, 1000); ps[6] = S.last_steps;
+      if (result_grasp) { result_final = close_gripper(500); ps[9] = S.last_steps; pr[9] = result_final; }
     }
-    pr[7] = move_ee(v3(0, (real)-0.6, (real)1.1), (real)0.05, 1000); ps[7] = last_steps;
-    pr[8] = move_ee(v3((real)0.6, 0, (real)1.15), (real)0.01, 1200); ps[8] = last_steps;
-    if (check_mode == 0 && result_grasp) { result_final = close_gripper(1000); ps[9] = last_steps; pr[9] = result_final; }
+    pr[7] = move_ee(v3(0, (real)-0.6, (real)1.1), (real)0.05, 1000); ps[7] = S.last_steps;
+    pr[8] = move_ee(v3((real)0.6, 0, (real)1.15), (real)0.01, 1200); ps[8] = S.last_steps;
+    if (check_mode == 0 && result_grasp) { result_final = close_gripper(1000); ps[9] = S.last_steps; pr[9] = result_final; }
     bool grasped = (result_final == RES_MAX_STEPS) && result_grasp;
-    pr[10] = open_gripper(false); ps[10] = last_steps;
+    pr[10] = open_gripper(false); ps[10] = S.last_steps;
     if (grasped) stay_ms(200);
-    pr[11] = rotate_wrist3(0); ps[11] = last_steps;
+    pr[11] = rotate_wrist3(0); ps[11] = S.last_steps;
     set_kp0(20);
     return grasped ? 1 : 0;
   }
@@ -1481,7 +1585,9 @@ template <class real, int NV_> struct Engine {
     } else if (P.op == UR5_OP_STEP) {
       int n = P.max_steps[env];
       for (int i = 0; i < n; i++) step();
-      last_steps = n;
+      SYNC();
+      if (UR5_LANE == 0) S.last_steps = n;
+      SYNC();
       result = RES_SUCCESS;
     } else if (P.op == UR5_OP_IK) {
       real q5[5];
@@ -1495,7 +1601,7 @@ template <class real, int NV_> struct Engine {
     }
     if (UR5_LANE == 0) {
       if (P.result) P.result[env] = result;
-      if (P.steps) P.steps[env] = last_steps;
+      if (P.steps) P.steps[env] = S.last_steps;
 #if defined(UR5_PROFILE) && !defined(UR5_EMUL)
       if (P.debug && P.op != UR5_OP_FORWARD) for (int i = 0; i < PF_COUNT; i++) P.debug[(size_t)UR5_DEBUG_STRIDE * env + i] = S.prof[i];
 #endif
@@ -1524,5 +1630,8 @@ template <class real, int NV_> struct Engine {
     }
   }
 };
+
+#undef S
+#undef M
 
 }  // namespace ur5

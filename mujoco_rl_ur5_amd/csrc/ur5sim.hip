@@ -8,16 +8,18 @@
 #include "ur5sim_host.h"
 
 template <int NV>
-__global__ void __launch_bounds__(64) ur5_run_kernel(const Ur5DevModel* __restrict__ M, double* __restrict__ rec, Ur5Launch P) {
-  __shared__ ur5::Lds<double, NV> S;
+__global__ void __launch_bounds__(64) ur5_run_kernel(double* __restrict__ rec, Ur5Launch P) {
   const int env = blockIdx.x;
   if (env >= P.n_env) return;
-  ur5::Engine<double, NV> eng(S, *M, P.pid_dt, P.contacts_enabled);
+  ur5::Engine<double, NV> eng;
   double* r = rec + (size_t)env * UR5_REC_STRIDE;
-  eng.load(r);
+  eng.load(r, P.pid_dt, P.contacts_enabled);
   eng.run(P, env);
   eng.save(r);
 }
+
+// the model sits in __constant__ memory (one copy per device); a handle re-uploads it only when another handle used the device last
+static ur5_sim* g_model_owner[64] = {nullptr};
 
 struct HipBackend {
   hipStream_t stream = nullptr;
@@ -46,6 +48,7 @@ static int be_open(ur5_sim* h, int device_id) {
 }
 static void be_close(ur5_sim* h) {
   HipBackend* b = (HipBackend*)h->be;
+  if (g_model_owner[h->device & 63] == h) g_model_owner[h->device & 63] = nullptr;
   if (!b) return;
   (void)hipSetDevice(h->device);
   if (b->stream) (void)hipStreamSynchronize(b->stream);
@@ -80,10 +83,15 @@ static int be_d2h(ur5_sim* h, void* dst, const void* src, size_t bytes) {
 static int be_launch(ur5_sim* h, const Ur5Launch& P) {
   HipBackend* b = (HipBackend*)h->be;
   HIPCHK(hipSetDevice(h->device));
+  if (g_model_owner[h->device & 63] != h) {
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(ur5_cmodel), &h->hm, sizeof(Ur5DevModel), 0, hipMemcpyHostToDevice));
+    g_model_owner[h->device & 63] = h;
+  }
   HIPCHK(hipEventRecord(b->ev0, b->stream));
   dim3 grid(h->n), block(64);
-  if (h->nvt == 32) hipLaunchKernelGGL(ur5_run_kernel<32>, grid, block, 0, b->stream, h->dm, h->d_rec, P);
-  else hipLaunchKernelGGL(ur5_run_kernel<UR5_MAXNV>, grid, block, 0, b->stream, h->dm, h->d_rec, P);
+  if (h->nvt == 32) hipLaunchKernelGGL(ur5_run_kernel<32>, grid, block, sizeof(ur5::Lds<double, 32>), b->stream, h->d_rec, P);
+  else hipLaunchKernelGGL(ur5_run_kernel<UR5_MAXNV>, grid, block, sizeof(ur5::Lds<double, UR5_MAXNV>), b->stream, h->d_rec, P);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(b->ev1, b->stream));
   b->timed = true;

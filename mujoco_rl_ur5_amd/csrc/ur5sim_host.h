@@ -243,6 +243,7 @@ static int build_model(const void* data, size_t nbytes, int ee_body, Ur5DevModel
     dev_of_geom[g] = k;
     dev2model_geom->push_back(g);
     D.g_type[k] = geom_type[g]; D.g_condim[k] = geom_condim[g];
+    if (geom_condim[g] > 4) return fail(UR5_ERR_MODEL, "condim 6 (rolling friction) is not compiled into this build (NB = 4)");
     memcpy(D.g_size[k], geom_size + 3 * g, 24);
     D.g_rbound[k] = geom_rbound[g]; D.g_margin[k] = geom_margin[g];
     memcpy(D.g_friction[k], geom_friction + 3 * g, 24);

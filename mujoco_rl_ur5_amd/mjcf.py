@@ -16,7 +16,9 @@ Documented deviations from a real MuJoCo compile (see DESIGN.md "Model constants
     1000. With it the reference's scripted moves converge the way media/console.png records (all phases
     "success"); the double-counted ``"signed"`` / ``"legacy"`` (|volume| pyramids, MuJoCo <= 2.1 as recalled)
     variants leave a P-only steady-state error above the 0.01 rad tolerance. Kept selectable;
-  * the seven UR5 arm-link meshes are not collidable unless ``arm_collision=True``.
+  * the seven UR5 arm-link meshes are not collidable (SURVEY.md H5) unless ``arm_collision=True``;
+  * collision hulls of the gripper meshes are capped at ``maxhullvert=32`` vertices (408 / 70 / 120 in the STL hulls),
+    grown farthest-point-first; the support function of a hull is a linear scan, so this bounds the MPR cost.
 """
 from __future__ import annotations
 
@@ -146,11 +148,32 @@ def mesh_inertia_signed(tris, density, dedup=False):
     return mass, com, inertia_c
 
 
-def convex_hull_vertices(verts):
+def convex_hull_vertices(verts, maxhullvert=0):
+    """Hull vertices of a mesh; with ``maxhullvert`` > 0 the hull is grown greedily (farthest point first, the order
+    quickhull adds points) and stopped at that many vertices -- MuJoCo's ``maxhullvert`` mesh attribute [3P, 3.x]."""
     from scipy.spatial import ConvexHull
     uniq = np.unique(np.round(verts.reshape(-1, 3), 9), axis=0)
     hull = ConvexHull(uniq)
-    return uniq[np.sort(hull.vertices)]
+    pts = uniq[np.sort(hull.vertices)]
+    if maxhullvert <= 0 or len(pts) <= maxhullvert:
+        return pts
+    chosen = []
+    for ax in range(3):
+        for i in (int(np.argmin(pts[:, ax])), int(np.argmax(pts[:, ax]))):
+            if i not in chosen:
+                chosen.append(i)
+    while len(chosen) < maxhullvert:
+        try:
+            h = ConvexHull(pts[chosen])
+        except Exception:
+            h = ConvexHull(pts[chosen], qhull_options="QJ")
+        d = (pts @ h.equations[:, :3].T + h.equations[:, 3]).max(axis=1)
+        d[chosen] = -1
+        i = int(np.argmax(d))
+        if d[i] < 1e-9:
+            break
+        chosen.append(i)
+    return pts[np.sort(chosen)]
 
 
 # ----------------------------------------------------------------------------- primitives
@@ -221,7 +244,7 @@ def _expand_includes(el, basedir):
             _expand_includes(child, basedir)
 
 
-def compile_mjcf(path, *, objects=None, arm_collision=False, mesh_inertia="dedup"):
+def compile_mjcf(path, *, objects=None, arm_collision=False, mesh_inertia="dedup", maxhullvert=32):
     """Compile an MJCF file.
 
     ``objects``: optional list of dicts replacing every free object of the scene (used for the
@@ -449,7 +472,7 @@ def compile_mjcf(path, *, objects=None, arm_collision=False, mesh_inertia="dedup
             name = g["mesh"]
             if name not in mesh_cache:
                 tris = load_stl(meshes[name])
-                hull = convex_hull_vertices(tris)
+                hull = convex_hull_vertices(tris, 0 if name in _ARM_MESHES else maxhullvert)
                 if mesh_inertia == "legacy":
                     mi = mesh_inertia_legacy(tris, density)
                 elif mesh_inertia == "signed":

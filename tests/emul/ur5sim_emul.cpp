@@ -20,8 +20,10 @@ template <int NV> static void run_all(ur5_sim* h, const Ur5Launch& P) {
   L* lds = new L();
   for (int e = 0; e < h->n; e++) {
     memset((void*)lds, 0, sizeof(L));
-    ur5::Engine<double, NV> eng(*lds, *h->dm, P.pid_dt, P.contacts_enabled);
-    eng.load(h->d_rec + (size_t)e * UR5_REC_STRIDE);
+    ur5_emul_lds = lds;
+    ur5_emul_model = h->dm;
+    ur5::Engine<double, NV> eng;
+    eng.load(h->d_rec + (size_t)e * UR5_REC_STRIDE, P.pid_dt, P.contacts_enabled);
     eng.run(P, e);
     eng.save(h->d_rec + (size_t)e * UR5_REC_STRIDE);
   }
