@@ -27,6 +27,7 @@
 #ifdef UR5_EMUL
 #define UR5_FN inline
 #define UR5_BIG inline
+#define UR5_CALL inline
 #define UR5_ATOMIC_ADD(p, v) (*(p) += (v))
 static void* ur5_emul_lds = nullptr;
 static const Ur5DevModel* ur5_emul_model = nullptr;
@@ -40,7 +41,8 @@ static const Ur5DevModel* ur5_emul_model = nullptr;
 #else
 #include <hip/hip_runtime.h>
 #define UR5_FN __device__ __forceinline__
-#define UR5_BIG __device__ __noinline__   // phase-sized routines: one copy in the code object, called from the script
+#define UR5_BIG __device__ __forceinline__  // phase routines: the interpreter in run() calls each of them from one place
+#define UR5_CALL __device__ __noinline__    // small helpers with many call sites: kept as real functions
 #define UR5_ATOMIC_ADD(p, v) __hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 // The scene lives in dynamic LDS and the model in constant memory, both reached through these file-scope symbols so that
 // every (non-inlined) phase routine addresses them with ds_* / s_load instead of flat instructions.
@@ -337,7 +339,7 @@ template <class real, int NV_> struct Engine {
   }
 
   // in-place lower Cholesky of the n x n matrix A (leading dimension ld) -- left-looking, one column per step
-  UR5_BIG void cholesky(real* A, int n, int ld) {
+  UR5_CALL void cholesky(real* A, int n, int ld) {
     for (int j = 0; j < n; j++) {
       PAR(ii, n - j) {
         int i = j + ii;
@@ -357,7 +359,7 @@ template <class real, int NV_> struct Engine {
     }
   }
   // b <- (L L^T)^-1 b
-  UR5_BIG void chol_solve(const real* A, int n, int ld, real* b) {
+  UR5_CALL void chol_solve(const real* A, int n, int ld, real* b) {
     for (int k = 0; k < n; k++) {
       real yk = b[k] / A[k * ld + k];
       SYNC();
@@ -550,7 +552,7 @@ template <class real, int NV_> struct Engine {
   // the one expensive routine, MPR, produces a single contact that is kept in registers between the two passes.
   struct Sink { int mode, slot, n, g1, g2; };
   struct Single { bool hit; v3 pos, normal; real dist; };
-  UR5_BIG void emit(Sink& k, v3 pos, v3 normal, real dist) const {
+  UR5_CALL void emit(Sink& k, v3 pos, v3 normal, real dist) const {
     if (k.mode) {
       int c = k.slot + k.n;
       if (c < UR5_MAXCON) {
@@ -788,41 +790,43 @@ template <class real, int NV_> struct Engine {
     }
     SYNC();
     PROF(PF_BROAD);
-    // narrow phase: one candidate per lane; contact slots are handed out in candidate order
+    // narrow phase: one candidate per lane, two passes over ONE narrow() call site: pass 0 counts each pair's contacts, a wave
+    // prefix sum hands out the slots in candidate order, pass 1 writes them
     int base = 0;
+#ifdef UR5_EMUL
+    for (int ci = 0; ci < ncand; ci++) {
+#else
     {
-#ifdef UR5_EMUL
-      for (int ci = 0; ci < ncand; ci++) {
-#else
-      int ci = UR5_LANE;
-      {
+      const int ci = UR5_LANE;
 #endif
-        Sink sink;
-        Single keep;
-        keep.hit = false;
-        sink.mode = 0; sink.slot = 0; sink.n = 0; sink.g1 = 0; sink.g2 = 0;
-        real margin = 0;
-        if (ci < ncand) {
-          int p = S.cand[ci];
-          sink.g1 = M.pair_g1[p]; sink.g2 = M.pair_g2[p];
-          margin = maxv((real)M.g_margin[sink.g1], (real)M.g_margin[sink.g2]);
-          narrow(sink.g1, sink.g2, margin, sink, keep);
-        }
-        int cnt = sink.n;
+      Sink sink;
+      Single keep;
+      keep.hit = false;
+      sink.slot = 0; sink.n = 0; sink.g1 = 0; sink.g2 = 0;
+      real margin = 0;
+      if (ci < ncand) {
+        int p = S.cand[ci];
+        sink.g1 = M.pair_g1[p]; sink.g2 = M.pair_g2[p];
+        margin = maxv((real)M.g_margin[sink.g1], (real)M.g_margin[sink.g2]);
+      }
+      int cnt = 0;
+      for (int pass = 0; pass < 2; pass++) {
+        sink.mode = pass;
+        if (pass == 1) {
 #ifdef UR5_EMUL
-        int slot = base;
-        base += cnt;
+          sink.slot = base;
+          base += cnt;
 #else
-        int incl = cnt;
+          int incl = cnt;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o, 64); if (UR5_LANE >= o) incl += t; }
-        int slot = incl - cnt;
-        base = __shfl(incl, 63, 64);
+          for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o, 64); if (UR5_LANE >= o) incl += t; }
+          sink.slot = incl - cnt;
+          base = __shfl(incl, 63, 64);
 #endif
-        if (cnt > 0) {
-          sink.mode = 1; sink.slot = slot; sink.n = 0;
-          narrow(sink.g1, sink.g2, margin, sink, keep);
         }
+        sink.n = 0;
+        if (ci < ncand && (pass == 0 || cnt > 0)) narrow(sink.g1, sink.g2, margin, sink, keep);
+        if (pass == 0) cnt = sink.n;
       }
     }
     SYNC();
@@ -951,7 +955,7 @@ template <class real, int NV_> struct Engine {
   // ------------------------------------------------------------------ Newton solver pieces
   UR5_FN real row_mu(int c, int k) const { return k <= 2 ? S.cfri[c][0] : (k == 3 ? S.cfri[c][1] : S.cfri[c][2]); }
   // twists of every body for a dof-space vector, then base images (with or without the aref offsets)
-  UR5_BIG void images(const real* vec, bool offset, real (*out)[NB], real* srout) {
+  UR5_CALL void images(const real* vec, bool offset, real (*out)[NB], real* srout) {
     PAR(b, nb()) {
       if (b < M.nrd) {
         real v[6] = {0, 0, 0, 0, 0, 0};
@@ -979,7 +983,7 @@ template <class real, int NV_> struct Engine {
     }
     SYNC();
   }
-  UR5_BIG void mat_vec_M(const real* vec, real* out) {
+  UR5_CALL void mat_vec_M(const real* vec, real* out) {
     PAR(i, M.nv) {
       if (i < M.nrd) { real s = 0; for (int e = 0; e < M.nrd; e++) s += S.Mr[i][e] * vec[e]; out[i] = s; }
       else out[i] = S.Mobj[i - M.nrd] * vec[i];
@@ -987,7 +991,7 @@ template <class real, int NV_> struct Engine {
     SYNC();
   }
   // constraint cost of the current images (ce, sr_jar) shifted by alpha along (cde, sr_jv); also first/second derivative
-  UR5_BIG void constraint_cost(real alpha, real* cost, real* d1, real* d2) {
+  UR5_CALL void constraint_cost(real alpha, real* cost, real* d1, real* d2) {
     real c0 = 0, g1 = 0, g2 = 0;
     PAR(c, S.ncon) {
       real D = S.cD[c];
@@ -1301,9 +1305,17 @@ template <class real, int NV_> struct Engine {
     const real scale = (real)1 / ((real)M.meaninertia * (real)(nv > 1 ? nv : 1));
     const real tolerance = (real)M.tolerance;
     PROF(PF_NEWTON_INIT);
-    newton_direction();
     int iters = 0;
-    for (int it = 0; it < M.iterations; it++) {
+    real improvement = 1;
+    for (int it = 0;; it++) {
+      newton_direction();   // gradient + search direction at the current point (single call site)
+      if (it > 0) {
+        real gn = 0;
+        PAR(i, nv) gn += S.grad[i] * S.grad[i];
+        gn = WAVE_SUM(gn);
+        if (improvement < tolerance || scale * sqrt(gn) < tolerance) break;
+      }
+      if (it >= M.iterations) break;
       iters = it + 1;
       PROF_T0();
       mat_vec_M(S.search, S.Mv);
@@ -1332,24 +1344,16 @@ template <class real, int NV_> struct Engine {
       if (a <= 0) break;
       SYNC();
       PAR(i, nv) { S.x[i] += a * S.search[i]; S.Ma[i] += a * S.Mv[i]; }
-      PAR(c, S.ncon) for (int k = 0; k < NB; k++) S.ce[c][k] += a * S.cde[c][k];
-      PAR(s, S.nsr) S.sr_jar[s] += a * S.sr_jv[s];
+      PAR(c, S.ncon) for (int k = 0; k < NB; k++) { S.ce[c][k] += a * S.cde[c][k]; S.cde[c][k] = 0; }
+      PAR(s, S.nsr) { S.sr_jar[s] += a * S.sr_jv[s]; S.sr_jv[s] = 0; }
       SYNC();
       real ccn, t1, t2;
-      PAR(c, S.ncon) for (int k = 0; k < NB; k++) S.cde[c][k] = 0;
-      PAR(s, S.nsr) S.sr_jv[s] = 0;
-      SYNC();
       constraint_cost(0, &ccn, &t1, &t2);
       real newcost = gauss_cost(S.x, S.Ma) + ccn;
-      real improvement = scale * (cost - newcost);
+      improvement = scale * (cost - newcost);
       cost = newcost;
       SYNC();
       PROF(PF_LINESEARCH);
-      newton_direction();
-      real gn = 0;
-      PAR(i, nv) gn += S.grad[i] * S.grad[i];
-      gn = WAVE_SUM(gn);
-      if (improvement < tolerance || scale * sqrt(gn) < tolerance) break;
     }
     if (UR5_LANE == 0) S.solver_iters += iters;
     SYNC();
@@ -1427,27 +1431,7 @@ template <class real, int NV_> struct Engine {
     PROF(PF_PID);
     return md;
   }
-  UR5_BIG int move_group(unsigned mask, real tol, int max_steps) {  // :269-393; targets already written
-    int steps = 1, result = RES_NONE;
-    bool reached = false;
-    while (!reached) {
-      real md = pid_and_deltas(mask);
-      if (md < tol) { result = RES_SUCCESS; reached = true; }  // no break: one more sim.step() follows (:351-363)
-      if (steps > max_steps) { result = RES_MAX_STEPS; break; }
-      step();
-      steps++;
-    }
-    SYNC();
-    if (UR5_LANE == 0) S.last_steps = steps;
-    SYNC();
-    return result;
-  }
   UR5_FN unsigned mask_all() const { return (1u << M.nu) - 1u; }
-  UR5_FN void set_target(int a, real v) { SYNC(); if (UR5_LANE == 0) target()[a] = v; SYNC(); }
-  UR5_FN void stay_chunks(int chunks) { for (int c = 0; c < chunks; c++) move_group(mask_all(), (real)1e-7, 10); }  // :621-636
-  UR5_FN void stay_ms(real ms) { stay_chunks((int)ceil(ms / (real)1000 / (real)M.timestep / (real)10 - (real)1e-9)); }
-  UR5_FN int open_gripper(bool half) { set_target(6, half ? (real)0 : (real)0.4); return move_group(1u << 6, (real)0.05, 1000); }
-  UR5_FN int close_gripper(int max_steps) { set_target(6, (real)-0.4); return move_group(1u << 6, (real)0.01, max_steps); }
 
   // ee_link pose for the 6 arm angles; every lane computes it (wave-uniform)
   UR5_BIG void arm_fk(const real* q6, v3* p, m3* Rout, v3* axes, v3* anchors) const {
@@ -1507,97 +1491,180 @@ template <class real, int NV_> struct Engine {
     for (int j = 0; j < 5; j++) out5[j] = q[j];
     return norm(p - tgt) <= (real)0.02;
   }
-  UR5_BIG int move_ee(v3 xyz, real tol, int max_steps) {  // :446-465
-    real q5[5];
-    if (!ik(xyz, q5)) { SYNC(); if (UR5_LANE == 0) S.last_steps = 0; SYNC(); return RES_IK_FAIL; }
-    SYNC();
-    if (UR5_LANE == 0) for (int j = 0; j < 5; j++) target()[j] = q5[j];
-    SYNC();
-    return move_group(0x1fu, tol, max_steps);
-  }
-  UR5_FN int rotate_wrist3(real degrees) {  // GraspingEnv.py:193-197
-    set_target(5, degrees * (real)3.14159265358979323846 / (real)180);
-    return move_group(mask_all(), (real)0.05, 500);
-  }
-  UR5_FN void set_kp0(real v) { SYNC(); if (UR5_LANE == 0) kp()[0] = v; SYNC(); }
+  // ------------------------------------------------------------------ one launch = one script per scene
+  // Every operation of the C ABI is a short script over ONE blocking primitive, "move the group until converged or out of
+  // steps" (MujocoController.py:269-393). The interpreter below keeps a wave-uniform program counter and has exactly one
+  // call site for ik(), pid_and_deltas() and step(), so the whole physics step is inlined once into the kernel.
+  struct Prim {
+    bool done, need_ik;
+    int repeat;           // stay(): number of 10-step chunks; otherwise 1
+    unsigned mask;
+    real tol;
+    int max_steps;
+    v3 xyz;               // gripper-centre target for need_ik
+  };
+  UR5_FN void write_target(int a, real v) { SYNC(); if (UR5_LANE == 0) target()[a] = v; SYNC(); }
+  UR5_FN void write_kp0(real v) { SYNC(); if (UR5_LANE == 0) kp()[0] = v; SYNC(); }
+  UR5_FN int stay_chunks_for(real ms) const { return (int)ceil(ms / (real)1000 / (real)M.timestep / (real)10 - (real)1e-9); }  // :621-636, H2
 
-  // GraspingEnv.py:205-386 (check_mode 1: the IT1 variant of README.md:20); mirrors oracle Sim::grasp_attempt()
-  UR5_BIG int grasp_attempt(v3 coord, int rotation, int check_mode, real table_height, int* ps, int* pr) {
-    const real rot_deg[6] = {0, 30, 60, 90, -30, -60};
-    for (int i = 0; i < 12; i++) { ps[i] = 0; pr[i] = -1; }
-    int result1 = move_ee(v3(coord.x, coord.y, (real)1.1), (real)0.05, 1000);
-    ps[0] = S.last_steps; pr[0] = result1;
-    if (result1 == RES_IK_FAIL) {
-      result1 = move_ee(v3(0, (real)-0.6, (real)1.1), (real)0.05, 1000);
-      ps[0] = S.last_steps; pr[0] = result1;
-    }
-    bool result_grasp = false;
-    if (result1 != RES_MAX_STEPS) {
-      pr[1] = rotate_wrist3(rot_deg[rotation]); ps[1] = S.last_steps;
-      pr[2] = open_gripper(true); ps[2] = S.last_steps;
-      int result2 = move_ee(v3(coord.x, coord.y, maxv(table_height, coord.z - (real)0.01)), (real)0.01, 300);
-      ps[3] = S.last_steps; pr[3] = result2;
-      if (result2 != RES_MAX_STEPS) {
-        stay_ms(100);
-        result_grasp = close_gripper(300) != RES_SUCCESS;
-        ps[5] = S.last_steps; pr[5] = result_grasp ? RES_MAX_STEPS : RES_SUCCESS;
-      }
-    }
-    set_kp0(10);
-    int result_final = -1;
-    if (check_mode == 1) {
-      pr[6] = move_ee(v3(coord.x, coord.y, (real)1.1), (real)0.05, 1000); ps[6] = S.last_steps;
-      if (result_grasp) { result_final = close_gripper(500); ps[9] = S.last_steps; pr[9] = result_final; }
-    }
-    pr[7] = move_ee(v3(0, (real)-0.6, (real)1.1), (real)0.05, 1000); ps[7] = S.last_steps;
-    pr[8] = move_ee(v3((real)0.6, 0, (real)1.15), (real)0.01, 1200); ps[8] = S.last_steps;
-    if (check_mode == 0 && result_grasp) { result_final = close_gripper(1000); ps[9] = S.last_steps; pr[9] = result_final; }
-    bool grasped = (result_final == RES_MAX_STEPS) && result_grasp;
-    pr[10] = open_gripper(false); ps[10] = S.last_steps;
-    if (grasped) stay_ms(200);
-    pr[11] = rotate_wrist3(0); ps[11] = S.last_steps;
-    set_kp0(20);
-    return grasped ? 1 : 0;
-  }
-
-  // ------------------------------------------------------------------ one launch = one scripted operation per scene
   UR5_FN void run(const Ur5Launch& P, int env) {
-    int result = RES_NONE;
-    if (P.op == UR5_OP_MOVE) {
-      unsigned mask = P.group_mask[env];
-      SYNC();
-      if (UR5_LANE == 0 && P.target) {
-        int k = 0;
-        for (int a = 0; a < M.nu; a++) if (mask >> a & 1u) { double t = P.target[8 * env + k++]; if (t == t) target()[a] = (real)t; }
+    const int op = P.op;
+    int pc = 0, result = RES_NONE, last_res = RES_NONE, last_n = 0;
+    // grasp-script registers (GraspingEnv.py:205-386; mirrors oracle Sim::grasp_attempt)
+    v3 coord;
+    int rotation = 0, result1 = RES_NONE, result_final = RES_NONE;
+    bool result_grasp = false, grasped = false;
+    if (op == UR5_OP_GRASP || op == UR5_OP_MOVE_EE || op == UR5_OP_IK) coord = v3((real)P.target[8 * env], (real)P.target[8 * env + 1], (real)P.target[8 * env + 2]);
+    if (op == UR5_OP_GRASP) {
+      rotation = (int)P.target[8 * env + 3];
+      if (UR5_LANE == 0) for (int i = 0; i < 12; i++) { if (P.phase_steps) P.phase_steps[12 * env + i] = 0; if (P.phase_result) P.phase_result[12 * env + i] = -1; }
+    }
+    auto record = [&](int slot, int res, int n) {
+      if (UR5_LANE == 0) { if (P.phase_steps) P.phase_steps[12 * env + slot] = n; if (P.phase_result) P.phase_result[12 * env + slot] = res; }
+    };
+    for (;;) {
+      Prim pr;
+      pr.done = false; pr.need_ik = false; pr.repeat = 1; pr.mask = 0; pr.tol = 0; pr.max_steps = 0;
+      int slot = -1;       // phase slot the primitive reports into (grasp script)
+      // ---------------- script logic: consume the previous result, choose the next primitive
+      if (op == UR5_OP_MOVE) {
+        if (pc == 0) {
+          pr.mask = P.group_mask[env];
+          SYNC();
+          if (UR5_LANE == 0 && P.target) {
+            int k = 0;
+            for (int a = 0; a < M.nu; a++) if (pr.mask >> a & 1u) { double t = P.target[8 * env + k++]; if (t == t) target()[a] = (real)t; }
+          }
+          SYNC();
+          pr.tol = (real)P.tol[env]; pr.max_steps = P.max_steps[env];
+        } else { result = last_res; pr.done = true; }
+      } else if (op == UR5_OP_STAY) {
+        if (pc == 0) { pr.mask = mask_all(); pr.tol = (real)1e-7; pr.max_steps = 10; pr.repeat = P.max_steps[env]; }
+        else { result = RES_SUCCESS; pr.done = true; }
+      } else if (op == UR5_OP_MOVE_EE) {
+        if (pc == 0) { pr.need_ik = true; pr.xyz = coord; pr.mask = 0x1fu; pr.tol = (real)P.tol[env]; pr.max_steps = P.max_steps[env]; }
+        else { result = last_res; pr.done = true; }
+      } else if (op == UR5_OP_GRASP) {
+        const real table_height = (real)P.table_height;
+        bool chosen = false;
+        while (!chosen) {
+          chosen = true;
+          switch (pc) {
+            case 0:   // :212 move above the target
+              pr.need_ik = true; pr.xyz = v3(coord.x, coord.y, (real)1.1); pr.mask = 0x1fu; pr.tol = (real)0.05; pr.max_steps = 1000; slot = 0; break;
+            case 1:   // :227-239 centre fallback when the IK failed
+              result1 = last_res;
+              if (result1 == RES_IK_FAIL) { pr.need_ik = true; pr.xyz = v3(0, (real)-0.6, (real)1.1); pr.mask = 0x1fu; pr.tol = (real)0.05; pr.max_steps = 1000; slot = 0; }
+              else { pc = 3; chosen = false; }
+              break;
+            case 2: result1 = last_res; pc = 3; chosen = false; break;
+            case 3:   // :242 stuck -> skip the grasp; else :252 rotate the wrist
+              if (result1 == RES_MAX_STEPS) { pc = 9; chosen = false; break; }
+              {
+                const real rot_deg[6] = {0, 30, 60, 90, -30, -60};
+                real deg = rotation == 0 ? rot_deg[0] : rotation == 1 ? rot_deg[1] : rotation == 2 ? rot_deg[2] : rotation == 3 ? rot_deg[3] : rotation == 4 ? rot_deg[4] : rot_deg[5];
+                write_target(5, deg * (real)3.14159265358979323846 / (real)180);
+              }
+              pr.mask = mask_all(); pr.tol = (real)0.05; pr.max_steps = 500; slot = 1; break;
+            case 4:   // :255 open_gripper(half=True)
+              write_target(6, (real)0); pr.mask = 1u << 6; pr.tol = (real)0.05; pr.max_steps = 1000; slot = 2; break;
+            case 5:   // :258-269 descend
+              pr.need_ik = true; pr.xyz = v3(coord.x, coord.y, maxv(table_height, coord.z - (real)0.01)); pr.mask = 0x1fu; pr.tol = (real)0.01; pr.max_steps = 300; slot = 3; break;
+            case 6:   // :272-277 could not reach -> no grasp; else stay(100)
+              if (last_res == RES_MAX_STEPS) { pc = 9; chosen = false; break; }
+              pr.mask = mask_all(); pr.tol = (real)1e-7; pr.max_steps = 10; pr.repeat = stay_chunks_for(100); break;
+            case 7:   // :278 grasp() = close_gripper(max_steps=300)
+              write_target(6, (real)-0.4); pr.mask = 1u << 6; pr.tol = (real)0.01; pr.max_steps = 300; break;
+            case 8:
+              result_grasp = last_res != RES_SUCCESS;
+              record(5, result_grasp ? RES_MAX_STEPS : RES_SUCCESS, last_n);
+              pc = 9; chosen = false; break;
+            case 9:   // :282
+              write_kp0(10);
+              if (P.check_mode == 1) { pr.need_ik = true; pr.xyz = v3(coord.x, coord.y, (real)1.1); pr.mask = 0x1fu; pr.tol = (real)0.05; pr.max_steps = 1000; slot = 6; }
+              else { pc = 12; chosen = false; }
+              break;
+            case 10:  // IT1 (README.md:20): 500-step closing check right after lifting
+              if (result_grasp) { write_target(6, (real)-0.4); pr.mask = 1u << 6; pr.tol = (real)0.01; pr.max_steps = 500; slot = 9; }
+              else { pc = 12; chosen = false; }
+              break;
+            case 11: result_final = last_res; pc = 12; chosen = false; break;
+            case 12:  // :285 back above the table centre
+              pr.need_ik = true; pr.xyz = v3(0, (real)-0.6, (real)1.1); pr.mask = 0x1fu; pr.tol = (real)0.05; pr.max_steps = 1000; slot = 7; break;
+            case 13:  // :297 to the drop position
+              pr.need_ik = true; pr.xyz = v3((real)0.6, 0, (real)1.15); pr.mask = 0x1fu; pr.tol = (real)0.01; pr.max_steps = 1200; slot = 8; break;
+            case 14:  // :312-321 closing check at the drop position
+              if (P.check_mode == 0 && result_grasp) { write_target(6, (real)-0.4); pr.mask = 1u << 6; pr.tol = (real)0.01; pr.max_steps = 1000; slot = 9; }
+              else { pc = 16; chosen = false; }
+              break;
+            case 15: result_final = last_res; pc = 16; chosen = false; break;
+            case 16:  // :327, :338 open the gripper
+              grasped = (result_final == RES_MAX_STEPS) && result_grasp;
+              write_target(6, (real)0.4); pr.mask = 1u << 6; pr.tol = (real)0.05; pr.max_steps = 1000; slot = 10; break;
+            case 17:  // :341-342
+              if (grasped) { pr.mask = mask_all(); pr.tol = (real)1e-7; pr.max_steps = 10; pr.repeat = stay_chunks_for(200); }
+              else { pc = 18; chosen = false; }
+              break;
+            case 18:  // :345 rotate back
+              write_target(5, (real)0); pr.mask = mask_all(); pr.tol = (real)0.05; pr.max_steps = 500; slot = 11; break;
+            default:  // :347
+              write_kp0(20);
+              result = grasped ? 1 : 0;
+              pr.done = true; break;
+          }
+        }
+      } else if (op == UR5_OP_STEP) {
+        if (pc == 0) { pr.mask = 0; pr.tol = (real)-1; pr.max_steps = P.max_steps[env]; pr.repeat = -1; }   // repeat < 0: raw sim.step() x max_steps
+        else { result = RES_SUCCESS; pr.done = true; }
+      } else if (op == UR5_OP_IK) {
+        if (pc == 0) { pr.need_ik = true; pr.xyz = coord; pr.repeat = 0; }
+        else { result = last_res; pr.done = true; }
+      } else {  // UR5_OP_FORWARD
+        if (pc == 0) pr.repeat = -2; else { result = RES_SUCCESS; pr.done = true; }
+      }
+      if (pr.done) break;
+      pc++;
+      // ---------------- the primitive
+      int res = RES_NONE, steps = 0;
+      bool ikfail = false;
+      if (pr.need_ik) {   // :446-465 move_ee = ik + move_group("Arm")
+        PROF_T0();
+        real q5[5];
+        bool ok = ik(pr.xyz, q5);
+        SYNC();
+        if (ok && op != UR5_OP_IK) { if (UR5_LANE == 0) for (int j = 0; j < 5; j++) target()[j] = q5[j]; }
+        if (op == UR5_OP_IK && UR5_LANE == 0 && P.out) for (int j = 0; j < 5; j++) P.out[8 * env + j] = (double)q5[j];
+        SYNC();
+        ikfail = !ok;
+        res = ok ? RES_SUCCESS : RES_IK_FAIL;
+        PROF(PF_IK);
+      }
+      if (pr.repeat == -2) {
+        forward();
+        if (P.debug) dump(P.debug + (size_t)UR5_DEBUG_STRIDE * env);
+      } else if (!ikfail && pr.repeat != 0) {
+        const bool raw = pr.repeat < 0;
+        const int reps = raw ? 1 : pr.repeat;
+        for (int rep = 0; rep < reps; rep++) {
+          steps = 1; res = RES_NONE;
+          bool reached = false;
+          while (!reached) {   // MujocoController.py:318-382
+            if (!raw) {
+              real md = pid_and_deltas(pr.mask);
+              if (md < pr.tol) { res = RES_SUCCESS; reached = true; }   // no break: one more sim.step() follows (:351-363)
+            }
+            if (steps > pr.max_steps) { res = RES_MAX_STEPS; break; }
+            step();
+            steps++;
+          }
+        }
+        if (raw) { steps = pr.max_steps; res = RES_SUCCESS; }
       }
       SYNC();
-      result = move_group(mask, (real)P.tol[env], P.max_steps[env]);
-    } else if (P.op == UR5_OP_STAY) {
-      stay_chunks(P.max_steps[env]);
-      result = RES_SUCCESS;
-    } else if (P.op == UR5_OP_MOVE_EE) {
-      result = move_ee(v3((real)P.target[8 * env], (real)P.target[8 * env + 1], (real)P.target[8 * env + 2]), (real)P.tol[env], P.max_steps[env]);
-    } else if (P.op == UR5_OP_GRASP) {
-      int ps[12], pr[12];
-      result = grasp_attempt(v3((real)P.target[8 * env], (real)P.target[8 * env + 1], (real)P.target[8 * env + 2]), (int)P.target[8 * env + 3],
-                             P.check_mode, (real)P.table_height, ps, pr);
-      if (UR5_LANE == 0) for (int i = 0; i < 12; i++) { if (P.phase_steps) P.phase_steps[12 * env + i] = ps[i]; if (P.phase_result) P.phase_result[12 * env + i] = pr[i]; }
-    } else if (P.op == UR5_OP_STEP) {
-      int n = P.max_steps[env];
-      for (int i = 0; i < n; i++) step();
+      if (UR5_LANE == 0) S.last_steps = steps;
       SYNC();
-      if (UR5_LANE == 0) S.last_steps = n;
-      SYNC();
-      result = RES_SUCCESS;
-    } else if (P.op == UR5_OP_IK) {
-      real q5[5];
-      bool ok = ik(v3((real)P.target[8 * env], (real)P.target[8 * env + 1], (real)P.target[8 * env + 2]), q5);
-      if (UR5_LANE == 0 && P.out) for (int j = 0; j < 5; j++) P.out[8 * env + j] = (double)q5[j];
-      result = ok ? RES_SUCCESS : RES_IK_FAIL;
-    } else if (P.op == UR5_OP_FORWARD) {
-      forward();
-      if (P.debug) dump(P.debug + (size_t)UR5_DEBUG_STRIDE * env);
-      result = RES_SUCCESS;
+      last_res = res; last_n = steps;
+      if (slot >= 0) record(slot, res, steps);
     }
     if (UR5_LANE == 0) {
       if (P.result) P.result[env] = result;
@@ -1609,7 +1676,7 @@ template <class real, int NV_> struct Engine {
   }
 
   // introspection for the parity tests: [0] ncon, [1] nsr, [2..] fixed sections (see tests/test_parity_forward.py)
-  UR5_BIG void dump(double* out) {
+  UR5_CALL void dump(double* out) {
     SYNC();
     if (UR5_LANE != 0) return;
     int o = 0;
