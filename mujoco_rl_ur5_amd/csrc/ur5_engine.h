@@ -153,32 +153,47 @@ template <class real, int NV_> struct Lds {
   static constexpr int NV = NV_;
   static constexpr int LD = NV_ + 1;                 // padded leading dimension of H (odd multiple of the bank width)
   real rec[UR5_REC_STRIDE];                          // persistent state, same layout as the HBM record
-  // kinematics
-  real jq[UR5_MAXRD][4];
-  real bpos[UR5_MAXB][3], bmat[UR5_MAXB][9], bquat[UR5_MAXRD][4];
-  real anchor[UR5_MAXRD][3], axis[UR5_MAXRD][3], cdof[UR5_MAXRD][6], cdd[UR5_MAXRD][6];
-  real cinert[UR5_MAXRD][10], buf[UR5_MAXRD][6], cfrc[UR5_MAXRD][6];
-  real cvel[UR5_MAXB][6];                            // body twist velocity [rot; lin] about the body's reference point
+  // kinematics that the Newton phase still needs
+  real bpos[UR5_MAXB][3], bmat[UR5_MAXB][9], cdof[UR5_MAXRD][6];
   real Mr[UR5_MAXRD][UR5_MAXRD + 1], Lr[UR5_MAXRD][UR5_MAXRD + 1], Ld[UR5_MAXRD][UR5_MAXRD + 1];
   real Mobj[6 * UR5_MAXOBJ];
-  real dgpos[UR5_MAXDG][3], dgmat[UR5_MAXDG][9];
+#ifdef UR5_EMUL
+  static constexpr int HSIZE = NV_ * (NV_ + 1);      // unpacked staging, generic LDS Cholesky
+#define UR5_HIDX(i, j) ((i) * (NV_ + 1) + (j))
+#else
+  static constexpr int HSIZE = NV_ * (NV_ + 1) / 2;  // packed lower triangle
+#define UR5_HIDX(i, j) ((i) * ((i) + 1) / 2 + (j))
+#endif
+  // The Hessian staging area shares its LDS with everything that is dead once the constraint rows exist: per-step
+  // kinematic temporaries, body velocities and the moving geoms' poses are all recomputed by the next step.
+  union {
+    struct {
+      real jq[UR5_MAXRD][4], bquat[UR5_MAXRD][4], anchor[UR5_MAXRD][3], axis[UR5_MAXRD][3], cdd[UR5_MAXRD][6];
+      real cinert[UR5_MAXRD][10], buf[UR5_MAXRD][6], cfrc[UR5_MAXRD][6];
+      real cvel[UR5_MAXB][6];                        // body twist velocity [rot; lin] about the body's reference point
+      real dgpos[UR5_MAXDG][3], dgmat[UR5_MAXDG][9];
+    };
+    real H[HSIZE];
+  };
   // dynamics vectors (dof space)
   real fs[NV_], as[NV_], x[NV_], Ma[NV_], grad[NV_], search[NV_], Mv[NV_], tmpv[NV_ + 4];
   // contacts
   int ncon, nsr, ncand, ncouple;
+  unsigned bodymask;   // cbodies that carry at least one contact
   int cA[UR5_MAXCON], cB[UR5_MAXCON], cdim[UR5_MAXCON], cg1[UR5_MAXCON], cg2[UR5_MAXCON];
-  int cand[UR5_MAXCAND], couple[UR5_MAXCON];
-  real cpos[UR5_MAXCON][3], cframe[UR5_MAXCON][9], cdist[UR5_MAXCON], cfri[UR5_MAXCON][3];
-  real cD[UR5_MAXCON], cbv[UR5_MAXCON], ckr[UR5_MAXCON];
-  real cvb[UR5_MAXCON][NB], ce[UR5_MAXCON][NB], cde[UR5_MAXCON][NB], cfb[UR5_MAXCON][NB], cW[UR5_MAXCON][2 * NB - 1];
+  short cand[UR5_MAXCAND];
+  int couple[UR5_MAXCON];
+  real cpos[UR5_MAXCON][3], cframe[UR5_MAXCON][9], cdist[UR5_MAXCON], cfri[UR5_MAXCON][NB > 4 ? 3 : 2];
+  real cD[UR5_MAXCON];
+  real ceoff[UR5_MAXCON][NB], ce[UR5_MAXCON][NB], cde[UR5_MAXCON][NB], cfn[UR5_MAXCON];   // ceoff: -aref in base space; cfn: normal force
   // special rows (joint equality, joint limits): jar = c1 x[d1] + c2 x[d2] - aref
   int sr_d1[UR5_MAXSR], sr_d2[UR5_MAXSR], sr_uni[UR5_MAXSR];
   real sr_c1[UR5_MAXSR], sr_c2[UR5_MAXSR], sr_D[UR5_MAXSR], sr_aref[UR5_MAXSR], sr_jar[UR5_MAXSR], sr_jv[UR5_MAXSR];
   // body accumulators (twist space)
   real tw[UR5_MAXB][6], WB[UR5_MAXB][6], G[UR5_MAXB][21];
-  real H[NV_ * (NV_ + 1)];
-  real scal[16];
+#if defined(UR5_PROFILE) && !defined(UR5_EMUL)
   double prof[PF_COUNT];
+#endif
   int status, solver_iters, ncon_max;
   real pid_dt;
   int contacts_enabled, last_steps, total_steps;
@@ -207,7 +222,10 @@ template <class real, int NV_> struct Engine {
   UR5_FN void load(const double* rec, real dt, int con) {
     PAR(i, UR5_REC_STRIDE) S.rec[i] = (real)rec[i];
     if (UR5_LANE == 0) { S.pid_dt = dt; S.contacts_enabled = con; S.last_steps = 0; S.total_steps = 0; }
-    if (UR5_LANE == 0) { S.status = 0; S.solver_iters = 0; S.ncon_max = 0; S.ncon = 0; S.nsr = 0; for (int i = 0; i < PF_COUNT; i++) S.prof[i] = 0; }
+    if (UR5_LANE == 0) { S.status = 0; S.solver_iters = 0; S.ncon_max = 0; S.ncon = 0; S.nsr = 0; }
+#if defined(UR5_PROFILE) && !defined(UR5_EMUL)
+    if (UR5_LANE == 0) for (int i = 0; i < PF_COUNT; i++) S.prof[i] = 0;
+#endif
     SYNC();
     S.status = (int)S.rec[UR5_REC_MISC + 3];
   }
@@ -334,9 +352,84 @@ template <class real, int NV_> struct Engine {
       S.Ld[d][e] = S.Mr[d][e] + (d == e ? h * (real)M.rd_damping[d] : (real)0);
     }
     SYNC();
+#ifdef UR5_EMUL
     cholesky(&S.Lr[0][0], M.nrd, UR5_MAXRD + 1);
     cholesky(&S.Ld[0][0], M.nrd, UR5_MAXRD + 1);
+#else
+    {   // lanes 0-7: rows of Mr, lanes 8-15: rows of Mr + h B; both factored at once (block-parallel register Cholesky)
+      const int lane = UR5_LANE, nrd = M.nrd;
+      Blk b;
+      b.size = lane < 2 * UR5_MAXRD ? nrd : 0;
+      b.base = lane < UR5_MAXRD ? 0 : UR5_MAXRD;
+      b.loc = lane - b.base;
+      if (b.loc >= nrd) b.size = 0;
+      if (b.size == 0) { b.base = lane; b.loc = 0; }
+      real r[UR5_MAXRD];
+      real (*A)[UR5_MAXRD + 1] = lane < UR5_MAXRD ? S.Lr : S.Ld;
+#pragma unroll
+      for (int j = 0; j < UR5_MAXRD; j++) r[j] = (b.size > 0 && j <= b.loc) ? A[b.loc][j] : (real)0;
+      blk_cholesky(r, b);
+      if (b.size > 0) {
+#pragma unroll
+        for (int j = 0; j < UR5_MAXRD; j++) if (j <= b.loc) A[b.loc][j] = r[j];
+      }
+      SYNC();
+    }
+#endif
   }
+
+#ifndef UR5_EMUL
+  // ---- block-parallel register linear algebra: every lane owns one row of one diagonal block (<= 8 columns, held in
+  // registers r[0..7] by block-local column). All blocks are factored / solved simultaneously; the pivot row of each block
+  // is fetched with a lane shuffle (ds_bpermute), so 8 column steps serve the robot block and every object block at once.
+  struct Blk { int base, loc, size; };   // first lane of my block, my row inside it, its order (0 = lane idle)
+  static __device__ __forceinline__ real shfl_d(real v, int src) { return (real)__shfl((double)v, src, 64); }
+  // in-place Cholesky (lower, row-wise); returns 1 / (own diagonal entry)
+  static __device__ __forceinline__ real blk_cholesky(real (&r)[UR5_MAXRD], const Blk& b) {
+    real myinv = 1;
+#pragma unroll
+    for (int j = 0; j < UR5_MAXRD; j++) {
+      const bool act = j < b.size;
+      const int src = act ? b.base + j : (int)threadIdx.x;
+      real sacc = r[j];
+#pragma unroll
+      for (int k = 0; k < j; k++) sacc -= r[k] * shfl_d(r[k], src);
+      real djj = shfl_d(sacc, src);
+      djj = djj < (real)1e-15 ? (real)1e-15 : djj;
+      real inv = rsqrt(djj);
+      inv = inv * ((real)1.5 - (real)0.5 * djj * inv * inv);   // one Newton step: rsqrt -> full fp64 accuracy
+      if (act) {
+        r[j] = b.loc == j ? djj * inv : (b.loc > j ? sacc * inv : (real)0);
+        if (b.loc == j) myinv = inv;
+      }
+    }
+    return myinv;
+  }
+  // x <- (L L^T)^-1 x for every block; lt = LDS scratch of 64 x 8 reals used to transpose the factors
+  static __device__ __forceinline__ real blk_solve(const real (&r)[UR5_MAXRD], real myinv, const Blk& b, real x, real* lt) {
+    const int lane = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < UR5_MAXRD; j++) {
+      const bool act = j < b.size;
+      real yj = shfl_d(x * myinv, act ? b.base + j : lane);
+      if (act) x = b.loc == j ? yj : (b.loc > j ? x - r[j] * yj : x);
+    }
+#pragma unroll
+    for (int j = 0; j < UR5_MAXRD; j++) lt[lane * UR5_MAXRD + j] = r[j];
+    __syncthreads();
+    real t[UR5_MAXRD];
+#pragma unroll
+    for (int k = 0; k < UR5_MAXRD; k++) t[k] = (k < b.size && k > b.loc) ? lt[(b.base + k) * UR5_MAXRD + b.loc] : (real)0;
+    __syncthreads();
+#pragma unroll
+    for (int k = UR5_MAXRD - 1; k >= 0; k--) {
+      const bool act = k < b.size;
+      real xk = shfl_d(x * myinv, act ? b.base + k : lane);
+      if (act) x = b.loc == k ? xk : (b.loc < k ? x - t[k] * xk : x);
+    }
+    return x;
+  }
+#endif
 
   // in-place lower Cholesky of the n x n matrix A (leading dimension ld) -- left-looking, one column per step
   UR5_CALL void cholesky(real* A, int n, int ld) {
@@ -551,7 +644,7 @@ template <class real, int NV_> struct Engine {
   // pair is evaluated twice (count -> wave prefix sum -> write) so that no per-lane contact array (= scratch memory) is needed;
   // the one expensive routine, MPR, produces a single contact that is kept in registers between the two passes.
   struct Sink { int mode, slot, n, g1, g2; };
-  struct Single { bool hit; v3 pos, normal; real dist; };
+  struct Single { bool hit; v3 pos, normal; real dist; int sat_code; bool sat_flip; real sat_best; };
   UR5_CALL void emit(Sink& k, v3 pos, v3 normal, real dist) const {
     if (k.mode) {
       int c = k.slot + k.n;
@@ -562,7 +655,7 @@ template <class real, int NV_> struct Engine {
         S.cg1[c] = k.g1; S.cg2[c] = k.g2;
         S.cA[c] = body_of_geom(k.g1); S.cB[c] = body_of_geom(k.g2);
         S.cdim[c] = M.g_condim[k.g1] > M.g_condim[k.g2] ? M.g_condim[k.g1] : M.g_condim[k.g2];
-        for (int j = 0; j < 3; j++) S.cfri[c][j] = maxv((real)M.g_friction[k.g1][j], (real)M.g_friction[k.g2][j]);
+        for (int j = 0; j < (NB > 4 ? 3 : 2); j++) S.cfri[c][j] = maxv((real)M.g_friction[k.g1][j], (real)M.g_friction[k.g2][j]);
       }
     }
     k.n++;
@@ -570,40 +663,64 @@ template <class real, int NV_> struct Engine {
   // box-box: separating-axis test, then the vertices of (incident face) n (reference face) enumerated directly -- incident
   // corners inside the reference rectangle, reference corners inside the incident rectangle, edge/edge crossings -- which is
   // the vertex set Sutherland-Hodgman clipping (oracle collide_box_box) produces, without its run-time-indexed polygon arrays.
-  UR5_BIG void box_box(const GeomPose& A, v3 a, const GeomPose& B, v3 b, real margin, Sink& out) const {
+  // separating-axis test of two oriented boxes (15 axes, standard |R| formulation). Returns false when an axis separates them
+  // by more than margin; otherwise the axis of least penetration: code 0-2 face of A, 3-5 face of B, 6+3i+j edge i x edge j
+  // (an edge axis must beat the best face axis by 5 % to be chosen), its signed overlap `best` and whether it points B->A.
+  struct Sat { int code; bool flip; real best; };
+  UR5_FN bool box_sat(const GeomPose& A, v3 a, const GeomPose& B, v3 b, real margin, Sat& o) const {
     v3 t = B.pos - A.pos;
-    v3 ta(dot(t, A.mat.col(0)), dot(t, A.mat.col(1)), dot(t, A.mat.col(2)));
-    real best = -1e300; int code = -1; v3 bestn; bool flip = false;
+    real R[3][3], Q[3][3], tA[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-      v3 ai = A.mat.col(i);
-      real s = fabs(ta[i]) - (a[i] + b.x * fabs(dot(ai, B.mat.col(0))) + b.y * fabs(dot(ai, B.mat.col(1))) + b.z * fabs(dot(ai, B.mat.col(2))));
-      if (s > margin) return;
-      if (s > best) { best = s; code = i; bestn = ai; flip = ta[i] < 0; }
+      tA[i] = dot(t, A.mat.col(i));
+#pragma unroll
+      for (int j = 0; j < 3; j++) { R[i][j] = dot(A.mat.col(i), B.mat.col(j)); Q[i][j] = fabs(R[i][j]); }
+    }
+    real best = -1e300; int code = -1; bool flip = false;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      real s = fabs(tA[i]) - (a[i] + b.x * Q[i][0] + b.y * Q[i][1] + b.z * Q[i][2]);
+      if (s > margin) return false;
+      if (s > best) { best = s; code = i; flip = tA[i] < 0; }
     }
 #pragma unroll
     for (int j = 0; j < 3; j++) {
-      v3 bj = B.mat.col(j);
-      real tb = dot(t, bj);
-      real s = fabs(tb) - (b[j] + a.x * fabs(dot(A.mat.col(0), bj)) + a.y * fabs(dot(A.mat.col(1), bj)) + a.z * fabs(dot(A.mat.col(2), bj)));
-      if (s > margin) return;
-      if (s > best) { best = s; code = 3 + j; bestn = bj; flip = tb < 0; }
+      real tb = tA[0] * R[0][j] + tA[1] * R[1][j] + tA[2] * R[2][j];
+      real s = fabs(tb) - (b[j] + a.x * Q[0][j] + a.y * Q[1][j] + a.z * Q[2][j]);
+      if (s > margin) return false;
+      if (s > best) { best = s; code = 3 + j; flip = tb < 0; }
     }
 #pragma unroll
     for (int i = 0; i < 3; i++)
 #pragma unroll
       for (int j = 0; j < 3; j++) {
-        v3 Lx = cross(A.mat.col(i), B.mat.col(j));
-        real l = norm(Lx);
-        if (l < (real)1e-6) continue;
-        Lx = Lx * ((real)1 / l);
-        real tl = dot(t, Lx), ra = 0, rb = 0;
-#pragma unroll
-        for (int k = 0; k < 3; k++) { ra += a[k] * fabs(dot(A.mat.col(k), Lx)); rb += b[k] * fabs(dot(B.mat.col(k), Lx)); }
+        const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+        real l2 = (real)1 - R[i][j] * R[i][j];
+        if (l2 < (real)1e-12) continue;
+        real il = (real)1 / sqrt(l2);
+        real tl = (tA[i2] * R[i1][j] - tA[i1] * R[i2][j]) * il;
+        real ra = (a[i1] * Q[i2][j] + a[i2] * Q[i1][j]) * il, rb = (b[j1] * Q[i][j2] + b[j2] * Q[i][j1]) * il;
         real s = fabs(tl) - (ra + rb);
-        if (s > margin) return;
-        if (s > best + (real)1e-6 + (real)0.05 * fabs(best)) { best = s; code = 6 + 3 * i + j; bestn = Lx; flip = tl < 0; }
+        if (s > margin) return false;
+        if (s > best + (real)1e-6 + (real)0.05 * fabs(best)) { best = s; code = 6 + 3 * i + j; flip = tl < 0; }
       }
+    o.code = code; o.flip = flip; o.best = best;
+    return true;
+  }
+  // box-box: SAT (cached in `sat` between the count and the write pass), then the vertices of (incident face) n (reference
+  // face) enumerated directly -- incident corners inside the reference rectangle, reference corners inside the incident
+  // rectangle, edge/edge crossings -- the vertex set Sutherland-Hodgman clipping (oracle collide_box_box) produces, without
+  // its run-time-indexed polygon arrays.
+  UR5_BIG void box_box(const GeomPose& A, v3 a, const GeomPose& B, v3 b, real margin, Sink& out, Sat& sat) const {
+    if (out.mode == 0) { if (!box_sat(A, a, B, b, margin, sat)) { sat.code = -1; return; } }
+    if (sat.code < 0) return;
+    const int code = sat.code;
+    const bool flip = sat.flip;
+    const real best = sat.best;
+    v3 bestn;
+    if (code < 3) bestn = A.mat.col(code);
+    else if (code < 6) bestn = B.mat.col(code - 3);
+    else bestn = normalized(cross(A.mat.col((code - 6) / 3), B.mat.col((code - 6) % 3)));
     v3 n = flip ? -bestn : bestn;
     if (code >= 6) {
       int i = (code - 6) / 3, j = (code - 6) % 3;
@@ -644,6 +761,9 @@ template <class real, int NV_> struct Engine {
 #define UR5_INC(q, u, w) if (fabs(u) <= hu && fabs(w) <= hv) { real d = dot(q - rc, nref); if (d < margin) emit(out, q - nref * ((real)0.5 * d), n, d); }
     UR5_INC(q0, u0, w0) UR5_INC(q1, u1, w1) UR5_INC(q2, u2, w2) UR5_INC(q3, u3, w3)
 #undef UR5_INC
+    // the incident face lies entirely inside the reference face (a box resting on a larger one): the four corners are the
+    // whole intersection polygon -- no reference corner can be inside it and no edges cross
+    if (fabs(u0) <= hu && fabs(w0) <= hv && fabs(u1) <= hu && fabs(w1) <= hv && fabs(u2) <= hu && fabs(w2) <= hv && fabs(u3) <= hu && fabs(w3) <= hv) return;
     real den = dot(nref, ninc);
     if (fabs(den) > (real)1e-9) {
 #pragma unroll
@@ -723,7 +843,10 @@ template <class real, int NV_> struct Engine {
         emit(out, A.pos + e * ((real)0.5 * (best - r)), -e, -best - r);
       }
     } else if (t1 == UR5_GEOM_BOX && t2 == UR5_GEOM_BOX) {
-      box_box(A, v3(M.g_size[g1]), B, v3(M.g_size[g2]), margin, out);
+      Sat sat;
+      sat.code = keep.sat_code; sat.flip = keep.sat_flip; sat.best = keep.sat_best;
+      box_box(A, v3(M.g_size[g1]), B, v3(M.g_size[g2]), margin, out, sat);
+      keep.sat_code = sat.code; keep.sat_flip = sat.flip; keep.sat_best = sat.best;
     } else {
       if (out.mode == 0) {
         Shape sa = make_shape(g1, margin), sb = make_shape(g2, margin);
@@ -746,11 +869,16 @@ template <class real, int NV_> struct Engine {
     // conservative OBB refinement (keeps the finger/plate pair out of the narrow phase while the gripper is high above it)
     if (t2 == UR5_GEOM_BOX && dist_point_box(A.pos, B, v3(M.g_size[g2])) > r1 + margin) return true;
     if (t1 == UR5_GEOM_BOX && dist_point_box(B.pos, A, v3(M.g_size[g1])) > r2 + margin) return true;
+    // hull pairs go to MPR (expensive): first separate their oriented bounding boxes (g_size of a mesh = its extents)
+    if (t2 == UR5_GEOM_MESH && (t1 == UR5_GEOM_BOX || t1 == UR5_GEOM_MESH)) {
+      Sat tmp;
+      if (!box_sat(A, v3(M.g_size[g1]), B, v3(M.g_size[g2]), margin, tmp)) return true;
+    }
     return false;
   }
   UR5_FN static void make_frame(v3 n, real* fr) {
     v3 y = fabs(n.y) < (real)0.5 ? v3(0, 1, 0) : v3(0, 0, 1);
-    y = normalized(y - n * dot(n, y));
+    y = normalized(y - n * dot(n, y));   // |y - n (n.y)| >= 0.86: never degenerate
     v3 z = cross(n, y);
     n.store(fr); y.store(fr + 3); z.store(fr + 6);
   }
@@ -771,7 +899,7 @@ template <class real, int NV_> struct Engine {
       for (int p = p0; p < p0 + 64 && p < M.npair; p++) {
         int g1 = M.pair_g1[p], g2 = M.pair_g2[p];
         real margin = maxv((real)M.g_margin[g1], (real)M.g_margin[g2]);
-        if (!cull(g1, g2, margin) && ncand < UR5_MAXCAND) S.cand[ncand++] = p;
+        if (!cull(g1, g2, margin) && ncand < UR5_MAXCAND) S.cand[ncand++] = (short)p;
       }
 #else
       int p = p0 + UR5_LANE;
@@ -783,7 +911,7 @@ template <class real, int NV_> struct Engine {
       }
       unsigned long long mask = __ballot(keep);
       int slot = ncand + __popcll(mask & ((1ull << UR5_LANE) - 1ull));
-      if (keep && slot < UR5_MAXCAND) S.cand[slot] = p;
+      if (keep && slot < UR5_MAXCAND) S.cand[slot] = (short)p;
       ncand += __popcll(mask);
       if (ncand > UR5_MAXCAND) ncand = UR5_MAXCAND;
 #endif
@@ -801,7 +929,7 @@ template <class real, int NV_> struct Engine {
 #endif
       Sink sink;
       Single keep;
-      keep.hit = false;
+      keep.hit = false; keep.sat_code = -1; keep.sat_flip = false; keep.sat_best = 0;
       sink.slot = 0; sink.n = 0; sink.g1 = 0; sink.g2 = 0;
       real margin = 0;
       if (ci < ncand) {
@@ -925,8 +1053,14 @@ template <class real, int NV_> struct Engine {
       }
       S.nsr = ns;
       int nc = 0;
-      for (int c = 0; c < S.ncon; c++) if (S.cA[c] >= 0 && S.cB[c] >= 0) S.couple[nc++] = c;
+      unsigned bm = 0;
+      for (int c = 0; c < S.ncon; c++) {
+        if (S.cA[c] >= 0 && S.cB[c] >= 0) S.couple[nc++] = c;
+        if (S.cA[c] >= 0) bm |= 1u << S.cA[c];
+        if (S.cB[c] >= 0) bm |= 1u << S.cB[c];
+      }
       S.ncouple = nc;
+      S.bodymask = bm;
     }
     PAR(c, S.ncon) {
       int g1 = S.cg1[c], g2 = S.cg2[c];
@@ -944,16 +1078,18 @@ template <class real, int NV_> struct Engine {
       if (S.cdim[c] == 1) R = maxv((real)1e-15, (1 - imp) * tran / imp);
       else { real mu = fri0 * sqrt((real)1 / maxv((real)1e-15, (real)M.impratio)); R = 2 * mu * mu * R0; }
       S.cD[c] = (real)1 / R;
-      S.cbv[c] = B;
-      S.ckr[c] = K * imp * (pos - margin);
+      real ckr = K * imp * (pos - margin);
       bool hasA = S.cA[c] >= 0, hasB = S.cB[c] >= 0;
-      contact_image(c, hasA ? S.cvel[S.cA[c]] : S.cvel[0], hasB ? S.cvel[S.cB[c]] : S.cvel[0], hasA, hasB, S.cvb[c]);
+      real vb[NB];
+      contact_image(c, hasA ? S.cvel[S.cA[c]] : S.cvel[0], hasB ? S.cvel[S.cB[c]] : S.cvel[0], hasA, hasB, vb);
+      for (int k = 0; k < NB; k++) S.ceoff[c][k] = B * vb[k];
+      S.ceoff[c][0] += ckr;
     }
     SYNC();
   }
 
   // ------------------------------------------------------------------ Newton solver pieces
-  UR5_FN real row_mu(int c, int k) const { return k <= 2 ? S.cfri[c][0] : (k == 3 ? S.cfri[c][1] : S.cfri[c][2]); }
+  UR5_FN real row_mu(int c, int k) const { return k <= 2 ? S.cfri[c][0] : (k == 3 ? S.cfri[c][1] : S.cfri[c][NB > 4 ? 2 : 1]); }
   // twists of every body for a dof-space vector, then base images (with or without the aref offsets)
   UR5_CALL void images(const real* vec, bool offset, real (*out)[NB], real* srout) {
     PAR(b, nb()) {
@@ -973,7 +1109,7 @@ template <class real, int NV_> struct Engine {
       bool hasA = S.cA[c] >= 0, hasB = S.cB[c] >= 0;
       real e[NB];
       contact_image(c, hasA ? S.tw[S.cA[c]] : S.tw[0], hasB ? S.tw[S.cB[c]] : S.tw[0], hasA, hasB, e);
-      if (offset) { for (int k = 0; k < NB; k++) e[k] += S.cbv[c] * S.cvb[c][k]; e[0] += S.ckr[c]; }
+      if (offset) for (int k = 0; k < NB; k++) e[k] += S.ceoff[c][k];
       for (int k = 0; k < NB; k++) out[c][k] = e[k];
     }
     PAR(s, S.nsr) {
@@ -1019,6 +1155,24 @@ template <class real, int NV_> struct Engine {
     PAR(i, M.nv) g += (real)0.5 * (Ma[i] - S.fs[i]) * (xv[i] - S.as[i]);
     return WAVE_SUM(g);
   }
+  // base-space forces fb and the "arrow" weight matrix W (w[0] = W_00, w[k] = W_0k, w[NB-1+k] = W_kk) of contact c at S.ce
+  UR5_FN void contact_weights(int c, real* fb, real* w) const {
+    real D = S.cD[c], e0 = S.ce[c][0];
+    for (int k = 0; k < NB; k++) fb[k] = 0;
+    for (int k = 0; k < 2 * NB - 1; k++) w[k] = 0;
+    if (S.cdim[c] == 1) {
+      if (e0 < 0) { fb[0] = -D * e0; w[0] = D; }
+    } else {
+      for (int k = 1; k < S.cdim[c]; k++) {
+        real mu = row_mu(c, k), ek = mu * S.ce[c][k];
+        real rp = e0 + ek, rm = e0 - ek;
+        real ap = rp < 0 ? (real)1 : (real)0, am = rm < 0 ? (real)1 : (real)0;
+        real fp = -D * rp * ap, fm = -D * rm * am;
+        fb[0] += fp + fm; fb[k] += mu * (fp - fm);
+        w[0] += D * (ap + am); w[k] = D * mu * (ap - am); w[NB - 1 + k] = D * mu * mu * (ap + am);
+      }
+    }
+  }
   // unit twist [rot; lin] of dof-local index i of cbody b (zero when the dof does not move the body)
   UR5_FN bool unit_twist(int b, int i, real* tw) const {
     for (int k = 0; k < 6; k++) tw[k] = 0;
@@ -1035,7 +1189,8 @@ template <class real, int NV_> struct Engine {
     if (!unit_twist(A, ia, twA) || !unit_twist(B, ib, twB)) return 0;
     contact_image(c, twA, zero, true, false, ea);  // carries the minus sign of side A
     contact_image(c, zero, twB, false, true, eb);
-    const real* w = S.cW[c];
+    real fb[NB], w[2 * NB - 1];
+    contact_weights(c, fb, w);
     real v = w[0] * ea[0] * eb[0];
     for (int k = 1; k < NB; k++) v += w[k] * (ea[0] * eb[k] + ea[k] * eb[0]) + w[NB - 1 + k] * ea[k] * eb[k];
     return v;
@@ -1044,27 +1199,6 @@ template <class real, int NV_> struct Engine {
   UR5_BIG void newton_direction() {
     PROF_T0();
     const int nbod = nb();
-    PAR(c, S.ncon) {  // base forces and the "arrow" weight matrix of each contact
-      real D = S.cD[c], e0 = S.ce[c][0];
-      real fb[NB], w[2 * NB - 1];
-      for (int k = 0; k < NB; k++) fb[k] = 0;
-      for (int k = 0; k < 2 * NB - 1; k++) w[k] = 0;
-      if (S.cdim[c] == 1) {
-        if (e0 < 0) { fb[0] = -D * e0; w[0] = D; }
-      } else {
-        for (int k = 1; k < S.cdim[c]; k++) {
-          real mu = row_mu(c, k), ek = mu * S.ce[c][k];
-          real rp = e0 + ek, rm = e0 - ek;
-          real ap = rp < 0 ? (real)1 : (real)0, am = rm < 0 ? (real)1 : (real)0;
-          real fp = -D * rp * ap, fm = -D * rm * am;
-          fb[0] += fp + fm; fb[k] += mu * (fp - fm);
-          w[0] += D * (ap + am); w[k] = D * mu * (ap - am); w[NB - 1 + k] = D * mu * mu * (ap + am);
-        }
-      }
-      for (int k = 0; k < NB; k++) S.cfb[c][k] = fb[k];
-      for (int k = 0; k < 2 * NB - 1; k++) S.cW[c][k] = w[k];
-    }
-    SYNC();
     // per-body wrench (gradient) and 6x6 twist-space Hessian accumulators: every contact lane scatters its two sides with
     // LDS float atomics (ds_add_f64). Only this wavefront touches these words, so the sums are reproducible run to run.
     PAR(idx, nbod * 27) { int b = idx / 27, ent = idx % 27; if (ent < 6) S.WB[b][ent] = 0; else S.G[b][ent - 6] = 0; }
@@ -1072,8 +1206,8 @@ template <class real, int NV_> struct Engine {
     PAR(c, S.ncon) {
       v3 ax[3] = {v3(S.cframe[c]), v3(S.cframe[c] + 3), v3(S.cframe[c] + 6)};
       real fb[NB], w[2 * NB - 1];
-      for (int k = 0; k < NB; k++) fb[k] = S.cfb[c][k];
-      for (int k = 0; k < 2 * NB - 1; k++) w[k] = S.cW[c][k];
+      contact_weights(c, fb, w);
+      S.cfn[c] = fb[0];
       v3 F = ax[0] * fb[0] + ax[1] * fb[1] + ax[2] * fb[2];
       v3 T = ax[0] * fb[3];
       if constexpr (NB > 4) T = T + ax[1] * fb[NB - 2] + ax[2] * fb[NB - 1];
@@ -1123,9 +1257,12 @@ template <class real, int NV_> struct Engine {
       S.search[i] = S.grad[i];
     }
     PROF(PF_GRADG);
+#ifndef UR5_EMUL
+    if (S.ncouple == 0 && M.nrd == UR5_MAXRD) { newton_blockdiag(); PROF(PF_SOLVE); return; }
+#endif
     // Hessian, lower triangle
     const int nv = M.nv, LD = L::LD;
-    PAR(idx, nv * nv) { int i = idx / nv, j = idx % nv; if (j <= i) S.H[i * LD + j] = 0; }
+    PAR(idx, nv * nv) { int i = idx / nv, j = idx % nv; if (j <= i) S.H[UR5_HIDX(i, j)] = 0; }
     SYNC();
     PAR(idx, M.nrd * M.nrd) {
       int d = idx / M.nrd, e = idx % M.nrd;
@@ -1133,7 +1270,7 @@ template <class real, int NV_> struct Engine {
       real v = S.Mr[d][e];
       unsigned common = M.rd_desc[d] & M.rd_desc[e];
       for (int b = 0; b < M.nrd; b++) {
-        if (!(common >> b & 1u)) continue;
+        if (!(common >> b & 1u) || !(S.bodymask >> b & 1u)) continue;
         for (int i = 0; i < 6; i++) {
           real t = 0;
           for (int j = 0; j < 6; j++) t += S.G[b][sym6(i, j)] * S.cdof[e][j];
@@ -1146,7 +1283,7 @@ template <class real, int NV_> struct Engine {
         real ce = (S.sr_d1[s] == e ? S.sr_c1[s] : (real)0) + (S.sr_d2[s] == e ? S.sr_c2[s] : (real)0);
         v += S.sr_D[s] * cd * ce;
       }
-      S.H[d * LD + e] = v;
+      S.H[UR5_HIDX(d, e)] = v;
     }
     PAR(idx, M.nobj * 21) {
       int k = idx / 21, ent = idx % 21, b = M.nrd + k;
@@ -1165,7 +1302,7 @@ template <class real, int NV_> struct Engine {
         v += S.Mobj[6 * k + i];
         for (int s = 0; s < S.nsr; s++) if (S.sr_d1[s] == di && !(S.sr_uni[s] && S.sr_jar[s] >= 0)) v += S.sr_D[s] * S.sr_c1[s] * S.sr_c1[s];
       }
-      S.H[di * LD + dj] = v;
+      S.H[UR5_HIDX(di, dj)] = v;
     }
     SYNC();
     // coupling blocks: contacts between two movable bodies, one contact at a time (entries may collide across contacts)
@@ -1181,7 +1318,7 @@ template <class real, int NV_> struct Engine {
         real v = couple_term(c, A, ia, B, ib);
         if (both_robot) v = ia == ib ? 2 * v : v + couple_term(c, A, ib, B, ia);
         if (v != 0) {
-          if (da >= db) S.H[da * LD + db] += v; else S.H[db * LD + da] += v;
+          if (da >= db) S.H[UR5_HIDX(da, db)] += v; else S.H[UR5_HIDX(db, da)] += v;
         }
       }
       SYNC();
@@ -1193,10 +1330,74 @@ template <class real, int NV_> struct Engine {
     PAR(i, nv) S.search[i] = -S.search[i];
     SYNC();
 #else
-    if (S.ncouple == 0 && M.nrd == UR5_MAXRD) factor_solve_rows<true>(); else factor_solve_rows<false>();
+    (void)LD;
+    factor_solve_rows<false>();
     PROF(PF_SOLVE);
 #endif
   }
+
+#ifndef UR5_EMUL
+  // No contact couples two movable bodies: H = diag(robot 8x8, object 6x6, ...). Each lane builds ITS row of ITS block
+  // straight into registers (robot row d: Mr + sum_b cdof_d^T G_b cdof_e + equality/limit rows; object row: M + T^T G T)
+  // and the block-parallel Cholesky / solves above produce S.search = -H^-1 grad without any Hessian in LDS.
+  __device__ __forceinline__ void newton_blockdiag() {
+    const int lane = UR5_LANE, nv = M.nv;
+    Blk b;
+    real r[UR5_MAXRD];
+#pragma unroll
+    for (int j = 0; j < UR5_MAXRD; j++) r[j] = 0;
+    if (lane < UR5_MAXRD) {
+      b.base = 0; b.loc = lane; b.size = UR5_MAXRD;
+      const int d = lane;
+#pragma unroll
+      for (int e = 0; e < UR5_MAXRD; e++) if (e <= d) r[e] = S.Mr[d][e];
+      for (int bb = 0; bb < UR5_MAXRD; bb++) {
+        if (!(M.rd_desc[d] >> bb & 1u) || !(S.bodymask >> bb & 1u)) continue;
+        real t[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) { real a = 0; for (int j = 0; j < 6; j++) a += S.G[bb][sym6(i, j)] * S.cdof[d][j]; t[i] = a; }
+#pragma unroll
+        for (int e = 0; e < UR5_MAXRD; e++)
+          if (e <= d && (M.rd_desc[e] >> bb & 1u)) { real a = 0; for (int i = 0; i < 6; i++) a += S.cdof[e][i] * t[i]; r[e] += a; }
+      }
+      for (int s = 0; s < S.nsr; s++) {
+        if (S.sr_uni[s] && S.sr_jar[s] >= 0) continue;
+        real cd = (S.sr_d1[s] == d ? S.sr_c1[s] : (real)0) + (S.sr_d2[s] == d ? S.sr_c2[s] : (real)0);
+        if (cd == 0) continue;
+#pragma unroll
+        for (int e = 0; e < UR5_MAXRD; e++) {
+          real ce = (S.sr_d1[s] == e ? S.sr_c1[s] : (real)0) + (S.sr_d2[s] == e ? S.sr_c2[s] : (real)0);
+          if (e <= d) r[e] += S.sr_D[s] * cd * ce;
+        }
+      }
+    } else if (lane < nv) {
+      const int k = (lane - UR5_MAXRD) / 6, loc = (lane - UR5_MAXRD) % 6, body = UR5_MAXRD + k;
+      b.base = UR5_MAXRD + 6 * k; b.loc = loc; b.size = 6;
+      m3 R; R.load(S.bmat[body]);
+      real ti[6] = {0, 0, 0, 0, 0, 0};
+      if (loc < 3) ti[3 + loc] = 1; else { v3 c = R.col(loc - 3); ti[0] = c.x; ti[1] = c.y; ti[2] = c.z; }
+      real t[6];
+#pragma unroll
+      for (int i = 0; i < 6; i++) { real a = 0; for (int j = 0; j < 6; j++) a += S.G[body][sym6(i, j)] * ti[j]; t[i] = a; }
+#pragma unroll
+      for (int j = 0; j < 6; j++) {
+        if (j > loc) continue;
+        real v = j < 3 ? t[3 + j] : dot(R.col(j - 3), v3(t[0], t[1], t[2]));
+        if (j == loc) {
+          v += S.Mobj[6 * k + loc];
+          for (int s = 0; s < S.nsr; s++) if (S.sr_d1[s] == lane && !(S.sr_uni[s] && S.sr_jar[s] >= 0)) v += S.sr_D[s] * S.sr_c1[s] * S.sr_c1[s];
+        }
+        r[j] = v;
+      }
+    } else { b.base = lane; b.loc = 0; b.size = 0; }
+    real g = lane < nv ? S.grad[lane] : (real)0;
+    __syncthreads();   // every lane has read G / grad; H (aliased scratch) may be overwritten now
+    real myinv = blk_cholesky(r, b);
+    real x = blk_solve(r, myinv, b, g, S.H);
+    if (lane < nv) S.search[lane] = -x;
+    __syncthreads();
+  }
+#endif
 
 #ifndef UR5_EMUL
   // broadcast lane `src` (wave-uniform) of a double through two v_readlane
@@ -1211,11 +1412,11 @@ template <class real, int NV_> struct Engine {
   // is broadcast with v_readlane, so the whole factorisation runs without touching LDS. BLOCKDIAG: no contact couples two
   // movable bodies, H = diag(robot 8x8, object 6x6 ...) and every column only looks back to the start of its own block.
   template <bool BLOCKDIAG> __device__ __noinline__ void factor_solve_rows() {
-    constexpr int N = NV_, LD = L::LD;
+    constexpr int N = NV_;
     const int lane = threadIdx.x, nv = M.nv;
     real Lrow[N];
 #pragma unroll
-    for (int j = 0; j < N; j++) Lrow[j] = (lane < nv && j <= lane) ? S.H[lane * LD + j] : (j == lane ? (real)1 : (real)0);
+    for (int j = 0; j < N; j++) Lrow[j] = (lane < nv && j <= lane) ? S.H[UR5_HIDX(lane, j)] : (j == lane ? (real)1 : (real)0);
     real myinv = 1;
 #pragma unroll
     for (int j = 0; j < N; j++) {
@@ -1224,9 +1425,10 @@ template <class real, int NV_> struct Engine {
 #pragma unroll
       for (int k = 0; k < j; k++) if (k >= k0) sacc -= Lrow[k] * bcast(Lrow[k], j);
       real djj = bcast(sacc, j);
-      real d = sqrt(djj < (real)1e-15 ? (real)1e-15 : djj);
-      real inv = (real)1 / d;
-      Lrow[j] = lane == j ? d : (lane > j ? sacc * inv : (real)0);
+      djj = djj < (real)1e-15 ? (real)1e-15 : djj;
+      real inv = rsqrt(djj);
+      inv = inv * ((real)1.5 - (real)0.5 * djj * inv * inv);
+      Lrow[j] = lane == j ? djj * inv : (lane > j ? sacc * inv : (real)0);
       if (lane == j) myinv = inv;
     }
     real b = lane < nv ? S.search[lane] : (real)0;
@@ -1239,11 +1441,11 @@ template <class real, int NV_> struct Engine {
     SYNC();
     if (lane < nv) {
 #pragma unroll
-      for (int j = 0; j < N; j++) if (j <= lane) S.H[lane * LD + j] = Lrow[j];
+      for (int j = 0; j < N; j++) if (j <= lane) S.H[UR5_HIDX(lane, j)] = Lrow[j];
     }
     SYNC();
 #pragma unroll
-    for (int k = 0; k < N; k++) Lrow[k] = (k >= lane && k < nv && lane < nv) ? S.H[k * LD + lane] : (real)0;
+    for (int k = 0; k < N; k++) Lrow[k] = (k >= lane && k < nv && lane < nv) ? S.H[UR5_HIDX(k, lane)] : (real)0;
 #pragma unroll
     for (int k = N - 1; k >= 0; k--) {
       real xk = bcast(b * myinv, k);
@@ -1275,16 +1477,16 @@ template <class real, int NV_> struct Engine {
     real cw = gauss_cost(S.x, S.Ma) + ccw;
     SYNC();
     mat_vec_M(S.as, S.Mv);
-    images(S.as, true, S.cfb, S.tmpv);  // scratch: cfb / tmpv hold the images at qacc_smooth
+    images(S.as, true, S.cde, S.tmpv);  // scratch: cde / tmpv hold the images at qacc_smooth
     // cost at qacc_smooth: Gauss term vanishes
     real cs;
     {
       real c0 = 0;
       PAR(c, S.ncon) {
-        real D = S.cD[c], e0 = S.cfb[c][0];
+        real D = S.cD[c], e0 = S.cde[c][0];
         if (S.cdim[c] == 1) { if (e0 < 0) c0 += (real)0.5 * D * e0 * e0; }
         else for (int k = 1; k < S.cdim[c]; k++) {
-          real ek = row_mu(c, k) * S.cfb[c][k], rp = e0 + ek, rm = e0 - ek;
+          real ek = row_mu(c, k) * S.cde[c][k], rp = e0 + ek, rm = e0 - ek;
           if (rp < 0) c0 += (real)0.5 * D * rp * rp;
           if (rm < 0) c0 += (real)0.5 * D * rm * rm;
         }
@@ -1298,7 +1500,7 @@ template <class real, int NV_> struct Engine {
     else {
       cost = cs;
       PAR(i, nv) { S.x[i] = S.as[i]; S.Ma[i] = S.Mv[i]; }
-      PAR(c, S.ncon) for (int k = 0; k < NB; k++) S.ce[c][k] = S.cfb[c][k];
+      PAR(c, S.ncon) for (int k = 0; k < NB; k++) S.ce[c][k] = S.cde[c][k];
       PAR(s, S.nsr) S.sr_jar[s] = S.tmpv[s];
       SYNC();
     }
@@ -1693,7 +1895,7 @@ template <class real, int NV_> struct Engine {
       for (int k = 0; k < 3; k++) out[o++] = ok ? (double)S.cpos[c][k] : 0;
       for (int k = 0; k < 3; k++) out[o++] = ok ? (double)S.cframe[c][k] : 0;
       out[o++] = ok ? S.cg1[c] : -1; out[o++] = ok ? S.cg2[c] : -1;
-      out[o++] = ok ? (double)S.cfb[c][0] : 0;
+      out[o++] = ok ? (double)S.cfn[c] : 0;
     }
   }
 };

@@ -216,5 +216,5 @@ class BatchSim:
         self._check(self.lib.ur5_forward_debug(self._h, _dp(out)), "ur5_forward_debug")
         d = dict(ncon=out[:, 0].astype(int), nsr=out[:, 1].astype(int), bpos=out[:, 8:50].reshape(self.n, 14, 3),
                  Mr=out[:, 50:114].reshape(self.n, 8, 8), qfrc_smooth=out[:, 114:158], qacc_smooth=out[:, 158:202],
-                 qacc=out[:, 202:246], contacts=out[:, 246:246 + 320].reshape(self.n, 32, 10))
+                 qacc=out[:, 202:246], contacts=out[:, 246:246 + 240].reshape(self.n, 24, 10))
         return d

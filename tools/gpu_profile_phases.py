@@ -8,7 +8,7 @@ from mujoco_rl_ur5_amd.native import BatchSim
 NAMES = ["kin", "crb", "vel", "broad", "narrow", "rows", "newton_init", "images", "linesearch", "grad+G", "H_asm", "chol", "solve", "integrate", "pid", "ik"]
 m = load_model("it1_4box")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-sim = BatchSim(m, n, lib_path=os.path.join(os.path.dirname(os.path.abspath(__file__)), "libur5sim_prof.so"))
+sim = BatchSim(m, n, lib_path=os.environ.get("UR5_PROF_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), "libur5sim_prof.so")))
 sim.lib.ur5_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
 def read():
     out = np.zeros((n, 16)); sim.lib.ur5_profile_read(sim._h, out.ctypes.data_as(C.POINTER(C.c_double))); return out

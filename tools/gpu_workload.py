@@ -7,7 +7,7 @@ from mujoco_rl_ur5_amd.model import load_model
 from mujoco_rl_ur5_amd.native import BatchSim
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 m = load_model("it1_4box")
-sim = BatchSim(m, n)
+sim = BatchSim(m, n, lib_path=os.environ.get('UR5_LIB'))
 sim.reset(np.arange(n, dtype=np.uint64) + 20, 1, 1000.0)
 st = sim.get_state()["qpos"]
 acts = np.zeros((n, 3))
