@@ -16,6 +16,7 @@
  *   ur5_ik                MJ_Controller.ik                          MujocoController.py:467-517
  *   ur5_grasp_attempt     GraspEnv.move_and_grasp                   GraspingEnv.py:205-386
  *   ur5_body_xpos         sim.data.body_xpos[...]                   MujocoController.py:341,488
+ *   ur5_render            sim.render(w, h, camera, depth=True) + flips (get_image_data)   MujocoController.py:708-727
  *
  * Conventions: every function returns 0 on success and a negative code on error (ur5_last_error() has the text). Per-env
  * soft outcomes use the result codes below, which the Python facade maps back to the reference's strings "success",
@@ -77,6 +78,12 @@ double ur5_last_launch_ms(ur5_sim* h);
 int ur5_get_counters(ur5_sim* h, int64_t* counters);
 /* world positions of the engine's bodies [n][14][3]: 8 robot weld groups (dof order) then the objects */
 int ur5_body_xpos(ur5_sim* h, double* out);
+/* RGB-D image of every scene from model camera `camera_id` (1 = "top_down" in the reference's files): rgb[n][h][w][3] uint8,
+ * depth[n][h][w] float32, already in the orientation get_image_data returns (both flips applied). depth_mode 0 = metres along
+ * the optical axis (what depth_2_meters produces), 1 = GL window depth in [0,1] (what sim.render returns). Host pointers. */
+int ur5_render(ur5_sim* h, int camera_id, int width, int height, int depth_mode, uint8_t* rgb, float* depth);
+/* same with HIP device pointers; asynchronous on the handle's stream */
+int ur5_render_dev(ur5_sim* h, int camera_id, int width, int height, int depth_mode, uint8_t* rgb_dev, float* depth_dev);
 /* raw device pointer of the [n][192] double state records (layout: csrc/ur5_devmodel.h) */
 void* ur5_state_device_ptr(ur5_sim* h);
 /* test hook: runs forward dynamics once without integrating and dumps internals, [n][2048] doubles host */

@@ -5,7 +5,7 @@ arguments and result strings, but every call acts on ``n_envs`` independent scen
 return values have the reference's scalar shapes (one string, one array); otherwise lists / arrays gain a leading N.
 
 Not carried over (out of scope): viewer markers, joint-angle plots, debug printing, ``ik_2``,
-``toss_it_from_the_ellbow``. Rendering (``get_image_data``) is the HIP rasteriser of a later round.
+``toss_it_from_the_ellbow``, the ``show`` window of ``get_image_data``.
 """
 from __future__ import annotations
 
@@ -170,8 +170,10 @@ class MJ_Controller(object):
 
     # ------------------------------------------------------------------ camera maths (host side, per grasp -- not per step)
     def get_image_data(self, show=False, camera="top_down", width=200, height=200):   # :708-727
-        raise NotImplementedError("get_image_data needs the HIP RGB-D rasteriser (SURVEY.md K10/K11), which is not part of this "
-                                  "round; GraspEnv(observation='flat') provides the IT1 fixed-z observation instead.")
+        """RGB (uint8) and GL window depth in [0, 1] (float32) of ``camera``, both flips applied -- what the reference returns;
+        feed the depth to :meth:`depth_2_meters`. Rendered on the GPU by ray casting (csrc/ur5_raster.h)."""
+        rgb, depth = self.sim.render(self.model.camera_name2id(camera), width, height, depth_mode=1)
+        return self._one(rgb), self._one(depth)
 
     def depth_2_meters(self, depth):                                  # :729-740
         extend = self.model.opt["extent"]

@@ -21,6 +21,28 @@ __global__ void __launch_bounds__(64) ur5_run_kernel(double* __restrict__ rec, U
 // the model sits in __constant__ memory (one copy per device); a handle re-uploads it only when another handle used the device last
 static ur5_sim* g_model_owner[64] = {nullptr};
 
+// One 16x16 pixel tile of one scene per block: thread 0 runs the (serial) forward kinematics of the scene, the first ngeom
+// threads place the geoms, then every thread casts the ray of its pixel against the geoms staged in LDS.
+__global__ void __launch_bounds__(256) ur5_render_kernel(const Ur5RenderModel* __restrict__ R, const double* __restrict__ rec, int cam, int W, int H,
+                                                         int mode, uint8_t* __restrict__ rgb, float* __restrict__ depth) {
+  __shared__ float bp[UR5_MAXB][12];
+  __shared__ float gp[UR5_R_MAXG][12];
+  const int scene = blockIdx.y, tiles_x = (W + 15) / 16;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const double* r = rec + (size_t)scene * UR5_REC_STRIDE;
+  if (threadIdx.x == 0) ur5r::body_poses(ur5_cmodel, r, bp);
+  __syncthreads();
+  for (int g = threadIdx.x; g < R->ngeom; g += blockDim.x) ur5r::geom_pose(*R, ur5_cmodel, bp, g, gp[g]);
+  __syncthreads();
+  const int px = tx * 16 + (threadIdx.x & 15), py = ty * 16 + (threadIdx.x >> 4);
+  if (px >= W || py >= H) return;
+  uint8_t c[3];
+  float z = ur5r::shade_pixel(*R, gp, cam, W, H, px, py, c);
+  const size_t o = ((size_t)scene * H + py) * W + px;
+  rgb[3 * o] = c[0]; rgb[3 * o + 1] = c[1]; rgb[3 * o + 2] = c[2];
+  depth[o] = mode == 0 ? z : ur5r::gl_depth(*R, z);
+}
+
 struct HipBackend {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -80,18 +102,36 @@ static int be_d2h(ur5_sim* h, void* dst, const void* src, size_t bytes) {
   HIPCHK(hipStreamSynchronize(b->stream));
   return 0;
 }
+static int be_upload_model(ur5_sim* h);
 static int be_launch(ur5_sim* h, const Ur5Launch& P) {
   HipBackend* b = (HipBackend*)h->be;
   HIPCHK(hipSetDevice(h->device));
+  { int rcm = be_upload_model(h); if (rcm) return rcm; }
+  HIPCHK(hipEventRecord(b->ev0, b->stream));
+  dim3 grid(h->n), block(64);
+  if (h->nvt == 32) hipLaunchKernelGGL(ur5_run_kernel<32>, grid, block, sizeof(ur5::Lds<double, 32>), b->stream, h->d_rec, P);
+  else hipLaunchKernelGGL(ur5_run_kernel<UR5_MAXNV>, grid, block, sizeof(ur5::Lds<double, UR5_MAXNV>), b->stream, h->d_rec, P);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(b->ev1, b->stream));
+  b->timed = true;
+  return 0;
+}
+static int be_upload_model(ur5_sim* h) {
   if (g_model_owner[h->device & 63] != h) {
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(ur5_cmodel), &h->hm, sizeof(Ur5DevModel), 0, hipMemcpyHostToDevice));
     g_model_owner[h->device & 63] = h;
   }
+  return 0;
+}
+static int be_render(ur5_sim* h, int cam, int W, int Hh, int mode, uint8_t* rgb_dev, float* depth_dev) {
+  HipBackend* b = (HipBackend*)h->be;
+  HIPCHK(hipSetDevice(h->device));
+  int rc = be_upload_model(h);
+  if (rc) return rc;
   HIPCHK(hipEventRecord(b->ev0, b->stream));
-  dim3 grid(h->n), block(64);
-  if (h->nvt == 32) hipLaunchKernelGGL(ur5_run_kernel<32>, grid, block, sizeof(ur5::Lds<double, 32>), b->stream, h->d_rec, P);
-  else hipLaunchKernelGGL(ur5_run_kernel<UR5_MAXNV>, grid, block, sizeof(ur5::Lds<double, UR5_MAXNV>), b->stream, h->d_rec, P);
+  dim3 grid(((W + 15) / 16) * ((Hh + 15) / 16), h->n), block(256);
+  hipLaunchKernelGGL(ur5_render_kernel, grid, block, 0, b->stream, h->d_rm, h->d_rec, cam, W, Hh, mode, rgb_dev, depth_dev);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(b->ev1, b->stream));
   b->timed = true;

@@ -10,6 +10,7 @@
 #include <vector>
 #include "../../include/ur5sim.h"
 #include "ur5_devmodel.h"
+#include "ur5_raster.h"
 
 namespace ur5host {
 
@@ -73,7 +74,7 @@ static Xf compose(const Xf& a, const Xf& b) {  // a * b
 static Xf identity() { Xf r = {{0, 0, 0}, {1, 0, 0, 0}}; return r; }
 
 // ------------------------------------------------------------------ blob -> Ur5DevModel
-static int build_model(const void* data, size_t nbytes, int ee_body, Ur5DevModel* out, std::vector<int>* dev2model_geom) {
+static int build_model(const void* data, size_t nbytes, int ee_body, Ur5DevModel* out, std::vector<int>* dev2model_geom, Ur5RenderModel* RM) {
   Blob B{(const char*)data, nbytes};
   if (!B.ok()) return fail(UR5_ERR_MODEL, "model blob: bad magic");
   Ur5DevModel& D = *out;
@@ -294,6 +295,47 @@ static int build_model(const void* data, size_t nbytes, int ee_body, Ur5DevModel
     D.pair_g1[np] = a; D.pair_g2[np] = b; np++;
   }
   D.npair = np;
+  // ---- render model: every geom (collidable or not) with its pose relative to the engine body that carries it
+  if (RM) {
+    Ur5RenderModel& R = *RM;
+    memset(&R, 0, sizeof R);
+    int npl_tot = 0, ncam = 0;
+    const int* vadr = B.I("vis_planeadr");
+    const int* vnum = B.I("vis_planenum");
+    const double* vpl = B.F("vis_plane", &npl_tot);
+    const double* rgba = B.F("geom_rgba");
+    const double *cpos = B.F("cam_pos"), *cmat = B.F("cam_mat"), *cfov = B.F("cam_fovy", &ncam);
+    if (!vadr || !vnum || !rgba || !cfov) return fail(UR5_ERR_MODEL, "model blob lacks the render sections (re-run tools/compile_models.py)");
+    if (ngeom > UR5_R_MAXG || npl_tot / 4 > UR5_R_MAXPL || ncam > UR5_R_MAXCAM) return fail(UR5_ERR_MODEL, "render model exceeds its budgets");
+    R.ngeom = ngeom; R.nplane = npl_tot / 4; R.ncam = ncam;
+    for (int i = 0; i < npl_tot; i++) R.plane[i / 4][i % 4] = (float)vpl[i];
+    const double* gq = B.F("geom_quat");
+    for (int g = 0; g < ngeom; g++) {
+      int b = geom_body[g];
+      Xf gl; memcpy(gl.p, geom_pos + 3 * g, 24); memcpy(gl.q, gq + 4 * g, 32);
+      Xf x;
+      if (body_weld[b] == 0) { R.g_kind[g] = UR5_KIND_STATIC; R.g_owner[g] = -1; x = compose(rel_to(b, 0), gl); }
+      else if (body_tree[b] == 0) { R.g_kind[g] = UR5_KIND_ROBOT; R.g_owner[g] = cb_of_body[body_weld[b]]; x = compose(rel_to(b, body_weld[b]), gl); }
+      else { R.g_kind[g] = UR5_KIND_OBJECT; R.g_owner[g] = obj_of_body[b]; x = gl; }
+      double m9[9];
+      qmat(x.q, m9);
+      for (int k = 0; k < 3; k++) { R.g_pos[g][k] = (float)x.p[k]; R.g_size[g][k] = (float)geom_size[3 * g + k]; }
+      for (int k = 0; k < 9; k++) R.g_mat[g][k] = (float)m9[k];
+      for (int k = 0; k < 4; k++) R.g_rgba[g][k] = (float)rgba[4 * g + k];
+      R.g_type[g] = geom_type[g]; R.g_rbound[g] = (float)geom_rbound[g];
+      if (geom_type[g] == UR5_GEOM_MESH) { R.g_padr[g] = vadr[geom_mesh[g]]; R.g_pnum[g] = vnum[geom_mesh[g]]; }
+    }
+    for (int c = 0; c < ncam; c++) {
+      for (int k = 0; k < 3; k++) R.cam_pos[c][k] = (float)cpos[3 * c + k];
+      for (int k = 0; k < 9; k++) R.cam_mat[c][k] = (float)cmat[9 * c + k];
+      R.cam_fovy[c] = (float)cfov[c];
+    }
+    R.znear = (float)(optf[15] * optf[14]); R.zfar = (float)(optf[16] * optf[14]);
+    const double l[3] = {1.0, -1.0, 3.0 - 0.435};   // light3: directional, pos (1,-1,3) aimed at box_link (UR5gripper_2_finger.xml:108)
+    double ln = sqrt(l[0] * l[0] + l[1] * l[1] + l[2] * l[2]);
+    for (int k = 0; k < 3; k++) R.light[k] = (float)(l[k] / ln);
+    R.sky[0] = 0.65f; R.sky[1] = 0.65f; R.sky[2] = 0.9f;
+  }
   // ---- equality, actuators, options
   if (neq > 2) return fail(UR5_ERR_MODEL, "at most two joint equalities");
   D.neq = neq;
@@ -351,6 +393,11 @@ struct ur5_sim {
   std::vector<double> qpos0;
   std::vector<int> dev2model_geom;
   double* d_rec = nullptr;
+  Ur5RenderModel hrm;
+  Ur5RenderModel* d_rm = nullptr;
+  uint8_t* d_rgb = nullptr;
+  float* d_depth = nullptr;
+  size_t img_cap = 0;
   unsigned* d_mask = nullptr;
   double *d_target = nullptr, *d_tol = nullptr, *d_debug = nullptr;
   int *d_max = nullptr, *d_result = nullptr, *d_steps = nullptr, *d_ps = nullptr, *d_pr = nullptr;
@@ -368,6 +415,7 @@ static int be_h2d(ur5_sim* h, void* dst, const void* src, size_t bytes);
 static int be_d2h(ur5_sim* h, void* dst, const void* src, size_t bytes);
 static int be_launch(ur5_sim* h, const Ur5Launch& P);
 static int be_sync(ur5_sim* h);
+static int be_render(ur5_sim* h, int cam, int W, int Hh, int mode, uint8_t* rgb_dev, float* depth_dev);
 
 namespace ur5host {
 static int pull(ur5_sim* h) { h->h_rec.resize((size_t)h->n * UR5_REC_STRIDE); return be_d2h(h, h->h_rec.data(), h->d_rec, h->h_rec.size() * 8); }
@@ -392,7 +440,7 @@ int ur5_create(const void* blob, size_t nbytes, int n_env, int device_id, const 
   using namespace ur5host;
   if (!blob || !out || !cfg || n_env <= 0) return fail(UR5_ERR_ARG, "ur5_create: bad arguments");
   ur5_sim* h = new ur5_sim();
-  int rc = build_model(blob, nbytes, cfg->ee_body, &h->hm, &h->dev2model_geom);
+  int rc = build_model(blob, nbytes, cfg->ee_body, &h->hm, &h->dev2model_geom, &h->hrm);
   if (rc) { delete h; return rc; }
   h->n = n_env; h->device = device_id; h->contacts_enabled = cfg->contacts_enabled;
   h->pid_dt = cfg->pid_dt > 0 ? cfg->pid_dt : h->hm.timestep;
@@ -405,6 +453,7 @@ int ur5_create(const void* blob, size_t nbytes, int n_env, int device_id, const 
   if (rc) { delete h; return rc; }
   size_t n = (size_t)n_env;
   h->dm = (Ur5DevModel*)be_alloc(h, sizeof(Ur5DevModel));
+  h->d_rm = (Ur5RenderModel*)be_alloc(h, sizeof(Ur5RenderModel));
   h->d_rec = (double*)be_alloc(h, n * UR5_REC_STRIDE * 8);
   h->d_mask = (unsigned*)be_alloc(h, n * 4); h->d_target = (double*)be_alloc(h, n * 8 * 8); h->d_tol = (double*)be_alloc(h, n * 8);
   h->d_max = (int*)be_alloc(h, n * 4); h->d_result = (int*)be_alloc(h, n * 4); h->d_steps = (int*)be_alloc(h, n * 4);
@@ -414,6 +463,7 @@ int ur5_create(const void* blob, size_t nbytes, int n_env, int device_id, const 
     return fail(UR5_ERR_DEVICE, "device allocation failed");
   }
   be_h2d(h, h->dm, &h->hm, sizeof(Ur5DevModel));
+  if (h->d_rm) be_h2d(h, h->d_rm, &h->hrm, sizeof(Ur5RenderModel));
   // initial records: qpos0, controller construction state
   h->h_rec.assign(n * UR5_REC_STRIDE, 0.0);
   for (size_t e = 0; e < n; e++) {
@@ -433,7 +483,7 @@ int ur5_create(const void* blob, size_t nbytes, int n_env, int device_id, const 
 
 void ur5_destroy(ur5_sim* h) {
   if (!h) return;
-  void* ptrs[] = {h->dm, h->d_rec, h->d_mask, h->d_target, h->d_tol, h->d_max, h->d_result, h->d_steps, h->d_ps, h->d_pr, h->d_debug};
+  void* ptrs[] = {h->dm, h->d_rec, h->d_mask, h->d_target, h->d_tol, h->d_max, h->d_result, h->d_steps, h->d_ps, h->d_pr, h->d_debug, h->d_rm, h->d_rgb, h->d_depth};
   for (void* p : ptrs) if (p) be_free(h, p);
   be_close(h);
   delete h;
@@ -630,6 +680,28 @@ int ur5_ik(ur5_sim* h, const double* xyz, double* q5, int* result) {
   if (!rc) rc = be_d2h(h, t.data(), h->d_target, t.size() * 8);
   if (!rc && result) rc = be_d2h(h, result, h->d_result, (size_t)h->n * 4);
   if (!rc) for (int e = 0; e < h->n; e++) for (int k = 0; k < 5; k++) q5[5 * e + k] = t[8 * e + k];
+  return rc;
+}
+int ur5_render_dev(ur5_sim* h, int camera_id, int width, int height, int depth_mode, uint8_t* rgb_dev, float* depth_dev) {
+  using namespace ur5host;
+  if (!rgb_dev || !depth_dev || width <= 0 || height <= 0) return fail(UR5_ERR_ARG, "ur5_render_dev: bad arguments");
+  if (camera_id < 0 || camera_id >= h->hrm.ncam) return fail(UR5_ERR_ARG, "ur5_render: unknown camera id");
+  return be_render(h, camera_id, width, height, depth_mode, rgb_dev, depth_dev);
+}
+int ur5_render(ur5_sim* h, int camera_id, int width, int height, int depth_mode, uint8_t* rgb, float* depth) {
+  using namespace ur5host;
+  if (!rgb || !depth || width <= 0 || height <= 0) return fail(UR5_ERR_ARG, "ur5_render: bad arguments");
+  size_t px = (size_t)h->n * width * height;
+  if (px > h->img_cap) {
+    if (h->d_rgb) be_free(h, h->d_rgb);
+    if (h->d_depth) be_free(h, h->d_depth);
+    h->d_rgb = (uint8_t*)be_alloc(h, px * 3); h->d_depth = (float*)be_alloc(h, px * 4); h->img_cap = px;
+    if (!h->d_rgb || !h->d_depth) { h->img_cap = 0; return fail(UR5_ERR_DEVICE, "image buffer allocation failed"); }
+  }
+  int rc = ur5_render_dev(h, camera_id, width, height, depth_mode, h->d_rgb, h->d_depth);
+  if (!rc) rc = be_sync(h);
+  if (!rc) rc = be_d2h(h, rgb, h->d_rgb, px * 3);
+  if (!rc) rc = be_d2h(h, depth, h->d_depth, px * 4);
   return rc;
 }
 int ur5_sync(ur5_sim* h) { return be_sync(h); }

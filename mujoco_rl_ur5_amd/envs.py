@@ -6,9 +6,10 @@ action_info) -> (obs, reward, done, info)``, ``reset() -> obs``, ``action_space 
 With ``n_envs == 1`` shapes equal the reference's; otherwise actions are ``int[N, 2]``, observations and rewards gain a
 leading N. The whole 12-phase ``move_and_grasp`` script (:205-386) of every scene runs inside ONE kernel launch.
 
-Observation: this round ships ``observation="flat"`` -- the IT1 setting of README.md:20 ("fixed z-coordinate for
-grasping"): depth = camera height - TABLE_HEIGHT everywhere, rgb zeros. ``observation="render"`` (the 200x200 HIP RGB-D
-rasteriser) is a later row of the scope table and raises until it lands.
+Observation: ``observation="render"`` (default) is the reference's RGB-D observation -- ``get_image_data`` +
+``depth_2_meters`` (GraspingEnv.py:390-406), ray-cast on the GPU (csrc/ur5_raster.h) -- so the grasp height comes from
+the depth image (IT4+, GraspingEnv.py:100-104,258-259). ``observation="flat"`` is the IT1 setting of README.md:20 ("fixed
+z-coordinate for grasping"): depth = camera height - TABLE_HEIGHT everywhere, rgb zeros, nothing rendered.
 """
 from __future__ import annotations
 
@@ -43,7 +44,7 @@ class GraspEnv(object):
     metadata = {"render.modes": ["human", "rgb_array"], "video.frames_per_second": 500}
 
     def __init__(self, file="/UR5+gripper/UR5gripper_2_finger_many_objects.xml", image_width=200, image_height=200, show_obs=True,
-                 demo=False, render=False, n_envs=1, device_id=0, observation="flat", check_mode=0, base_seed=20, _lib_path=None):
+                 demo=False, render=False, n_envs=1, device_id=0, observation="render", check_mode=0, base_seed=20, _lib_path=None):
         self.initialized = False
         self.IMAGE_WIDTH = image_width
         self.IMAGE_HEIGHT = image_height
@@ -65,8 +66,6 @@ class GraspEnv(object):
         self.render = render
         if observation not in ("flat", "render"):
             raise ValueError("observation must be 'flat' or 'render'")
-        if observation == "render":
-            raise NotImplementedError("observation='render' needs the HIP RGB-D rasteriser (SURVEY.md K10), not part of this round")
         self.observation_mode = observation
         self.check_mode = check_mode                                         # 0 = in-tree script, 1 = IT1 (README.md:20)
         self.base_seed = base_seed                                           # Grasping_Agent_multidiscrete.py:64
@@ -144,9 +143,13 @@ class GraspEnv(object):
         return self.current_observation
 
     def get_observation(self, show=True):                                    # :390-406
-        cam_z = self.model.cam_pos0[self.model.camera_name2id("top_down")][2]
-        depth = np.full((self.n_envs, self.IMAGE_HEIGHT, self.IMAGE_WIDTH), cam_z - 0.91, dtype=np.float32)
-        rgb = np.zeros((self.n_envs, self.IMAGE_HEIGHT, self.IMAGE_WIDTH, 3), dtype=np.uint8)
+        if self.observation_mode == "render":
+            rgb, depth = self.sim.render(self.model.camera_name2id("top_down"), self.IMAGE_WIDTH, self.IMAGE_HEIGHT, depth_mode=1)
+            depth = self.controller.depth_2_meters(depth).astype(np.float32)  # :398-399
+        else:
+            cam_z = self.model.cam_pos0[self.model.camera_name2id("top_down")][2]
+            depth = np.full((self.n_envs, self.IMAGE_HEIGHT, self.IMAGE_WIDTH), cam_z - 0.91, dtype=np.float32)
+            rgb = np.zeros((self.n_envs, self.IMAGE_HEIGHT, self.IMAGE_WIDTH, 3), dtype=np.uint8)
         observation = defaultdict()
         observation["rgb"] = self._one(rgb)
         observation["depth"] = self._one(depth)

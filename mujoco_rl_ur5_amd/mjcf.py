@@ -244,7 +244,16 @@ def _expand_includes(el, basedir):
             _expand_includes(child, basedir)
 
 
-def compile_mjcf(path, *, objects=None, arm_collision=False, mesh_inertia="dedup", maxhullvert=32):
+def hull_planes(verts):
+    """Outward face planes (n, d) with n.x + d <= 0 inside, one row per distinct face of the convex hull of ``verts``."""
+    from scipy.spatial import ConvexHull
+    eq = ConvexHull(verts).equations
+    key = np.round(eq, 7)
+    _, idx = np.unique(key, axis=0, return_index=True)
+    return eq[np.sort(idx)]
+
+
+def compile_mjcf(path, *, objects=None, arm_collision=False, mesh_inertia="dedup", maxhullvert=32, maxvisvert=48):
     """Compile an MJCF file.
 
     ``objects``: optional list of dicts replacing every free object of the scene (used for the
@@ -449,6 +458,7 @@ def compile_mjcf(path, *, objects=None, arm_collision=False, mesh_inertia="dedup
 
     # ---- geoms, meshes
     mesh_cache, mesh_vert, mesh_adr, mesh_num, mesh_names = {}, [], [], [], []
+    vis_adr, vis_num, vis_plane = [], [], []
     ngeom = len(geoms)
     m.geom_type = np.array([g["type"] for g in geoms], dtype=np.int32)
     m.geom_bodyid = np.array([g["body"] for g in geoms], dtype=np.int32)
@@ -486,6 +496,10 @@ def compile_mjcf(path, *, objects=None, arm_collision=False, mesh_inertia="dedup
                 mesh_num.append(len(hull))
                 mesh_vert.append(hull)
                 mesh_names.append(name)
+                # faces of the (capped) hull for the ray caster: the collision hull where one exists, else <= maxvisvert vertices
+                vis = hull if name not in _ARM_MESHES else convex_hull_vertices(tris, maxvisvert)
+                pl = hull_planes(vis)
+                vis_adr.append(sum(vis_num)); vis_num.append(len(pl)); vis_plane.append(pl)
             mid, (mass, com, inert) = mesh_cache[name]
             m.geom_meshid[k] = mid
             geom_mass[k], geom_com[k], geom_inertia[k] = mass, com, inert
@@ -502,6 +516,9 @@ def compile_mjcf(path, *, objects=None, arm_collision=False, mesh_inertia="dedup
     m.mesh_vertadr = np.array(mesh_adr, dtype=np.int32)
     m.mesh_vertnum = np.array(mesh_num, dtype=np.int32)
     m.mesh_vert = np.concatenate(mesh_vert) if mesh_vert else np.zeros((0, 3))
+    m.vis_planeadr = np.array(vis_adr, dtype=np.int32)
+    m.vis_planenum = np.array(vis_num, dtype=np.int32)
+    m.vis_plane = np.concatenate(vis_plane) if vis_plane else np.zeros((0, 4))
 
     # ---- body inertias from geoms (inertiafromgeom="true")
     m.body_mass = np.zeros(nbody)

@@ -27,7 +27,7 @@ _ARRAYS = [
     "dof_invweight0", "tree_dofadr", "tree_dofnum",
     "geom_type", "geom_bodyid", "geom_size", "geom_pos", "geom_quat", "geom_friction", "geom_condim",
     "geom_margin", "geom_solref", "geom_solimp", "geom_rgba", "geom_meshid", "geom_rbound", "geom_collide",
-    "mesh_vertadr", "mesh_vertnum", "mesh_vert", "pair_geom1", "pair_geom2",
+    "mesh_vertadr", "mesh_vertnum", "mesh_vert", "vis_planeadr", "vis_planenum", "vis_plane", "pair_geom1", "pair_geom2",
     "eq_jnt1", "eq_jnt2", "eq_polycoef", "eq_solref", "eq_solimp",
     "act_jntid", "act_gear", "act_ctrlrange", "act_ctrllimited",
     "cam_pos", "cam_mat", "cam_fovy", "opt_f", "opt_i",
@@ -157,7 +157,7 @@ class CompiledModel:
 
     _SHAPES = dict(body_pos=3, body_quat=4, body_ipos=3, body_inertia=6, body_invweight0=2, jnt_pos=3, jnt_axis=3,
                    jnt_range=2, geom_size=3, geom_pos=3, geom_quat=4, geom_friction=3, geom_solref=2, geom_solimp=5,
-                   geom_rgba=4, mesh_vert=3, eq_polycoef=5, eq_solref=2, eq_solimp=5, act_ctrlrange=2, cam_pos=3,
+                   geom_rgba=4, mesh_vert=3, vis_plane=4, eq_polycoef=5, eq_solref=2, eq_solimp=5, act_ctrlrange=2, cam_pos=3,
                    cam_mat=9)
 
     def _reshape(self):

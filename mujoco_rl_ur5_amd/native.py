@@ -19,7 +19,7 @@ DEBUG_STRIDE, REC_STRIDE, MAXB = 2048, 192, 14
 EXPORTS = ["ur5_last_error", "ur5_create", "ur5_destroy", "ur5_num_envs", "ur5_nq", "ur5_nv", "ur5_nu", "ur5_reset",
            "ur5_set_state", "ur5_get_state", "ur5_set_ctrl", "ur5_get_ctrl", "ur5_step", "ur5_move_group", "ur5_stay",
            "ur5_move_ee", "ur5_ik", "ur5_grasp_attempt", "ur5_grasp_attempt_dev", "ur5_sync", "ur5_last_launch_ms",
-           "ur5_get_counters", "ur5_body_xpos", "ur5_state_device_ptr", "ur5_forward_debug"]
+           "ur5_get_counters", "ur5_body_xpos", "ur5_render", "ur5_render_dev", "ur5_state_device_ptr", "ur5_forward_debug"]
 
 
 class Config(C.Structure):
@@ -63,6 +63,8 @@ def load(path=None):
     L.ur5_state_device_ptr.argtypes = [vp]
     L.ur5_state_device_ptr.restype = vp
     L.ur5_forward_debug.argtypes = [vp, dp]
+    L.ur5_render.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint8), C.POINTER(C.c_float)]
+    L.ur5_render_dev.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
     _libs[path] = L
     return L
 
@@ -210,6 +212,18 @@ class BatchSim:
         out = np.zeros((self.n, MAXB, 3))
         self._check(self.lib.ur5_body_xpos(self._h, _dp(out)), "ur5_body_xpos")
         return out
+
+    def render(self, camera_id=1, width=200, height=200, depth_mode=0):
+        """rgb uint8 [n, h, w, 3], depth float32 [n, h, w] in get_image_data orientation (depth_mode 0 = metres, 1 = GL [0,1])."""
+        rgb = np.zeros((self.n, height, width, 3), dtype=np.uint8)
+        depth = np.zeros((self.n, height, width), dtype=np.float32)
+        self._check(self.lib.ur5_render(self._h, int(camera_id), int(width), int(height), int(depth_mode),
+                                        rgb.ctypes.data_as(C.POINTER(C.c_uint8)), depth.ctypes.data_as(C.POINTER(C.c_float))), "ur5_render")
+        return rgb, depth
+
+    def render_dev(self, rgb_ptr, depth_ptr, camera_id=1, width=200, height=200, depth_mode=0):
+        self._check(self.lib.ur5_render_dev(self._h, int(camera_id), int(width), int(height), int(depth_mode), C.c_void_p(rgb_ptr),
+                                            C.c_void_p(depth_ptr)), "ur5_render_dev")
 
     def forward_debug(self):
         out = np.zeros((self.n, DEBUG_STRIDE))

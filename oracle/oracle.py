@@ -66,6 +66,7 @@ def lib():
         L.ur5o_get_vec.argtypes = [vp, C.c_int, dp]
         L.ur5o_get_contacts.argtypes = [vp, dp]
         L.ur5o_get_rows.argtypes = [vp, dp]
+        L.ur5o_render.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_ubyte), C.POINTER(C.c_float)]
         _LIB = L
     return _LIB
 
@@ -195,6 +196,13 @@ class Oracle:
         out = np.zeros(self.nv)
         lib().ur5o_get_vec(self._h, which, _dp(out))
         return out
+
+    def render(self, camera_id=1, width=200, height=200, depth_mode=0):
+        rgb = np.zeros((height, width, 3), dtype=np.uint8)
+        depth = np.zeros((height, width), dtype=np.float32)
+        lib().ur5o_render(self._h, camera_id, width, height, depth_mode, rgb.ctypes.data_as(C.POINTER(C.c_ubyte)),
+                          depth.ctypes.data_as(C.POINTER(C.c_float)))
+        return rgb, depth
 
     def contacts(self):
         n = lib().ur5o_ncon(self._h)

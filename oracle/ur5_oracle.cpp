@@ -138,7 +138,9 @@ struct Model {
   const double *geom_size, *geom_pos, *geom_quat, *geom_friction, *geom_margin, *geom_solref, *geom_solimp, *geom_rbound;
   const int *mesh_vertadr, *mesh_vertnum;
   const double* mesh_vert;
-  const int *pair_geom1, *pair_geom2, *eq_jnt1, *eq_jnt2;
+  const int *pair_geom1, *pair_geom2, *eq_jnt1, *eq_jnt2, *vis_planeadr, *vis_planenum;
+  const double *vis_plane, *geom_rgba;
+  double extent, znear, zfar;
   const double *eq_polycoef, *eq_solref, *eq_solimp;
   const int *act_jntid, *act_ctrllimited;
   const double *act_gear, *act_ctrlrange, *cam_pos, *cam_mat, *cam_fovy;
@@ -211,7 +213,8 @@ struct Model {
     for (int i = 0; i < 3; i++) gravity[i] = of[3 + i];
     for (int i = 0; i < 2; i++) jnt_solref[i] = of[6 + i];
     for (int i = 0; i < 5; i++) jnt_solimp[i] = of[8 + i];
-    meaninertia = of[13];
+    meaninertia = of[13]; extent = of[14]; znear = of[15]; zfar = of[16];
+    vis_planeadr = I("vis_planeadr"); vis_planenum = I("vis_planenum"); vis_plane = F("vis_plane"); geom_rgba = F("geom_rgba");
     iterations = I("opt_i")[0];
     body_rootid.assign(nbody, 0);
     for (int b = 1; b < nbody; b++) body_rootid[b] = body_parentid[b] == 0 ? b : body_rootid[body_parentid[b]];
@@ -1394,6 +1397,66 @@ struct Sim {
   }
   int ik_ee_body = -1, ik_base_body = -1;
 
+  // sim.render(w, h, camera, depth=True) + fliplr(flipud(.)) + depth_2_meters (MujocoController.py:708-740), restated as a
+  // per-pixel ray cast against the scene's convex shapes in fp64 (the engine's ur5_raster.h does the same in fp32).
+  // mode 0: metres along the optical axis, 1: GL window depth. rgb: flat albedo x (0.35 + 0.65 max(0, n.l)).
+  void render(int cam, int W, int H, int mode, unsigned char* rgb, float* depth) {
+    kinematics();
+    const double PI = 3.14159265358979323846;
+    double f = 0.5 * H / std::tan(M.cam_fovy[cam] * PI / 360.0);
+    V3 o = v3(M.cam_pos + 3 * cam);
+    M3 Rc; for (int k = 0; k < 9; k++) Rc.m[k] = M.cam_mat[9 * cam + k];
+    double near = M.znear * M.extent, far = M.zfar * M.extent;
+    V3 light = normalized(V3(1.0, -1.0, 3.0 - 0.435));
+    const double sky[3] = {0.65, 0.65, 0.9};
+    for (int py = 0; py < H; py++) for (int px = 0; px < W; px++) {
+      double xc = ((W - 1 - px) + 0.5 - 0.5 * W) / f, yc = ((H - 1 - py) + 0.5 - 0.5 * H) / f;
+      V3 d = mul(Rc, V3(xc, yc, -1.0));
+      double tbest = far; V3 nbest(0, 0, 1); int gbest = -1;
+      for (int g = 0; g < M.ngeom; g++) {
+        V3 ol = mulT(gxmat[g], o - gxpos[g]), dl = mulT(gxmat[g], d);
+        V3 s = v3(M.geom_size + 3 * g);
+        double t = -1; V3 nl(0, 0, 1);
+        int type = M.geom_type[g];
+        if (type == GEOM_PLANE) { if (dl.z < -1e-12) t = -ol.z / dl.z; }
+        else if (type == GEOM_SPHERE) {
+          double dd = dot(dl, dl), b = dot(ol, dl), c = dot(ol, ol) - s.x * s.x, disc = b * b - dd * c;
+          if (disc >= 0) { t = (-b - std::sqrt(disc)) / dd; nl = (ol + dl * t) * (1.0 / s.x); }
+        } else if (type == GEOM_BOX) {
+          double t0 = -1e300, t1 = 1e300; int ax = 0; double sg = 1; bool miss = false;
+          for (int k = 0; k < 3; k++) {
+            if (std::fabs(dl[k]) < 1e-15) { if (std::fabs(ol[k]) > s[k]) miss = true; continue; }
+            double ta = (-s[k] - ol[k]) / dl[k], tb = (s[k] - ol[k]) / dl[k];
+            double tn = std::min(ta, tb), tf = std::max(ta, tb);
+            if (tn > t0) { t0 = tn; ax = k; sg = dl[k] > 0 ? -1.0 : 1.0; }
+            t1 = std::min(t1, tf);
+          }
+          if (!miss && t0 <= t1 && t0 > 0) { t = t0; nl = V3(); nl[ax] = sg; }
+        } else if (type == GEOM_MESH) {
+          int k0 = M.vis_planeadr[M.geom_meshid[g]], kn = M.vis_planenum[M.geom_meshid[g]];
+          double t0 = -1e300, t1 = 1e300; int kb = -1; bool miss = false;
+          for (int k = 0; k < kn && !miss; k++) {
+            const double* pl = M.vis_plane + 4 * (k0 + k);
+            double nd = pl[0] * dl.x + pl[1] * dl.y + pl[2] * dl.z, no = pl[0] * ol.x + pl[1] * ol.y + pl[2] * ol.z + pl[3];
+            if (std::fabs(nd) < 1e-15) { if (no > 0) miss = true; continue; }
+            double tt = -no / nd;
+            if (nd < 0) { if (tt > t0) { t0 = tt; kb = k; } } else t1 = std::min(t1, tt);
+            if (t0 > t1) miss = true;
+          }
+          if (!miss && kb >= 0 && t0 > 0) { t = t0; const double* pl = M.vis_plane + 4 * (k0 + kb); nl = V3(pl[0], pl[1], pl[2]); }
+        }
+        if (t > near && t < tbest) { tbest = t; nbest = mul(gxmat[g], nl); gbest = g; }
+      }
+      size_t idx = (size_t)py * W + px;
+      if (gbest < 0) for (int k = 0; k < 3; k++) rgb[3 * idx + k] = (unsigned char)(255.0 * sky[k]);
+      else {
+        double sh = 0.35 + 0.65 * std::max(0.0, dot(nbest, light));
+        for (int k = 0; k < 3; k++) rgb[3 * idx + k] = (unsigned char)std::min(255.0, 255.0 * M.geom_rgba[4 * gbest + k] * sh + 0.5);
+      }
+      depth[idx] = (float)(mode == 0 ? tbest : (1.0 - near / tbest) / (1.0 - near / far));
+    }
+  }
+
   int move_ee(const double* xyz, double tolerance, int max_steps) {  // :446-465
     double q5[5];
     if (!ik(xyz, q5)) { last_steps = 0; ikfail_count++; return RES_IK_FAIL; }
@@ -1584,6 +1647,7 @@ void ur5o_get_vec(void* h, int which, double* out) {
   const std::vector<double>* v[] = {&s->qfrc_bias, &s->qfrc_passive, &s->qfrc_actuator, &s->qacc_smooth, &s->qacc, &s->qfrc_constraint};
   memcpy(out, v[which]->data(), 8 * s->nv);
 }
+void ur5o_render(void* h, int cam, int W, int H, int mode, unsigned char* rgb, float* depth) { ((Sim*)h)->render(cam, W, H, mode, rgb, depth); }
 int ur5o_ncon(void* h) { return (int)((Sim*)h)->contacts.size(); }
 int ur5o_nefc(void* h) { return (int)((Sim*)h)->rows.size(); }
 int ur5o_solver_iter_last(void* h) { return ((Sim*)h)->solver_iter_last; }

@@ -29,6 +29,19 @@ template <int NV> static void run_all(ur5_sim* h, const Ur5Launch& P) {
   }
   delete lds;
 }
+static int be_render(ur5_sim* h, int cam, int W, int Hh, int mode, uint8_t* rgb, float* depth) {
+  static float bp[UR5_MAXB][12], gp[UR5_R_MAXG][12];
+  for (int e = 0; e < h->n; e++) {
+    ur5r::body_poses(*h->dm, h->d_rec + (size_t)e * UR5_REC_STRIDE, bp);
+    for (int g = 0; g < h->d_rm->ngeom; g++) ur5r::geom_pose(*h->d_rm, *h->dm, bp, g, gp[g]);
+    for (int py = 0; py < Hh; py++) for (int px = 0; px < W; px++) {
+      size_t o = ((size_t)e * Hh + py) * W + px;
+      float z = ur5r::shade_pixel(*h->d_rm, gp, cam, W, Hh, px, py, rgb + 3 * o);
+      depth[o] = mode == 0 ? z : ur5r::gl_depth(*h->d_rm, z);
+    }
+  }
+  return 0;
+}
 static int be_launch(ur5_sim* h, const Ur5Launch& P) {
   if (h->nvt == 32) run_all<32>(h, P); else run_all<UR5_MAXNV>(h, P);
   return 0;

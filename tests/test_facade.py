@@ -8,7 +8,7 @@ from mujoco_rl_ur5_amd.envs import GraspEnv, make
 
 @pytest.fixture(scope="module")
 def env(model_it1, emul_lib):
-    return GraspEnv(file=model_it1, show_obs=False, render=False, n_envs=1, _lib_path=emul_lib)
+    return GraspEnv(file=model_it1, show_obs=False, render=False, n_envs=1, observation="flat", _lib_path=emul_lib)
 
 
 def test_env_surface_matches_reference(env):
@@ -59,12 +59,12 @@ def test_controller_strings_and_groups(model_it1, emul_lib):
     assert c.sim.get_ctrl()[0, 6] == 0.5
     c.stay(20)
     assert isinstance(c.grasp(quiet=True), bool)
-    with pytest.raises(NotImplementedError):
-        c.get_image_data()
+    rgb, d = c.get_image_data(width=40, height=40)
+    assert rgb.shape == (40, 40, 3) and rgb.dtype == np.uint8 and 0 < d.min() and d.max() <= 1.0
 
 
 def test_batched_env_and_make(model_it1, emul_lib):
-    e = make("gym_grasper:Grasper-v0", file=model_it1, n_envs=2, show_obs=False, _lib_path=emul_lib)
+    e = make("gym_grasper:Grasper-v0", file=model_it1, n_envs=2, show_obs=False, observation="flat", _lib_path=emul_lib)
     obs = e.reset()
     assert obs["depth"].shape == (2, 200, 200)
     a = np.stack([e.action_space.sample(), e.action_space.sample()])

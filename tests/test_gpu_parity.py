@@ -123,6 +123,25 @@ def test_full_size_batch_properties(native_mod, model_it1):
     assert np.isfinite(sim.get_state()["qpos"]).all()
 
 
+def test_six_object_scene_nv44_kernel(native_mod, model_2f):
+    """The in-tree UR5gripper_2_finger.xml (3 boxes + 3 spheres, nv = 44) runs through the NV=44 instantiation: settle + one
+    grasp attempt against the oracle."""
+    from oracle.oracle import Oracle
+    m = model_2f
+    sim = native_mod.BatchSim(m, 4)
+    sim.reset(20 + np.arange(4, dtype=np.uint64), 1, 1000.0)
+    o = Oracle(m)
+    o.reset(21, 1, True)
+    st = sim.get_state()
+    assert np.abs(st["qpos"][1] - o.get_state()["qpos"]).max() < 1e-8
+    acts = aimed_actions(st["qpos"], 6)
+    rew, ps, pr = sim.grasp_attempt(acts, rot=0, check_mode=0)
+    r, pso, pro = o.grasp_attempt(acts[1], 0, 0)
+    assert r == rew[1] and pso.tolist() == ps[1].tolist()
+    assert np.abs(sim.get_state()["qpos"][1][:8] - o.get_state()["qpos"][:8]).max() < 1e-6
+    assert np.all(sim.counters()["status"] == 0)
+
+
 def test_device_pointer_entry(native_mod, model_it1):
     import torch
     m = model_it1

@@ -1,0 +1,76 @@
+"""RGB-D observation: engine ray caster (lane emulation here, HIP kernel under -m gpu) vs the
+oracle's fp64 restatement, plus known answers that need no oracle."""
+import numpy as np
+import pytest
+
+from mujoco_rl_ur5_amd.controller import MJ_Controller
+from mujoco_rl_ur5_amd.envs import GraspEnv
+from mujoco_rl_ur5_amd.native import BatchSim
+from oracle.oracle import Oracle
+
+
+def _known_answers(model, sim, depth, rgb):
+    """Table top at z = 0.91, floor at 0, settled 4 cm cubes at 0.951; camera at z = 2 looking straight down."""
+    c = MJ_Controller(model, simulation=sim)
+    assert abs(depth[100, 100] - 1.09) < 2e-5                       # plate top (UR5gripper_2_finger.xml:126)
+    assert abs(depth[190, 5] - 2.0) < 2e-5                          # floor plane beside the table
+    q = sim.get_state()["qpos"][0]
+    for k in range(4):
+        o = q[8 + 7 * k: 8 + 7 * k + 3]
+        z_top = 0.95 + 0.1 * k + o[2] + 0.02
+        px = c.world_2_pixel([o[0], -0.6 + o[1], z_top])
+        assert abs(depth[px[1], px[0]] - (2.0 - z_top)) < 2e-3       # cube top seen at its own pixel
+        w = c.pixel_2_world(px[0], px[1], depth[px[1], px[0]])       # GraspingEnv.py:100-104: pixel + depth -> grasp point
+        assert np.linalg.norm(w[:2] - [o[0], -0.6 + o[1]]) < 6e-3 and abs(w[2] - z_top) < 2e-3
+    assert rgb[100, 100].min() > 60 and rgb[100, 100].tolist() != rgb[190, 5].tolist()
+
+
+def test_render_matches_oracle_and_known_answers(model_it1, emul_lib):
+    sim = BatchSim(model_it1, 2, lib_path=emul_lib)
+    sim.reset([20, 21], 1, 1000.0)
+    sim.move_ee([0.05, -0.55, 1.0], 0.05, 600)                      # bring the gripper meshes into view
+    o = Oracle(model_it1)
+    o.reset(20, 1, True)
+    o.move_ee([0.05, -0.55, 1.0], 0.05, 600)
+    rgb, depth = sim.render(1, 200, 200, 0)
+    rgbo, deptho = o.render(1, 200, 200, 0)
+    assert np.abs(depth[0] - deptho).max() < 1e-4                   # metres; fp32 engine vs fp64 oracle
+    assert (np.abs(rgb[0].astype(int) - rgbo.astype(int)).max(axis=2) > 2).mean() < 1e-3
+    assert depth[0].min() < 0.8                                     # the gripper is the closest thing to the camera
+    _known_answers(model_it1, sim, depth[0], rgb[0])
+    gl = sim.render(1, 200, 200, 1)[1]
+    c = MJ_Controller(model_it1, simulation=sim)
+    assert np.abs(c.depth_2_meters(gl[0]) - depth[0]).max() < 2e-4   # depth_2_meters inverts the GL encoding (:737-740)
+
+
+def test_env_with_rendered_observation(model_it1, emul_lib):
+    env = GraspEnv(file=model_it1, show_obs=False, n_envs=1, observation="render", image_width=100, image_height=100, _lib_path=emul_lib)
+    obs = env.reset()
+    assert obs["rgb"].shape == (100, 100, 3) and obs["depth"].shape == (100, 100)
+    q = env.sim.get_state()["qpos"][0]
+    px = env.controller.world_2_pixel([q[8], -0.6 + q[9], 0.951], width=100, height=100)
+    obs, reward, done, info = env.step([px[1] * 100 + px[0], 0])    # grasp height now comes from the depth image (IT4)
+    assert reward in (0, 1) and info["phase_steps"][3] > 0
+
+
+@pytest.mark.gpu
+def test_render_on_gpu(model_it1):
+    import torch
+    assert torch.cuda.is_available()
+    sim = BatchSim(model_it1, 8)
+    sim.reset(20 + np.arange(8, dtype=np.uint64), 1, 1000.0)
+    sim.move_ee([0.05, -0.55, 1.0], 0.05, 600)
+    o = Oracle(model_it1)
+    o.reset(23, 1, True)
+    o.move_ee([0.05, -0.55, 1.0], 0.05, 600)
+    rgb, depth = sim.render(1, 200, 200, 0)
+    rgbo, deptho = o.render(1, 200, 200, 0)
+    assert np.abs(depth[3] - deptho).max() < 1e-4
+    assert (np.abs(rgb[3].astype(int) - rgbo.astype(int)).max(axis=2) > 2).mean() < 1e-3
+    _known_answers(model_it1, sim, depth[0], rgb[0])
+    img = torch.zeros((8, 200, 200, 3), dtype=torch.uint8, device="cuda")
+    dep = torch.zeros((8, 200, 200), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    sim.render_dev(img.data_ptr(), dep.data_ptr(), 1, 200, 200, 0)
+    sim.sync()
+    assert np.array_equal(dep.cpu().numpy(), depth) and np.array_equal(img.cpu().numpy(), rgb)
