@@ -646,17 +646,18 @@ template <class real, int NV_> struct Engine {
   struct Sink { int mode, slot, n, g1, g2; };
   struct Single { bool hit; v3 pos, normal; real dist; int sat_code; bool sat_flip; real sat_best; };
   UR5_CALL void emit(Sink& k, v3 pos, v3 normal, real dist) const {
-    if (k.mode) {
-      int c = k.slot + k.n;
-      if (c < UR5_MAXCON) {
-        pos.store(S.cpos[c]);
-        make_frame(normal, S.cframe[c]);
-        S.cdist[c] = dist;
-        S.cg1[c] = k.g1; S.cg2[c] = k.g2;
-        S.cA[c] = body_of_geom(k.g1); S.cB[c] = body_of_geom(k.g2);
-        S.cdim[c] = M.g_condim[k.g1] > M.g_condim[k.g2] ? M.g_condim[k.g1] : M.g_condim[k.g2];
-        for (int j = 0; j < (NB > 4 ? 3 : 2); j++) S.cfri[c][j] = maxv((real)M.g_friction[k.g1][j], (real)M.g_friction[k.g2][j]);
-      }
+    // one pass: a slot is claimed with an LDS atomic counter. Only this wavefront touches the counter, so the order is
+    // reproducible (it differs from the oracle's pair order, which only permutes floating-point sums downstream).
+#ifdef UR5_EMUL
+    int c = S.ncon++;
+#else
+    int c = __hip_atomic_fetch_add(&S.ncon, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+    if (c < UR5_MAXCON) {
+      pos.store(S.cpos[c]);
+      normal.store(S.cframe[c]);          // tangents, friction, condim, bodies: make_constraints(), one lane per contact
+      S.cdist[c] = dist;
+      S.cg1[c] = k.g1; S.cg2[c] = k.g2;
     }
     k.n++;
   }
@@ -918,48 +919,27 @@ template <class real, int NV_> struct Engine {
     }
     SYNC();
     PROF(PF_BROAD);
-    // narrow phase: one candidate per lane, two passes over ONE narrow() call site: pass 0 counts each pair's contacts, a wave
-    // prefix sum hands out the slots in candidate order, pass 1 writes them
-    int base = 0;
+    // narrow phase: one candidate per lane, single pass
 #ifdef UR5_EMUL
     for (int ci = 0; ci < ncand; ci++) {
 #else
     {
       const int ci = UR5_LANE;
 #endif
-      Sink sink;
-      Single keep;
-      keep.hit = false; keep.sat_code = -1; keep.sat_flip = false; keep.sat_best = 0;
-      sink.slot = 0; sink.n = 0; sink.g1 = 0; sink.g2 = 0;
-      real margin = 0;
       if (ci < ncand) {
+        Sink sink;
+        Single keep;
+        keep.hit = false; keep.sat_code = -1; keep.sat_flip = false; keep.sat_best = 0;
+        sink.mode = 0; sink.slot = 0; sink.n = 0;
         int p = S.cand[ci];
         sink.g1 = M.pair_g1[p]; sink.g2 = M.pair_g2[p];
-        margin = maxv((real)M.g_margin[sink.g1], (real)M.g_margin[sink.g2]);
-      }
-      int cnt = 0;
-      for (int pass = 0; pass < 2; pass++) {
-        sink.mode = pass;
-        if (pass == 1) {
-#ifdef UR5_EMUL
-          sink.slot = base;
-          base += cnt;
-#else
-          int incl = cnt;
-#pragma unroll
-          for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o, 64); if (UR5_LANE >= o) incl += t; }
-          sink.slot = incl - cnt;
-          base = __shfl(incl, 63, 64);
-#endif
-        }
-        sink.n = 0;
-        if (ci < ncand && (pass == 0 || cnt > 0)) narrow(sink.g1, sink.g2, margin, sink, keep);
-        if (pass == 0) cnt = sink.n;
+        real margin = maxv((real)M.g_margin[sink.g1], (real)M.g_margin[sink.g2]);
+        narrow(sink.g1, sink.g2, margin, sink, keep);
       }
     }
     SYNC();
     if (UR5_LANE == 0) {
-      int n = base;
+      int n = S.ncon;
       if (n > UR5_MAXCON) { n = UR5_MAXCON; S.status |= UR5_ST_CONTACT_OVERFLOW; }
       S.ncon = n;
       if (n > S.ncon_max) S.ncon_max = n;
@@ -1052,18 +1032,13 @@ template <class real, int NV_> struct Engine {
         }
       }
       S.nsr = ns;
-      int nc = 0;
-      unsigned bm = 0;
-      for (int c = 0; c < S.ncon; c++) {
-        if (S.cA[c] >= 0 && S.cB[c] >= 0) S.couple[nc++] = c;
-        if (S.cA[c] >= 0) bm |= 1u << S.cA[c];
-        if (S.cB[c] >= 0) bm |= 1u << S.cB[c];
-      }
-      S.ncouple = nc;
-      S.bodymask = bm;
     }
     PAR(c, S.ncon) {
       int g1 = S.cg1[c], g2 = S.cg2[c];
+      make_frame(v3(S.cframe[c]), S.cframe[c]);
+      S.cA[c] = body_of_geom(g1); S.cB[c] = body_of_geom(g2);
+      S.cdim[c] = M.g_condim[g1] > M.g_condim[g2] ? M.g_condim[g1] : M.g_condim[g2];
+      for (int j = 0; j < (NB > 4 ? 3 : 2); j++) S.cfri[c][j] = maxv((real)M.g_friction[g1][j], (real)M.g_friction[g2][j]);
       real margin = maxv((real)M.g_margin[g1], (real)M.g_margin[g2]);
       real pos = S.cdist[c];
       double solref[2], solimp[5];
@@ -1084,6 +1059,18 @@ template <class real, int NV_> struct Engine {
       contact_image(c, hasA ? S.cvel[S.cA[c]] : S.cvel[0], hasB ? S.cvel[S.cB[c]] : S.cvel[0], hasA, hasB, vb);
       for (int k = 0; k < NB; k++) S.ceoff[c][k] = B * vb[k];
       S.ceoff[c][0] += ckr;
+    }
+    SYNC();
+    if (UR5_LANE == 0) {
+      int nc = 0;
+      unsigned bm = 0;
+      for (int c = 0; c < S.ncon; c++) {
+        if (S.cA[c] >= 0 && S.cB[c] >= 0) S.couple[nc++] = c;
+        if (S.cA[c] >= 0) bm |= 1u << S.cA[c];
+        if (S.cB[c] >= 0) bm |= 1u << S.cB[c];
+      }
+      S.ncouple = nc;
+      S.bodymask = bm;
     }
     SYNC();
   }
