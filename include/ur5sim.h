@@ -74,7 +74,7 @@ int ur5_grasp_attempt_dev(ur5_sim* h, const double* action_dev, int check_mode, 
 int ur5_sync(ur5_sim* h);
 /* duration of the last launch in ms, from HIP events recorded on the handle's stream around the kernel */
 double ur5_last_launch_ms(ur5_sim* h);
-/* counters[n][4] host: total physics steps, last_movement_steps, status bits, Newton iterations */
+/* counters[n][5] host: total physics steps, last_movement_steps, status bits, Newton iterations, max contacts seen in a step */
 int ur5_get_counters(ur5_sim* h, int64_t* counters);
 /* world positions of the engine's bodies [n][14][3]: 8 robot weld groups (dof order) then the objects */
 int ur5_body_xpos(ur5_sim* h, double* out);

@@ -15,7 +15,7 @@
 #define UR5_MAXG 48
 #define UR5_MAXDG 16                               // dynamic (robot / object) collidable geoms
 #define UR5_MAXPAIR 384
-#define UR5_MAXCON 24
+#define UR5_MAXCON 30
 #define UR5_MAXSR 16                               // equality + limit rows
 #define UR5_MAXCAND 64
 #define UR5_MAXHV 1024                             // hull vertices of collidable meshes

@@ -151,10 +151,11 @@ UR5_FN int sym6(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1
 // ---------------------------------------------------------------------------------------------- LDS image of one scene
 template <class real, int NV_> struct Lds {
   static constexpr int NV = NV_;
+  static constexpr int NBODY = UR5_MAXRD + (NV_ - UR5_MAXRD) / 6;   // cbodies of this instantiation
   static constexpr int LD = NV_ + 1;                 // padded leading dimension of H (odd multiple of the bank width)
   real rec[UR5_REC_STRIDE];                          // persistent state, same layout as the HBM record
   // kinematics that the Newton phase still needs
-  real bpos[UR5_MAXB][3], bmat[UR5_MAXB][9], cdof[UR5_MAXRD][6];
+  real bpos[NBODY][3], bmat[NBODY][9], cdof[UR5_MAXRD][6];
   real Mr[UR5_MAXRD][UR5_MAXRD + 1], Lr[UR5_MAXRD][UR5_MAXRD + 1], Ld[UR5_MAXRD][UR5_MAXRD + 1];
   real Mobj[6 * UR5_MAXOBJ];
 #ifdef UR5_EMUL
@@ -170,7 +171,7 @@ template <class real, int NV_> struct Lds {
     struct {
       real jq[UR5_MAXRD][4], bquat[UR5_MAXRD][4], anchor[UR5_MAXRD][3], axis[UR5_MAXRD][3], cdd[UR5_MAXRD][6];
       real cinert[UR5_MAXRD][10], buf[UR5_MAXRD][6], cfrc[UR5_MAXRD][6];
-      real cvel[UR5_MAXB][6];                        // body twist velocity [rot; lin] about the body's reference point
+      real cvel[NBODY][6];                           // body twist velocity [rot; lin] about the body's reference point
       real dgpos[UR5_MAXDG][3], dgmat[UR5_MAXDG][9];
     };
     real H[HSIZE];
@@ -183,14 +184,17 @@ template <class real, int NV_> struct Lds {
   int cA[UR5_MAXCON], cB[UR5_MAXCON], cdim[UR5_MAXCON], cg1[UR5_MAXCON], cg2[UR5_MAXCON];
   short cand[UR5_MAXCAND];
   int couple[UR5_MAXCON];
-  real cpos[UR5_MAXCON][3], cframe[UR5_MAXCON][9], cdist[UR5_MAXCON], cfri[UR5_MAXCON][NB > 4 ? 3 : 2];
+  real cpos[UR5_MAXCON][3], cframe[UR5_MAXCON][6], cdist[UR5_MAXCON], cfri[UR5_MAXCON][NB > 4 ? 3 : 2];   // cframe: normal, tangent 1 (tangent 2 = n x t1)
   real cD[UR5_MAXCON];
-  real ceoff[UR5_MAXCON][NB], ce[UR5_MAXCON][NB], cde[UR5_MAXCON][NB], cfn[UR5_MAXCON];   // ceoff: -aref in base space; cfn: normal force
+  real ceoff[UR5_MAXCON][NB], ce[UR5_MAXCON][NB], cde[UR5_MAXCON][NB];   // ceoff: -aref in base space
+#ifdef UR5_EMUL
+  real cfn[UR5_MAXCON];                              // normal force, test introspection only
+#endif
   // special rows (joint equality, joint limits): jar = c1 x[d1] + c2 x[d2] - aref
   int sr_d1[UR5_MAXSR], sr_d2[UR5_MAXSR], sr_uni[UR5_MAXSR];
   real sr_c1[UR5_MAXSR], sr_c2[UR5_MAXSR], sr_D[UR5_MAXSR], sr_aref[UR5_MAXSR], sr_jar[UR5_MAXSR], sr_jv[UR5_MAXSR];
   // body accumulators (twist space)
-  real tw[UR5_MAXB][6], WB[UR5_MAXB][6], G[UR5_MAXB][21];
+  real tw[NBODY][6], WB[NBODY][6], G[NBODY][21];
 #if defined(UR5_PROFILE) && !defined(UR5_EMUL)
   double prof[PF_COUNT];
 #endif
@@ -880,8 +884,7 @@ template <class real, int NV_> struct Engine {
   UR5_FN static void make_frame(v3 n, real* fr) {
     v3 y = fabs(n.y) < (real)0.5 ? v3(0, 1, 0) : v3(0, 0, 1);
     y = normalized(y - n * dot(n, y));   // |y - n (n.y)| >= 0.86: never degenerate
-    v3 z = cross(n, y);
-    n.store(fr); y.store(fr + 3); z.store(fr + 6);
+    n.store(fr); y.store(fr + 3);   // the third axis is cross(n, y), recomputed where needed
   }
   UR5_FN int body_of_geom(int g) const {  // cbody index (robot dof or nrd + object) or -1 for static
     int k = M.g_kind[g];
@@ -975,7 +978,8 @@ template <class real, int NV_> struct Engine {
     v3 u, w;
     if (hasB) { v3 r = p - body_ref(S.cB[c]); v3 om(twB), vl(twB + 3); u = vl + cross(om, r); w = om; }
     if (hasA) { v3 r = p - body_ref(S.cA[c]); v3 om(twA), vl(twA + 3); u = u - (vl + cross(om, r)); w = w - om; }
-    v3 n(S.cframe[c]), t1(S.cframe[c] + 3), t2(S.cframe[c] + 6);
+    v3 n(S.cframe[c]), t1(S.cframe[c] + 3);
+    v3 t2 = cross(n, t1);
     e[0] = dot(n, u); e[1] = dot(t1, u); e[2] = dot(t2, u); e[3] = dot(n, w);
     if constexpr (NB > 4) { e[NB - 2] = dot(t1, w); e[NB - 1] = dot(t2, w); }
   }
@@ -1191,10 +1195,12 @@ template <class real, int NV_> struct Engine {
     PAR(idx, nbod * 27) { int b = idx / 27, ent = idx % 27; if (ent < 6) S.WB[b][ent] = 0; else S.G[b][ent - 6] = 0; }
     SYNC();
     PAR(c, S.ncon) {
-      v3 ax[3] = {v3(S.cframe[c]), v3(S.cframe[c] + 3), v3(S.cframe[c] + 6)};
+      v3 ax[3] = {v3(S.cframe[c]), v3(S.cframe[c] + 3), cross(v3(S.cframe[c]), v3(S.cframe[c] + 3))};
       real fb[NB], w[2 * NB - 1];
       contact_weights(c, fb, w);
+#ifdef UR5_EMUL
       S.cfn[c] = fb[0];
+#endif
       v3 F = ax[0] * fb[0] + ax[1] * fb[1] + ax[2] * fb[2];
       v3 T = ax[0] * fb[3];
       if constexpr (NB > 4) T = T + ax[1] * fb[NB - 2] + ax[2] * fb[NB - 1];
@@ -1882,7 +1888,11 @@ template <class real, int NV_> struct Engine {
       for (int k = 0; k < 3; k++) out[o++] = ok ? (double)S.cpos[c][k] : 0;
       for (int k = 0; k < 3; k++) out[o++] = ok ? (double)S.cframe[c][k] : 0;
       out[o++] = ok ? S.cg1[c] : -1; out[o++] = ok ? S.cg2[c] : -1;
+#ifdef UR5_EMUL
       out[o++] = ok ? (double)S.cfn[c] : 0;
+#else
+      out[o++] = 0;
+#endif
     }
   }
 };

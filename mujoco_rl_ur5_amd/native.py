@@ -144,9 +144,9 @@ class BatchSim:
         return c
 
     def counters(self):
-        c = np.zeros((self.n, 4), dtype=np.int64)
+        c = np.zeros((self.n, 5), dtype=np.int64)
         self._check(self.lib.ur5_get_counters(self._h, c.ctypes.data_as(C.POINTER(C.c_int64))), "ur5_get_counters")
-        return dict(total_steps=c[:, 0], last_steps=c[:, 1], status=c[:, 2], solver_iters=c[:, 3])
+        return dict(total_steps=c[:, 0], last_steps=c[:, 1], status=c[:, 2], solver_iters=c[:, 3], ncon_max=c[:, 4])
 
     # ---- dynamics
     def step(self, nsteps=1):
@@ -230,5 +230,5 @@ class BatchSim:
         self._check(self.lib.ur5_forward_debug(self._h, _dp(out)), "ur5_forward_debug")
         d = dict(ncon=out[:, 0].astype(int), nsr=out[:, 1].astype(int), bpos=out[:, 8:50].reshape(self.n, 14, 3),
                  Mr=out[:, 50:114].reshape(self.n, 8, 8), qfrc_smooth=out[:, 114:158], qacc_smooth=out[:, 158:202],
-                 qacc=out[:, 202:246], contacts=out[:, 246:246 + 240].reshape(self.n, 24, 10))
+                 qacc=out[:, 202:246], contacts=out[:, 246:246 + 300].reshape(self.n, 30, 10))
         return d

@@ -17,4 +17,13 @@ for e in range(n):
 c0 = sim.counters()["total_steps"].sum()
 rew, ps, pr = sim.grasp_attempt(acts, rot=np.arange(n) % 6, check_mode=1)
 c1 = sim.counters()["total_steps"].sum()
+c = sim.counters()
+print("ncon_max histogram:", np.bincount(c["ncon_max"])[10:].tolist(), "status!=0:", int((c["status"] != 0).sum()))
+for r in range(int(os.environ.get("EXTRA_ROUNDS", "0"))):
+    st = sim.get_state()["qpos"]
+    for e in range(n):
+        o = st[e][8:].reshape(-1, 7); k = (e + r + 1) % 4
+        acts[e] = [o[k, 0], -0.6 + o[k, 1], 0.91]
+    sim.grasp_attempt(acts, rot=np.arange(n) % 6, check_mode=1)
+    c = sim.counters(); print("round", r + 2, "ncon_max histogram from 10:", np.bincount(c["ncon_max"])[10:].tolist(), "status!=0:", int((c["status"] != 0).sum()))
 print("grasp kernel %.1f ms, %d env-steps, %.3e env-steps/s, success %.2f" % (sim.last_launch_ms(), c1 - c0, (c1 - c0) / sim.last_launch_ms() * 1e3, rew.mean()))
