@@ -134,6 +134,14 @@ def main():
         bytes_per_step = 2 * words * 8
         k_s = sum(kernel_ms) * 1e-3
         achieved = steps_local * bytes_per_step / k_s / 1e9
+        # measured HBM bytes per env-step from the rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this same command (profiles/)
+        traffic, traffic_src = None, None
+        tp = os.path.join(ROOT, "profiles", "r01_e_hbm_traffic.json")
+        if os.path.exists(tp):
+            with open(tp) as f:
+                tj = json.load(f)
+            traffic = tj["hbm_bytes_per_env_step"] * steps_local / args.steps
+            traffic_src = "profiles/r01_e_hbm_traffic.json: (FETCH_SIZE + WRITE_SIZE) per env-step x env-steps of an average timed launch"
         out = {
             "metric": "env-steps/sec (+ grasp-attempts/sec), 4096 parallel UR5 scenes per MI355X",
             "value": steps_all / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -147,7 +155,7 @@ def main():
                                    "fixed z = 0.91, lift + 500-step closing check, one grasp-attempt round per step",
                        "scenes_per_gpu": n_local, "scenes_total": n_total, "solver": "Newton (MuJoCo default), tol 1e-10",
                        "timestep_s": model.opt["timestep"], "parallelism": f"scenes sharded x{world}, 1 all_gather of 16 B outcome records per round"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "ur5_run_kernel<32>", "bytes_per_env_step": bytes_per_step,
                          "avg_launch_ms": float(np.mean(kernel_ms)), "env_steps_per_launch": steps_local / args.steps,
                          "note": "algorithmic state bytes x env-steps / HIP-event kernel time on the handle's stream (rank 0). The kernel keeps a "

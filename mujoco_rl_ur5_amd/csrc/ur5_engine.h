@@ -120,8 +120,12 @@ template <class T> UR5_FN Q4<T> qnormalize(Q4<T> q) {
 template <class T> struct M3 {  // row-major
   T m[9];
   // selects instead of m[j]: a run-time index into a register array would push the matrix into scratch memory
-  UR5_FN V3<T> col(int j) const { return j == 0 ? V3<T>(m[0], m[3], m[6]) : (j == 1 ? V3<T>(m[1], m[4], m[7]) : V3<T>(m[2], m[5], m[8])); }
-  UR5_FN V3<T> row(int i) const { return i == 0 ? V3<T>(m[0], m[1], m[2]) : (i == 1 ? V3<T>(m[3], m[4], m[5]) : V3<T>(m[6], m[7], m[8])); }
+  UR5_FN V3<T> col(int j) const {   // per-component scalar selects (a select between whole structs is lowered through scratch)
+    return V3<T>(j == 0 ? m[0] : (j == 1 ? m[1] : m[2]), j == 0 ? m[3] : (j == 1 ? m[4] : m[5]), j == 0 ? m[6] : (j == 1 ? m[7] : m[8]));
+  }
+  UR5_FN V3<T> row(int i) const {
+    return V3<T>(i == 0 ? m[0] : (i == 1 ? m[3] : m[6]), i == 0 ? m[1] : (i == 1 ? m[4] : m[7]), i == 0 ? m[2] : (i == 1 ? m[5] : m[8]));
+  }
   template <class U> UR5_FN void load(const U* p) { for (int i = 0; i < 9; i++) m[i] = (T)p[i]; }
   template <class U> UR5_FN void store(U* p) const { for (int i = 0; i < 9; i++) p[i] = m[i]; }
 };
@@ -1118,7 +1122,8 @@ template <class real, int NV_> struct Engine {
     SYNC();
   }
   // constraint cost of the current images (ce, sr_jar) shifted by alpha along (cde, sr_jv); also first/second derivative
-  UR5_CALL void constraint_cost(real alpha, real* cost, real* d1, real* d2) {
+  struct Cost3 { real c, d1, d2; };
+  UR5_CALL Cost3 constraint_cost(real alpha) {
     real c0 = 0, g1 = 0, g2 = 0;
     PAR(c, S.ncon) {
       real D = S.cD[c];
@@ -1139,7 +1144,9 @@ template <class real, int NV_> struct Engine {
       real r = S.sr_jar[s] + alpha * S.sr_jv[s], j = S.sr_jv[s];
       if (!S.sr_uni[s] || r < 0) { c0 += (real)0.5 * S.sr_D[s] * r * r; g1 += S.sr_D[s] * r * j; g2 += S.sr_D[s] * j * j; }
     }
-    *cost = WAVE_SUM(c0); *d1 = WAVE_SUM(g1); *d2 = WAVE_SUM(g2);
+    Cost3 r;
+    r.c = WAVE_SUM(c0); r.d1 = WAVE_SUM(g1); r.d2 = WAVE_SUM(g2);
+    return r;
   }
   UR5_FN real gauss_cost(const real* xv, const real* Ma) {
     real g = 0;
@@ -1458,7 +1465,7 @@ template <class real, int NV_> struct Engine {
     }
     PROF_T0();
     // warm start: cheaper of qacc_warmstart and qacc_smooth
-    real dummy1, dummy2, ccw;
+    real ccw;
     PAR(i, nv) S.x[i] = warm()[i];
     SYNC();
     mat_vec_M(S.x, S.Ma);
@@ -1466,7 +1473,7 @@ template <class real, int NV_> struct Engine {
     PAR(c, S.ncon) for (int k = 0; k < NB; k++) S.cde[c][k] = 0;
     PAR(s, S.nsr) S.sr_jv[s] = 0;
     SYNC();
-    constraint_cost(0, &ccw, &dummy1, &dummy2);
+    ccw = constraint_cost(0).c;
     real cw = gauss_cost(S.x, S.Ma) + ccw;
     SYNC();
     mat_vec_M(S.as, S.Mv);
@@ -1521,17 +1528,16 @@ template <class real, int NV_> struct Engine {
       q1 = WAVE_SUM(q1); q2 = WAVE_SUM(q2); sn = sqrt(WAVE_SUM(sn));
       if (sn < (real)1e-15) break;
       real gtol = tolerance * (real)0.01 * sn / scale;
-      real lo = 0, hi = -1, a = 0, cc, d1, d2;
-      constraint_cost(0, &cc, &d1, &d2);
-      d1 += q1; d2 += q2;
+      real lo = 0, hi = -1, a = 0, d1, d2;
+      { Cost3 k0 = constraint_cost(0); d1 = k0.d1 + q1; d2 = k0.d2 + q2; }
       if (d1 < 0) {
         for (int ls = 0; ls < 50; ls++) {
           real an = a - d1 / d2;
           if (hi > 0 && (an <= lo || an >= hi)) an = (real)0.5 * (lo + hi);
           if (hi < 0 && an <= lo) an = 2 * lo + (real)1e-12;
           a = an;
-          constraint_cost(a, &cc, &d1, &d2);
-          d1 += q1 + a * q2; d2 += q2;
+          Cost3 ka = constraint_cost(a);
+          d1 = ka.d1 + q1 + a * q2; d2 = ka.d2 + q2;
           if (fabs(d1) <= gtol) break;
           if (d1 < 0) lo = a; else hi = a;
         }
@@ -1542,9 +1548,7 @@ template <class real, int NV_> struct Engine {
       PAR(c, S.ncon) for (int k = 0; k < NB; k++) { S.ce[c][k] += a * S.cde[c][k]; S.cde[c][k] = 0; }
       PAR(s, S.nsr) { S.sr_jar[s] += a * S.sr_jv[s]; S.sr_jv[s] = 0; }
       SYNC();
-      real ccn, t1, t2;
-      constraint_cost(0, &ccn, &t1, &t2);
-      real newcost = gauss_cost(S.x, S.Ma) + ccn;
+      real newcost = gauss_cost(S.x, S.Ma) + constraint_cost(0).c;
       improvement = scale * (cost - newcost);
       cost = newcost;
       SYNC();
