@@ -142,6 +142,33 @@ def test_six_object_scene_nv44_kernel(native_mod, model_2f):
     assert np.all(sim.counters()["status"] == 0)
 
 
+def test_grasp_bit_agreement_statistics(native_mod, model_it1):
+    """agreement rate of the binary grasp outcome over many scenes, all six wrist rotations, a third of the
+    attempts aimed off-centre (profiles/r01_e_grasp_agreement_384scenes.json has the 384-scene run: 100 %)."""
+    from oracle.oracle import Oracle
+    m = model_it1
+    n = 48
+    sim = native_mod.BatchSim(m, n)
+    seeds = 5000 + np.arange(n, dtype=np.uint64)
+    sim.reset(seeds, 1, 1000.0)
+    acts = aimed_actions(sim.get_state()["qpos"], 4)
+    rng = np.random.default_rng(3)
+    acts[::3, :2] += rng.uniform(-0.012, 0.012, size=(len(acts[::3]), 2))
+    rots = np.arange(n) % 6
+    rew, ps, pr = sim.grasp_attempt(acts, rot=rots, check_mode=1)
+    s2 = sim.get_state()["qpos"]
+    agree, worst = 0, 0.0
+    for e in range(n):
+        o = Oracle(m)
+        o.reset(int(seeds[e]), 1, True)
+        r, pso, pro = o.grasp_attempt(acts[e], int(rots[e]), 1)
+        agree += int(r == rew[e])
+        worst = max(worst, np.abs(s2[e][:8] - o.get_state()["qpos"][:8]).max() / max(1.0, np.abs(o.get_state()["qpos"][:8]).max()))
+    assert agree == n                    # bit-exact grasp outcomes
+    assert worst < 1e-4                  # north_star: joint trajectories within 1e-4 rel
+    assert 0.1 < rew.mean() < 0.95
+
+
 def test_device_pointer_entry(native_mod, model_it1):
     import torch
     m = model_it1

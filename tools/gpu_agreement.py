@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Grasp-outcome agreement statistics: HIP engine vs the fp64 CPU oracle over many scenes, all 6 rotations,
+both check modes. Prints one JSON line; run through gpurun, keep the result under profiles/."""
+import json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from mujoco_rl_ur5_amd.model import load_model
+from mujoco_rl_ur5_amd.native import BatchSim
+from oracle.oracle import Oracle
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 192
+m = load_model("it1_4box")
+out = {}
+for mode in (0, 1):
+    sim = BatchSim(m, n)
+    seeds = 1000 * (mode + 1) + np.arange(n, dtype=np.uint64)
+    sim.reset(seeds, 1, 1000.0)
+    st = sim.get_state()["qpos"]
+    rng = np.random.default_rng(7 + mode)
+    acts = np.zeros((n, 3)); rots = np.arange(n) % 6
+    for e in range(n):
+        o = st[e][8:].reshape(-1, 7); k = e % 4
+        jitter = rng.uniform(-0.012, 0.012, size=2) if e % 3 == 0 else 0.0      # a third of the attempts aim slightly off
+        acts[e] = [o[k, 0], -0.6 + o[k, 1], 0.91]; acts[e, :2] += jitter
+    rew, ps, pr = sim.grasp_attempt(acts, rot=rots, check_mode=mode)
+    s2 = sim.get_state()["qpos"]
+    t0 = time.time(); agree = 0; steps_equal = 0; worst = 0.0; worst_obj = 0.0
+    for e in range(n):
+        orc = Oracle(m); orc.reset(int(seeds[e]), 1, True)
+        r, pso, pro = orc.grasp_attempt(acts[e], int(rots[e]), mode)
+        so = orc.get_state()["qpos"]
+        agree += int(r == rew[e]); steps_equal += int(pso.tolist() == ps[e].tolist())
+        rel = np.abs(s2[e][:8] - so[:8]).max() / max(1.0, np.abs(so[:8]).max())
+        worst = max(worst, rel)
+        if pso.tolist() == ps[e].tolist(): worst_obj = max(worst_obj, np.abs(s2[e][8:] - so[8:]).max())
+    out["check_mode_%d" % mode] = dict(scenes=n, grasp_bit_agreement=agree / n, phase_steps_identical=steps_equal / n,
+                                       worst_arm_rel_error=worst, worst_object_abs_error_when_steps_equal=worst_obj,
+                                       success_rate=float(rew.mean()), oracle_seconds=round(time.time() - t0, 1),
+                                       status_nonzero=int((sim.counters()["status"] != 0).sum()))
+print(json.dumps(out))
