@@ -12,6 +12,7 @@
 #define UR5_MAXNV (UR5_MAXRD + 6 * UR5_MAXOBJ)     // 44
 #define UR5_MAXNQ (UR5_MAXRD + 7 * UR5_MAXOBJ)     // 50
 #define UR5_MAXNU 8
+#define UR5_MAXRG 4                                // robot weld groups that carry collision geoms (wrist_3 group, two knuckle groups)
 #define UR5_MAXG 48
 #define UR5_MAXDG 16                               // dynamic (robot / object) collidable geoms
 #define UR5_MAXPAIR 384
@@ -41,13 +42,15 @@ enum { UR5_KIND_STATIC = 0, UR5_KIND_ROBOT = 1, UR5_KIND_OBJECT = 2 };
 #define UR5_ST_ROW_OVERFLOW 4
 
 struct Ur5DevModel {
-  int nrd, nobj, nv, nq, nu, ngeom, npair, neq, ndg, iterations, ee_cbody, pad0;
+  int nrd, nobj, nv, nq, nu, ngeom, npair, neq, ndg, iterations, ee_cbody, nrg;
+  int rd_gslot[UR5_MAXRD], rg_body[UR5_MAXRG];   // contact-accumulator slot of a robot cbody (-1: it has no collision geom) and back
   // ---- robot weld groups (cbody d == dof d)
   int rd_parent[UR5_MAXRD];
   unsigned rd_anc[UR5_MAXRD];   // ancestors incl. self (bit e set: dof e moves cbody d)
   unsigned rd_desc[UR5_MAXRD];  // descendants incl. self
   int rd_limited[UR5_MAXRD];
   double rd_pos[UR5_MAXRD][3], rd_quat[UR5_MAXRD][4];  // weld-root frame in the parent cbody frame (world for the root)
+  double rd_mat[UR5_MAXRD][9];                         // rotation matrix of rd_quat
   double rd_jpos[UR5_MAXRD][3], rd_jaxis[UR5_MAXRD][3];
   double rd_mass[UR5_MAXRD], rd_ipos[UR5_MAXRD][3], rd_inertia[UR5_MAXRD][6];  // welded children folded in
   double rd_armature[UR5_MAXRD], rd_damping[UR5_MAXRD], rd_lo[UR5_MAXRD], rd_hi[UR5_MAXRD], rd_invweight[UR5_MAXRD], rd_qpos0[UR5_MAXRD];

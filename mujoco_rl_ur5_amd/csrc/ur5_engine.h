@@ -156,11 +156,15 @@ UR5_FN int sym6(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1
 template <class real, int NV_> struct Lds {
   static constexpr int NV = NV_;
   static constexpr int NBODY = UR5_MAXRD + (NV_ - UR5_MAXRD) / 6;   // cbodies of this instantiation
+  static constexpr int NSLOT = UR5_MAXRG + (NV_ - UR5_MAXRD) / 6;   // bodies that can carry contacts: robot weld groups with collision geoms + objects
   static constexpr int LD = NV_ + 1;                 // padded leading dimension of H (odd multiple of the bank width)
   real rec[UR5_REC_STRIDE];                          // persistent state, same layout as the HBM record
   // kinematics that the Newton phase still needs
   real bpos[NBODY][3], bmat[NBODY][9], cdof[UR5_MAXRD][6];
-  real Mr[UR5_MAXRD][UR5_MAXRD + 1], Lr[UR5_MAXRD][UR5_MAXRD + 1], Ld[UR5_MAXRD][UR5_MAXRD + 1];
+  real Mr[UR5_MAXRD][UR5_MAXRD + 1];
+#ifdef UR5_EMUL
+  real Lr[UR5_MAXRD][UR5_MAXRD + 1], Ld[UR5_MAXRD][UR5_MAXRD + 1];   // GPU build: the two factors live in registers (Fact)
+#endif
   real Mobj[6 * UR5_MAXOBJ];
 #ifdef UR5_EMUL
   static constexpr int HSIZE = NV_ * (NV_ + 1);      // unpacked staging, generic LDS Cholesky
@@ -173,7 +177,7 @@ template <class real, int NV_> struct Lds {
   // kinematic temporaries, body velocities and the moving geoms' poses are all recomputed by the next step.
   union {
     struct {
-      real jq[UR5_MAXRD][4], bquat[UR5_MAXRD][4], anchor[UR5_MAXRD][3], axis[UR5_MAXRD][3], cdd[UR5_MAXRD][6];
+      real anchor[UR5_MAXRD][3], axis[UR5_MAXRD][3], cdd[UR5_MAXRD][6];
       real cinert[UR5_MAXRD][10], buf[UR5_MAXRD][6], cfrc[UR5_MAXRD][6];
       real cvel[NBODY][6];                           // body twist velocity [rot; lin] about the body's reference point
       real dgpos[UR5_MAXDG][3], dgmat[UR5_MAXDG][9];
@@ -198,7 +202,7 @@ template <class real, int NV_> struct Lds {
   int sr_d1[UR5_MAXSR], sr_d2[UR5_MAXSR], sr_uni[UR5_MAXSR];
   real sr_c1[UR5_MAXSR], sr_c2[UR5_MAXSR], sr_D[UR5_MAXSR], sr_aref[UR5_MAXSR], sr_jar[UR5_MAXSR], sr_jv[UR5_MAXSR];
   // body accumulators (twist space)
-  real tw[NBODY][6], WB[NBODY][6], G[NBODY][21];
+  real tw[NSLOT][6], WB[NSLOT][6], G[NSLOT][21];   // indexed by slot_of(body)
 #if defined(UR5_PROFILE) && !defined(UR5_EMUL)
   double prof[PF_COUNT];
 #endif
@@ -226,6 +230,9 @@ template <class real, int NV_> struct Engine {
   UR5_FN real* pid_out() { return S.rec + UR5_REC_PIDOUT; }
   UR5_FN real* kp() { return S.rec + UR5_REC_KP; }
   UR5_FN int nb() const { return M.nrd + M.nobj; }
+  UR5_FN int nslot() const { return M.nrg + M.nobj; }
+  UR5_FN int slot_of(int b) const { return b < M.nrd ? M.rd_gslot[b] : M.nrg + (b - M.nrd); }
+  UR5_FN int body_of_slot(int sl) const { return sl < M.nrg ? M.rg_body[sl] : M.nrd + (sl - M.nrg); }
 
   UR5_FN void load(const double* rec, real dt, int con) {
     PAR(i, UR5_REC_STRIDE) S.rec[i] = (real)rec[i];
@@ -252,10 +259,29 @@ template <class real, int NV_> struct Engine {
 
   // ------------------------------------------------------------------ kinematics (mj_kinematics + mj_comPos [3P])
   UR5_BIG void kinematics() {
+    // ping-pong buffers of the pointer-jumping pass: ce / cde (contact images, dead until this step's constraint rows are
+    // built) hold the frames, cand (broad-phase list, rebuilt later) the ancestor links
+    static_assert(UR5_MAXCON * NB >= 12 * UR5_MAXRD && UR5_MAXCAND * sizeof(short) >= 2 * UR5_MAXRD * sizeof(int), "scratch aliasing");
+    real* const kbuf[2] = {&S.ce[0][0], &S.cde[0][0]};
+    int* const kanc = reinterpret_cast<int*>(S.cand);
+#define UR5_KR(bf, d) (kbuf[bf] + 9 * (d))
+#define UR5_KP(bf, d) (kbuf[bf] + 9 * UR5_MAXRD + 3 * (d))
+#define UR5_KA(bf, d) kanc[(bf) * UR5_MAXRD + (d)]
+    // robot tree: local transform of every weld group (parent frame -> own frame, joint rotation included) in parallel, then
+    // three rounds of pointer jumping compose them to world frames (tree depth <= 8) instead of walking the chain serially
     PAR(d, M.nrd) {
-      real a = (real)0.5 * (qpos()[d] - (real)M.rd_qpos0[d]);
-      real s = sin(a), c = cos(a);
-      S.jq[d][0] = c; S.jq[d][1] = (real)M.rd_jaxis[d][0] * s; S.jq[d][2] = (real)M.rd_jaxis[d][1] * s; S.jq[d][3] = (real)M.rd_jaxis[d][2] * s;
+      real a = qpos()[d] - (real)M.rd_qpos0[d];
+      real sn = sin(a), cs = cos(a), oc = (real)1 - cs;
+      v3 u(M.rd_jaxis[d]);
+      m3 Rq;   // Rodrigues
+      Rq.m[0] = cs + oc * u.x * u.x; Rq.m[1] = oc * u.x * u.y - sn * u.z; Rq.m[2] = oc * u.x * u.z + sn * u.y;
+      Rq.m[3] = oc * u.y * u.x + sn * u.z; Rq.m[4] = cs + oc * u.y * u.y; Rq.m[5] = oc * u.y * u.z - sn * u.x;
+      Rq.m[6] = oc * u.z * u.x - sn * u.y; Rq.m[7] = oc * u.z * u.y + sn * u.x; Rq.m[8] = cs + oc * u.z * u.z;
+      m3 R0; R0.load(M.rd_mat[d]);
+      v3 jp(M.rd_jpos[d]);
+      matmul(R0, Rq).store(UR5_KR(0, d));
+      (v3(M.rd_pos[d]) + mul(R0, jp - mul(Rq, jp))).store(UR5_KP(0, d));
+      UR5_KA(0, d) = M.rd_parent[d];
     }
     PAR(k, M.nobj) {
       int b = M.nrd + k, qa = M.nrd + 7 * k;
@@ -266,24 +292,33 @@ template <class real, int NV_> struct Engine {
       qmat(q).store(S.bmat[b]);
     }
     SYNC();
-    // the robot chain is sequential: every lane walks it redundantly (wave-uniform), results land in LDS
-    for (int d = 0; d < M.nrd; d++) {
-      int p = M.rd_parent[d];
-      v3 ppos;
-      q4 pq{1, 0, 0, 0};
-      if (p >= 0) { ppos = v3(S.bpos[p]); pq = q4{S.bquat[p][0], S.bquat[p][1], S.bquat[p][2], S.bquat[p][3]}; }
-      v3 pos = ppos + mul(qmat(pq), v3(M.rd_pos[d]));
-      q4 quat = qmul(pq, q4{(real)M.rd_quat[d][0], (real)M.rd_quat[d][1], (real)M.rd_quat[d][2], (real)M.rd_quat[d][3]});
-      m3 Rb = qmat(quat);
-      v3 anc = pos + mul(Rb, v3(M.rd_jpos[d]));
-      v3 ax = mul(Rb, v3(M.rd_jaxis[d]));
-      quat = qnormalize(qmul(quat, q4{S.jq[d][0], S.jq[d][1], S.jq[d][2], S.jq[d][3]}));
-      m3 R = qmat(quat);
-      pos = anc - mul(R, v3(M.rd_jpos[d]));
-      pos.store(S.bpos[d]); R.store(S.bmat[d]); anc.store(S.anchor[d]); ax.store(S.axis[d]);
-      S.bquat[d][0] = quat.w; S.bquat[d][1] = quat.x; S.bquat[d][2] = quat.y; S.bquat[d][3] = quat.z;
+    for (int round = 0; round < 3; round++) {
+      const int src = round & 1, dst = src ^ 1;
+      PAR(d, M.nrd) {
+        int a = UR5_KA(src, d);
+        m3 R; R.load(UR5_KR(src, d));
+        v3 p(UR5_KP(src, d));
+        if (a >= 0) {
+          m3 Ra; Ra.load(UR5_KR(src, a));
+          p = v3(UR5_KP(src, a)) + mul(Ra, p);
+          R = matmul(Ra, R);
+          a = UR5_KA(src, a);
+        }
+        R.store(UR5_KR(dst, d)); p.store(UR5_KP(dst, d)); UR5_KA(dst, d) = a;
+      }
       SYNC();
     }
+    PAR(d, M.nrd) {   // after three rounds buffer 1 holds the world frames
+      m3 R; R.load(UR5_KR(1, d));
+      v3 p(UR5_KP(1, d));
+      R.store(S.bmat[d]); p.store(S.bpos[d]);
+      (p + mul(R, v3(M.rd_jpos[d]))).store(S.anchor[d]);
+      mul(R, v3(M.rd_jaxis[d])).store(S.axis[d]);
+    }
+    SYNC();
+#undef UR5_KR
+#undef UR5_KP
+#undef UR5_KA
     v3 o(M.ref_point);
     PAR(d, M.nrd) {
       v3 ax(S.axis[d]);
@@ -331,7 +366,16 @@ template <class real, int NV_> struct Engine {
   }
 
   // ------------------------------------------------------------------ CRBA (robot block) + object diagonals + factors
-  UR5_BIG void crb_and_factor() {
+  // factors of Mr (lanes 0-7) and Mr + h B (lanes 8-15) kept in registers for the whole step (GPU build); the lane-emulation
+  // build keeps them in LDS (S.Lr / S.Ld) and leaves this empty
+  struct Fact {
+#ifndef UR5_EMUL
+    real r[UR5_MAXRD];
+    real inv;
+    int base, loc, size;
+#endif
+  };
+  UR5_BIG void crb_and_factor(Fact& fr) {
     PAR(d, M.nrd) {
       real crb[10];
       for (int i = 0; i < 10; i++) crb[i] = 0;
@@ -354,13 +398,13 @@ template <class real, int NV_> struct Engine {
     }
     SYNC();
     real h = (real)M.timestep;
+#ifdef UR5_EMUL
     PAR(idx, M.nrd * M.nrd) {
       int d = idx / M.nrd, e = idx % M.nrd;
       S.Lr[d][e] = S.Mr[d][e];
       S.Ld[d][e] = S.Mr[d][e] + (d == e ? h * (real)M.rd_damping[d] : (real)0);
     }
     SYNC();
-#ifdef UR5_EMUL
     cholesky(&S.Lr[0][0], M.nrd, UR5_MAXRD + 1);
     cholesky(&S.Ld[0][0], M.nrd, UR5_MAXRD + 1);
 #else
@@ -373,15 +417,13 @@ template <class real, int NV_> struct Engine {
       if (b.loc >= nrd) b.size = 0;
       if (b.size == 0) { b.base = lane; b.loc = 0; }
       real r[UR5_MAXRD];
-      real (*A)[UR5_MAXRD + 1] = lane < UR5_MAXRD ? S.Lr : S.Ld;
+      const real hb = (lane >= UR5_MAXRD && b.size > 0) ? h * (real)M.rd_damping[b.loc] : (real)0;
 #pragma unroll
-      for (int j = 0; j < UR5_MAXRD; j++) r[j] = (b.size > 0 && j <= b.loc) ? A[b.loc][j] : (real)0;
-      blk_cholesky(r, b);
-      if (b.size > 0) {
+      for (int j = 0; j < UR5_MAXRD; j++) r[j] = (b.size > 0 && j <= b.loc) ? S.Mr[b.loc][j] + (j == b.loc ? hb : (real)0) : (real)0;
+      fr.inv = blk_cholesky(r, b);
 #pragma unroll
-        for (int j = 0; j < UR5_MAXRD; j++) if (j <= b.loc) A[b.loc][j] = r[j];
-      }
-      SYNC();
+      for (int j = 0; j < UR5_MAXRD; j++) fr.r[j] = r[j];
+      fr.base = b.base; fr.loc = b.loc; fr.size = b.size;
     }
 #endif
   }
@@ -414,7 +456,7 @@ template <class real, int NV_> struct Engine {
     return myinv;
   }
   // x <- (L L^T)^-1 x for every block; lt = LDS scratch of 64 x 8 reals used to transpose the factors
-  static __device__ __forceinline__ real blk_solve(const real (&r)[UR5_MAXRD], real myinv, const Blk& b, real x, real* lt) {
+  static __device__ __forceinline__ real blk_solve(const real (&r)[UR5_MAXRD], real myinv, const Blk& b, real x, real* lt, int nl = 64) {
     const int lane = threadIdx.x;
 #pragma unroll
     for (int j = 0; j < UR5_MAXRD; j++) {
@@ -422,8 +464,10 @@ template <class real, int NV_> struct Engine {
       real yj = shfl_d(x * myinv, act ? b.base + j : lane);
       if (act) x = b.loc == j ? yj : (b.loc > j ? x - r[j] * yj : x);
     }
+    if (lane < nl) {
 #pragma unroll
-    for (int j = 0; j < UR5_MAXRD; j++) lt[lane * UR5_MAXRD + j] = r[j];
+      for (int j = 0; j < UR5_MAXRD; j++) lt[lane * UR5_MAXRD + j] = r[j];
+    }
     __syncthreads();
     real t[UR5_MAXRD];
 #pragma unroll
@@ -481,7 +525,7 @@ template <class real, int NV_> struct Engine {
   }
 
   // ------------------------------------------------------------------ velocity stage: body twists, bias, passive (mj_comVel + mj_rne)
-  UR5_BIG void velocity_stage() {
+  UR5_BIG void velocity_stage(const Fact& fr) {
     PAR(b, M.nrd) {
       real v[6] = {0, 0, 0, 0, 0, 0};
       for (int e = 0; e < M.nrd; e++) if (M.rd_anc[b] >> e & 1u) { real q = qvel()[e]; for (int i = 0; i < 6; i++) v[i] += S.cdof[e][i] * q; }
@@ -531,7 +575,17 @@ template <class real, int NV_> struct Engine {
     SYNC();
     PAR(i, M.nv) S.as[i] = i < M.nrd ? S.fs[i] : S.fs[i] / S.Mobj[i - M.nrd];
     SYNC();
+#ifdef UR5_EMUL
     chol_solve(&S.Lr[0][0], M.nrd, UR5_MAXRD + 1, S.as);
+#else
+    {   // qacc_smooth of the robot: lanes 0-7 hold the rows of chol(Mr); S.x..S.Mv are free until the Newton solve (scratch)
+      Blk b; b.base = fr.base; b.loc = fr.loc; b.size = fr.size;
+      real rhs = UR5_LANE < M.nrd ? S.as[UR5_LANE] : (real)0;
+      real xs = blk_solve(fr.r, fr.inv, b, rhs, S.x, 2 * UR5_MAXRD);
+      if (UR5_LANE < M.nrd) S.as[UR5_LANE] = xs;
+      SYNC();
+    }
+#endif
   }
 
   // ------------------------------------------------------------------ collision
@@ -1087,23 +1141,24 @@ template <class real, int NV_> struct Engine {
   UR5_FN real row_mu(int c, int k) const { return k <= 2 ? S.cfri[c][0] : (k == 3 ? S.cfri[c][1] : S.cfri[c][NB > 4 ? 2 : 1]); }
   // twists of every body for a dof-space vector, then base images (with or without the aref offsets)
   UR5_CALL void images(const real* vec, bool offset, real (*out)[NB], real* srout) {
-    PAR(b, nb()) {
+    PAR(sl, nslot()) {
+      const int b = body_of_slot(sl);
       if (b < M.nrd) {
         real v[6] = {0, 0, 0, 0, 0, 0};
         for (int e = 0; e < M.nrd; e++) if (M.rd_anc[b] >> e & 1u) { real q = vec[e]; for (int i = 0; i < 6; i++) v[i] += S.cdof[e][i] * q; }
-        for (int i = 0; i < 6; i++) S.tw[b][i] = v[i];
+        for (int i = 0; i < 6; i++) S.tw[sl][i] = v[i];
       } else {
         int va = M.nrd + 6 * (b - M.nrd);
         m3 R; R.load(S.bmat[b]);
-        mul(R, v3(vec[va + 3], vec[va + 4], vec[va + 5])).store(S.tw[b]);
-        v3(vec[va], vec[va + 1], vec[va + 2]).store(S.tw[b] + 3);
+        mul(R, v3(vec[va + 3], vec[va + 4], vec[va + 5])).store(S.tw[sl]);
+        v3(vec[va], vec[va + 1], vec[va + 2]).store(S.tw[sl] + 3);
       }
     }
     SYNC();
     PAR(c, S.ncon) {
       bool hasA = S.cA[c] >= 0, hasB = S.cB[c] >= 0;
       real e[NB];
-      contact_image(c, hasA ? S.tw[S.cA[c]] : S.tw[0], hasB ? S.tw[S.cB[c]] : S.tw[0], hasA, hasB, e);
+      contact_image(c, hasA ? S.tw[slot_of(S.cA[c])] : S.tw[0], hasB ? S.tw[slot_of(S.cB[c])] : S.tw[0], hasA, hasB, e);
       if (offset) for (int k = 0; k < NB; k++) e[k] += S.ceoff[c][k];
       for (int k = 0; k < NB; k++) out[c][k] = e[k];
     }
@@ -1199,7 +1254,7 @@ template <class real, int NV_> struct Engine {
     const int nbod = nb();
     // per-body wrench (gradient) and 6x6 twist-space Hessian accumulators: every contact lane scatters its two sides with
     // LDS float atomics (ds_add_f64). Only this wavefront touches these words, so the sums are reproducible run to run.
-    PAR(idx, nbod * 27) { int b = idx / 27, ent = idx % 27; if (ent < 6) S.WB[b][ent] = 0; else S.G[b][ent - 6] = 0; }
+    PAR(idx, nslot() * 27) { int b = idx / 27, ent = idx % 27; if (ent < 6) S.WB[b][ent] = 0; else S.G[b][ent - 6] = 0; }
     SYNC();
     PAR(c, S.ncon) {
       v3 ax[3] = {v3(S.cframe[c]), v3(S.cframe[c] + 3), cross(v3(S.cframe[c]), v3(S.cframe[c] + 3))};
@@ -1217,8 +1272,9 @@ template <class real, int NV_> struct Engine {
         real sg = side == 0 ? (real)-1 : (real)1;
         v3 r = v3(S.cpos[c]) - body_ref(b);
         v3 Mo = cross(r, F) + T;
-        UR5_ATOMIC_ADD(&S.WB[b][0], sg * Mo.x); UR5_ATOMIC_ADD(&S.WB[b][1], sg * Mo.y); UR5_ATOMIC_ADD(&S.WB[b][2], sg * Mo.z);
-        UR5_ATOMIC_ADD(&S.WB[b][3], sg * F.x); UR5_ATOMIC_ADD(&S.WB[b][4], sg * F.y); UR5_ATOMIC_ADD(&S.WB[b][5], sg * F.z);
+        const int sl = slot_of(b);
+        UR5_ATOMIC_ADD(&S.WB[sl][0], sg * Mo.x); UR5_ATOMIC_ADD(&S.WB[sl][1], sg * Mo.y); UR5_ATOMIC_ADD(&S.WB[sl][2], sg * Mo.z);
+        UR5_ATOMIC_ADD(&S.WB[sl][3], sg * F.x); UR5_ATOMIC_ADD(&S.WB[sl][4], sg * F.y); UR5_ATOMIC_ADD(&S.WB[sl][5], sg * F.z);
         // F_k (6-vector [rot; lin]): k<3 -> [r x a_k ; a_k], k>=3 -> [a_{k-3} ; 0];  G += sum_kl W_kl F_k F_l^T (arrow-shaped W)
         real Fk[NB][6];
         for (int k = 0; k < 3; k++) {
@@ -1231,7 +1287,7 @@ template <class real, int NV_> struct Engine {
           for (int gj = 0; gj <= gi; gj++, ent++) {
             real v = w[0] * Fk[0][gi] * Fk[0][gj];
             for (int k = 1; k < NB; k++) v += w[k] * (Fk[0][gi] * Fk[k][gj] + Fk[k][gi] * Fk[0][gj]) + w[NB - 1 + k] * Fk[k][gi] * Fk[k][gj];
-            if (v != 0) UR5_ATOMIC_ADD(&S.G[b][ent], v);
+            if (v != 0) UR5_ATOMIC_ADD(&S.G[sl][ent], v);
           }
       }
     }
@@ -1240,11 +1296,12 @@ template <class real, int NV_> struct Engine {
     PAR(i, M.nv) {
       real jf = 0;
       if (i < M.nrd) {
-        for (int b = 0; b < M.nrd; b++) if (M.rd_desc[i] >> b & 1u) for (int k = 0; k < 6; k++) jf += S.cdof[i][k] * S.WB[b][k];
+        for (int rg = 0; rg < M.nrg; rg++) if (M.rd_desc[i] >> M.rg_body[rg] & 1u) for (int k = 0; k < 6; k++) jf += S.cdof[i][k] * S.WB[rg][k];
       } else {
         int k = (i - M.nrd) / 6, j = (i - M.nrd) % 6, b = M.nrd + k;
-        if (j < 3) jf = S.WB[b][3 + j];
-        else { m3 R; R.load(S.bmat[b]); jf = dot(R.col(j - 3), v3(S.WB[b])); }
+        const int sl = M.nrg + k;
+        if (j < 3) jf = S.WB[sl][3 + j];
+        else { m3 R; R.load(S.bmat[b]); jf = dot(R.col(j - 3), v3(S.WB[sl])); }
       }
       for (int s = 0; s < S.nsr; s++) {
         real r = S.sr_jar[s];
@@ -1269,11 +1326,12 @@ template <class real, int NV_> struct Engine {
       if (e > d) continue;
       real v = S.Mr[d][e];
       unsigned common = M.rd_desc[d] & M.rd_desc[e];
-      for (int b = 0; b < M.nrd; b++) {
+      for (int rg = 0; rg < M.nrg; rg++) {
+        const int b = M.rg_body[rg];
         if (!(common >> b & 1u) || !(S.bodymask >> b & 1u)) continue;
         for (int i = 0; i < 6; i++) {
           real t = 0;
-          for (int j = 0; j < 6; j++) t += S.G[b][sym6(i, j)] * S.cdof[e][j];
+          for (int j = 0; j < 6; j++) t += S.G[rg][sym6(i, j)] * S.cdof[e][j];
           v += S.cdof[d][i] * t;
         }
       }
@@ -1296,7 +1354,7 @@ template <class real, int NV_> struct Engine {
       if (i < 3) ti[3 + i] = 1; else { v3 cI = R.col(i - 3); ti[0] = cI.x; ti[1] = cI.y; ti[2] = cI.z; }
       if (j < 3) tj[3 + j] = 1; else { v3 cJ = R.col(j - 3); tj[0] = cJ.x; tj[1] = cJ.y; tj[2] = cJ.z; }
       real v = 0;
-      for (int a = 0; a < 6; a++) { real t = 0; for (int bb = 0; bb < 6; bb++) t += S.G[b][sym6(a, bb)] * tj[bb]; v += ti[a] * t; }
+      for (int a = 0; a < 6; a++) { real t = 0; for (int bb = 0; bb < 6; bb++) t += S.G[M.nrg + k][sym6(a, bb)] * tj[bb]; v += ti[a] * t; }
       int di = M.nrd + 6 * k + i, dj = M.nrd + 6 * k + j;
       if (i == j) {
         v += S.Mobj[6 * k + i];
@@ -1341,6 +1399,7 @@ template <class real, int NV_> struct Engine {
   // straight into registers (robot row d: Mr + sum_b cdof_d^T G_b cdof_e + equality/limit rows; object row: M + T^T G T)
   // and the block-parallel Cholesky / solves above produce S.search = -H^-1 grad without any Hessian in LDS.
   __device__ __forceinline__ void newton_blockdiag() {
+    PROF_T0();
     const int lane = UR5_LANE, nv = M.nv;
     Blk b;
     real r[UR5_MAXRD];
@@ -1351,11 +1410,12 @@ template <class real, int NV_> struct Engine {
       const int d = lane;
 #pragma unroll
       for (int e = 0; e < UR5_MAXRD; e++) if (e <= d) r[e] = S.Mr[d][e];
-      for (int bb = 0; bb < UR5_MAXRD; bb++) {
+      for (int rg = 0; rg < M.nrg; rg++) {
+        const int bb = M.rg_body[rg];
         if (!(M.rd_desc[d] >> bb & 1u) || !(S.bodymask >> bb & 1u)) continue;
         real t[6];
 #pragma unroll
-        for (int i = 0; i < 6; i++) { real a = 0; for (int j = 0; j < 6; j++) a += S.G[bb][sym6(i, j)] * S.cdof[d][j]; t[i] = a; }
+        for (int i = 0; i < 6; i++) { real a = 0; for (int j = 0; j < 6; j++) a += S.G[rg][sym6(i, j)] * S.cdof[d][j]; t[i] = a; }
 #pragma unroll
         for (int e = 0; e < UR5_MAXRD; e++)
           if (e <= d && (M.rd_desc[e] >> bb & 1u)) { real a = 0; for (int i = 0; i < 6; i++) a += S.cdof[e][i] * t[i]; r[e] += a; }
@@ -1378,7 +1438,7 @@ template <class real, int NV_> struct Engine {
       if (loc < 3) ti[3 + loc] = 1; else { v3 c = R.col(loc - 3); ti[0] = c.x; ti[1] = c.y; ti[2] = c.z; }
       real t[6];
 #pragma unroll
-      for (int i = 0; i < 6; i++) { real a = 0; for (int j = 0; j < 6; j++) a += S.G[body][sym6(i, j)] * ti[j]; t[i] = a; }
+      for (int i = 0; i < 6; i++) { real a = 0; for (int j = 0; j < 6; j++) a += S.G[M.nrg + k][sym6(i, j)] * ti[j]; t[i] = a; }
 #pragma unroll
       for (int j = 0; j < 6; j++) {
         if (j > loc) continue;
@@ -1392,6 +1452,7 @@ template <class real, int NV_> struct Engine {
     } else { b.base = lane; b.loc = 0; b.size = 0; }
     real g = lane < nv ? S.grad[lane] : (real)0;
     __syncthreads();   // every lane has read G / grad; H (aliased scratch) may be overwritten now
+    PROF(PF_CHOL);     // profile builds: row assembly is booked under "chol", factor + solves under "solve"
     real myinv = blk_cholesky(r, b);
     real x = blk_solve(r, myinv, b, g, S.H);
     if (lane < nv) S.search[lane] = -x;
@@ -1559,14 +1620,26 @@ template <class real, int NV_> struct Engine {
   }
 
   // ------------------------------------------------------------------ mj_Euler with implicit joint damping, then the clock [3P, C.5]
-  UR5_BIG void integrate() {
+  UR5_BIG void integrate(const Fact& fr) {
     const real h = (real)M.timestep;
     PAR(i, M.nv) {
       warm()[i] = S.x[i];
       if (i < M.nrd) { real s = 0; for (int e = 0; e < M.nrd; e++) s += S.Mr[i][e] * S.x[e]; S.tmpv[i] = s; }
     }
     SYNC();
+#ifdef UR5_EMUL
     chol_solve(&S.Ld[0][0], M.nrd, UR5_MAXRD + 1, S.tmpv);
+#else
+    {   // (Mr + h B) qacc' = Mr qacc: lanes 8-15 hold the rows of chol(Mr + h B); S.Ma..S.Mv are dead after the solve (scratch)
+      Blk b; b.base = fr.base; b.loc = fr.loc; b.size = fr.size;
+      const int l8 = UR5_LANE - UR5_MAXRD;
+      real rhs = (l8 >= 0 && l8 < M.nrd) ? S.tmpv[l8] : (real)0;
+      real xs = blk_solve(fr.r, fr.inv, b, rhs, S.Ma, 2 * UR5_MAXRD);
+      SYNC();
+      if (l8 >= 0 && l8 < M.nrd) S.tmpv[l8] = xs;
+      SYNC();
+    }
+#endif
     PAR(i, M.nv) {
       if (i < M.nrd) { qvel()[i] += h * S.tmpv[i]; qpos()[i] += h * qvel()[i]; }
       else {
@@ -1595,20 +1668,21 @@ template <class real, int NV_> struct Engine {
     SYNC();
   }
 
-  UR5_FN void forward() {
+  UR5_FN void forward(Fact& fr) {
     PROF_T0();
     kinematics(); PROF(PF_KIN);
-    crb_and_factor(); PROF(PF_CRB);
-    velocity_stage(); PROF(PF_VEL);
+    crb_and_factor(fr); PROF(PF_CRB);
+    velocity_stage(fr); PROF(PF_VEL);
     collision();
     PROF_RE();
     make_constraints(); PROF(PF_ROWS);
     solve_newton();
   }
   UR5_BIG void step() {  // sim.step(), MujocoController.py:379
-    forward();
+    Fact fr;
+    forward(fr);
     PROF_T0();
-    integrate(); PROF(PF_INTEGRATE);
+    integrate(fr); PROF(PF_INTEGRATE);
     if (UR5_LANE == 0) S.total_steps++;
   }
 
@@ -1839,7 +1913,8 @@ template <class real, int NV_> struct Engine {
         PROF(PF_IK);
       }
       if (pr.repeat == -2) {
-        forward();
+        Fact fr0;
+        forward(fr0);
         if (P.debug) dump(P.debug + (size_t)UR5_DEBUG_STRIDE * env);
       } else if (!ikfail && pr.repeat != 0) {
         const bool raw = pr.repeat < 0;

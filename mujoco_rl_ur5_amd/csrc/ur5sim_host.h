@@ -137,6 +137,7 @@ static int build_model(const void* data, size_t nbytes, int ee_body, Ur5DevModel
     Xf x = rel_to(b, pb > 0 ? pb : 0);
     memcpy(D.rd_pos[d], x.p, 24);
     memcpy(D.rd_quat[d], x.q, 32);
+    qmat(x.q, D.rd_mat[d]);
     int j = body_jntadr[b];
     memcpy(D.rd_jpos[d], jnt_pos + 3 * j, 24);
     memcpy(D.rd_jaxis[d], jnt_axis + 3 * j, 24);
@@ -286,6 +287,12 @@ static int build_model(const void* data, size_t nbytes, int ee_body, Ur5DevModel
     }
   }
   D.ngeom = ng; D.ndg = ndg;
+  D.nrg = 0;
+  for (int d = 0; d < nrd; d++) D.rd_gslot[d] = -1;
+  for (int k = 0; k < ng; k++) if (D.g_kind[k] == UR5_KIND_ROBOT && D.rd_gslot[D.g_owner[k]] < 0) {
+    if (D.nrg >= UR5_MAXRG) return fail(UR5_ERR_MODEL, "more than 4 robot weld groups carry collision geoms");
+    D.rd_gslot[D.g_owner[k]] = D.nrg; D.rg_body[D.nrg++] = D.g_owner[k];
+  }
   int np = 0;
   for (int p = 0; p < npair; p++) {
     int a = dev_of_geom[pair1[p]], b = dev_of_geom[pair2[p]];
