@@ -36,26 +36,45 @@ def aimed_actions(qpos, first_id, round_idx, nobj=4):
     return a
 
 
-def cpu_baseline(model, budget_s=12.0):
-    """The fp64 oracle (a port: the reference's own MuJoCo binary cannot exist here) on ONE host core, same scenes/actions."""
+def cpu_baseline(model, budget_s=10.0):
+    """The fp64 oracle (a port: the reference's own MuJoCo binary cannot exist here) on the host cores, same scenes/actions:
+    one scene per thread on every core (SURVEY.md section 8d ii; ctypes releases the GIL), plus the single-core rate."""
+    import threading
     from oracle.oracle import Oracle
-    t_used, steps, attempts = 0.0, 0, 0
-    g = 0
-    while t_used < budget_s:
-        o = Oracle(model)
-        o.reset(20 + g, 1, True)
-        a = aimed_actions(o.get_state()["qpos"][None, :], g, 0)[0]
-        n0 = o.total_steps
+
+    def worker(ids, deadline, out):
+        steps = attempts = 0
+        for g in ids:
+            if time.perf_counter() >= deadline:
+                break
+            o = Oracle(model)
+            o.reset(20 + g, 1, True)
+            a = aimed_actions(o.get_state()["qpos"][None, :], g, 0)[0]
+            o.grasp_attempt(a[:3], int(a[3]), 1)
+            steps += o.total_steps                      # reset settling (500 steps) + the attempt: all are timed
+            attempts += 1
+        out.append((steps, attempts))
+
+    def run(nthreads, budget):
+        out, threads = [], []
         t0 = time.perf_counter()
-        o.grasp_attempt(a[:3], int(a[3]), 1)
-        t_used += time.perf_counter() - t0
-        steps += o.total_steps - n0
-        attempts += 1
-        g += 1
-    return dict(value=steps / t_used, unit="env-steps/s", cores=1, kind="port",
-                sample=f"{attempts} IT1 grasp attempts ({steps} physics steps) of scenes 0..{attempts - 1}, oracle/ur5_oracle.cpp, "
-                       f"{t_used:.1f} s on one core of {os.cpu_count()}",
-                grasp_attempts_per_s=attempts / t_used)
+        for t in range(nthreads):
+            th = threading.Thread(target=worker, args=(range(t, 1 << 20, nthreads), t0 + budget, out))
+            th.start()
+            threads.append(th)
+        for th in threads:
+            th.join()
+        dt = time.perf_counter() - t0
+        return sum(o[0] for o in out), sum(o[1] for o in out), dt
+
+    cores = os.cpu_count() or 1
+    s1, a1, t1 = run(1, 0.4 * budget_s)
+    sn, an, tn = run(cores, 0.6 * budget_s)
+    return dict(value=sn / tn, unit="env-steps/s", cores=cores, kind="port",
+                sample=f"{an} IT1 grasp attempts ({sn} physics steps incl. each scene's reset settling) "
+                       f"of scenes 0..{an - 1}, oracle/ur5_oracle.cpp, one scene per thread on {cores} threads for {tn:.1f} s wall",
+                grasp_attempts_per_s=an / tn,
+                single_core={"value": s1 / t1, "grasp_attempts_per_s": a1 / t1, "sample": f"{a1} attempts, {t1:.1f} s on one core"})
 
 
 def main():
@@ -136,12 +155,12 @@ def main():
         achieved = steps_local * bytes_per_step / k_s / 1e9
         # measured HBM bytes per env-step from the rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this same command (profiles/)
         traffic, traffic_src = None, None
-        tp = os.path.join(ROOT, "profiles", "r01_e_hbm_traffic.json")
+        tp = os.path.join(ROOT, "profiles", "r01_g_hbm_traffic.json")
         if os.path.exists(tp):
             with open(tp) as f:
                 tj = json.load(f)
             traffic = tj["hbm_bytes_per_env_step"] * steps_local / args.steps
-            traffic_src = "profiles/r01_e_hbm_traffic.json: (FETCH_SIZE + WRITE_SIZE) per env-step x env-steps of an average timed launch"
+            traffic_src = "profiles/r01_g_hbm_traffic.json: (FETCH_SIZE + WRITE_SIZE) per env-step x env-steps of an average timed launch"
         out = {
             "metric": "env-steps/sec (+ grasp-attempts/sec), 4096 parallel UR5 scenes per MI355X",
             "value": steps_all / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -29,6 +29,8 @@
 #define UR5_BIG inline
 #define UR5_CALL inline
 #define UR5_ATOMIC_ADD(p, v) (*(p) += (v))
+#define UR5_MPR_ATTR inline
+#define UR5_BOXBOX_ATTR inline
 static void* ur5_emul_lds = nullptr;
 static const Ur5DevModel* ur5_emul_model = nullptr;
 #define UR5_LDS_PTR(T) (static_cast<T*>(ur5_emul_lds))
@@ -44,6 +46,12 @@ static const Ur5DevModel* ur5_emul_model = nullptr;
 #define UR5_BIG __device__ __forceinline__  // phase routines: the interpreter in run() calls each of them from one place
 #define UR5_CALL __device__ __noinline__    // small helpers with many call sites: kept as real functions
 #define UR5_ATOMIC_ADD(p, v) __hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#ifndef UR5_MPR_ATTR
+#define UR5_MPR_ATTR UR5_BIG
+#endif
+#ifndef UR5_BOXBOX_ATTR
+#define UR5_BOXBOX_ATTR UR5_BIG
+#endif
 // The scene lives in dynamic LDS and the model in constant memory, both reached through these file-scope symbols so that
 // every (non-inlined) phase routine addresses them with ds_* / s_load instead of flat instructions.
 extern __shared__ __attribute__((aligned(16))) double ur5_smem[];
@@ -126,8 +134,14 @@ template <class T> struct M3 {  // row-major
   UR5_FN V3<T> row(int i) const {
     return V3<T>(i == 0 ? m[0] : (i == 1 ? m[3] : m[6]), i == 0 ? m[1] : (i == 1 ? m[4] : m[7]), i == 0 ? m[2] : (i == 1 ? m[5] : m[8]));
   }
-  template <class U> UR5_FN void load(const U* p) { for (int i = 0; i < 9; i++) m[i] = (T)p[i]; }
-  template <class U> UR5_FN void store(U* p) const { for (int i = 0; i < 9; i++) p[i] = m[i]; }
+  // explicit element lists: in this very large kernel a counted loop over m[] is not always unrolled, and a run-time index
+  // would move the whole matrix to scratch memory
+  template <class U> UR5_FN void load(const U* p) {
+    m[0] = (T)p[0]; m[1] = (T)p[1]; m[2] = (T)p[2]; m[3] = (T)p[3]; m[4] = (T)p[4]; m[5] = (T)p[5]; m[6] = (T)p[6]; m[7] = (T)p[7]; m[8] = (T)p[8];
+  }
+  template <class U> UR5_FN void store(U* p) const {
+    p[0] = m[0]; p[1] = m[1]; p[2] = m[2]; p[3] = m[3]; p[4] = m[4]; p[5] = m[5]; p[6] = m[6]; p[7] = m[7]; p[8] = m[8];
+  }
 };
 template <class T> UR5_FN M3<T> qmat(Q4<T> q) {
   T w = q.w, x = q.x, y = q.y, z = q.z;
@@ -141,8 +155,9 @@ template <class T> UR5_FN V3<T> mul(const M3<T>& a, V3<T> v) { return V3<T>(dot(
 template <class T> UR5_FN V3<T> mulT(const M3<T>& a, V3<T> v) { return V3<T>(dot(a.col(0), v), dot(a.col(1), v), dot(a.col(2), v)); }
 template <class T> UR5_FN M3<T> matmul(const M3<T>& a, const M3<T>& b) {
   M3<T> r;
-  for (int i = 0; i < 3; i++)
-    for (int j = 0; j < 3; j++) r.m[3 * i + j] = a.m[3 * i] * b.m[j] + a.m[3 * i + 1] * b.m[3 + j] + a.m[3 * i + 2] * b.m[6 + j];
+#define UR5_MM(i, j) r.m[3 * i + j] = a.m[3 * i] * b.m[j] + a.m[3 * i + 1] * b.m[3 + j] + a.m[3 * i + 2] * b.m[6 + j]
+  UR5_MM(0, 0); UR5_MM(0, 1); UR5_MM(0, 2); UR5_MM(1, 0); UR5_MM(1, 1); UR5_MM(1, 2); UR5_MM(2, 0); UR5_MM(2, 1); UR5_MM(2, 2);
+#undef UR5_MM
   return r;
 }
 template <class T> UR5_FN T clampv(T v, T lo, T hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -331,7 +346,7 @@ template <class real, int NV_> struct Engine {
       Ib.m[0] = (real)bi[0]; Ib.m[4] = (real)bi[1]; Ib.m[8] = (real)bi[2];
       Ib.m[1] = Ib.m[3] = (real)bi[3]; Ib.m[2] = Ib.m[6] = (real)bi[4]; Ib.m[5] = Ib.m[7] = (real)bi[5];
       m3 Rt;
-      for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Rt.m[3 * i + j] = R.m[3 * j + i];
+      Rt.m[0] = R.m[0]; Rt.m[1] = R.m[3]; Rt.m[2] = R.m[6]; Rt.m[3] = R.m[1]; Rt.m[4] = R.m[4]; Rt.m[5] = R.m[7]; Rt.m[6] = R.m[2]; Rt.m[7] = R.m[5]; Rt.m[8] = R.m[8];
       m3 Iw = matmul(matmul(R, Ib), Rt);
       real m = (real)M.rd_mass[d];
       v3 c = v3(S.bpos[d]) + mul(R, v3(M.rd_ipos[d])) - o;
@@ -640,7 +655,7 @@ template <class real, int NV_> struct Engine {
     return r;
   }
   // Minkowski portal refinement; same scheme, tolerances and result definition as oracle mpr_penetration()
-  UR5_BIG bool mpr(const Shape& A, const Shape& B, real* depth, v3* dir_out, v3* pos_out) const {
+  UR5_MPR_ATTR bool mpr(const Shape& A, const Shape& B, real* depth, v3* dir_out, v3* pos_out) const {
     const real tol = (real)1e-6;
     const int maxit = 50;
     MV v0, v1, v2, v3_, v4;
@@ -707,7 +722,7 @@ template <class real, int NV_> struct Engine {
   // the one expensive routine, MPR, produces a single contact that is kept in registers between the two passes.
   struct Sink { int mode, slot, n, g1, g2; };
   struct Single { bool hit; v3 pos, normal; real dist; int sat_code; bool sat_flip; real sat_best; };
-  UR5_CALL void emit(Sink& k, v3 pos, v3 normal, real dist) const {
+  UR5_FN void emit(Sink& k, v3 pos, v3 normal, real dist) const {
     // one pass: a slot is claimed with an LDS atomic counter. Only this wavefront touches the counter, so the order is
     // reproducible (it differs from the oracle's pair order, which only permutes floating-point sums downstream).
 #ifdef UR5_EMUL
@@ -774,7 +789,7 @@ template <class real, int NV_> struct Engine {
   // face) enumerated directly -- incident corners inside the reference rectangle, reference corners inside the incident
   // rectangle, edge/edge crossings -- the vertex set Sutherland-Hodgman clipping (oracle collide_box_box) produces, without
   // its run-time-indexed polygon arrays.
-  UR5_BIG void box_box(const GeomPose& A, v3 a, const GeomPose& B, v3 b, real margin, Sink& out, Sat& sat) const {
+  UR5_BOXBOX_ATTR void box_box(const GeomPose& A, v3 a, const GeomPose& B, v3 b, real margin, Sink& out, Sat& sat) const {
     if (out.mode == 0) { if (!box_sat(A, a, B, b, margin, sat)) { sat.code = -1; return; } }
     if (sat.code < 0) return;
     const int code = sat.code;
@@ -1010,6 +1025,10 @@ template <class real, int NV_> struct Engine {
   }
 
   // ------------------------------------------------------------------ constraint rows (mj_makeConstraint + mj_makeImpedance [3P])
+  // x^p of the impedance sigmoid: p = 2 (MuJoCo's default solimp) is a product; the general pow() is large, so it is kept
+  // out of line instead of being expanded at each of the eight places an impedance is evaluated
+  UR5_CALL static real pow_any(real x, real p) { return pow(x, p); }
+  UR5_FN static real powr(real x, real p) { return p == (real)2 ? x * x : pow_any(x, p); }
   UR5_FN static real impedance(const double* solimp, real x_abs) {
     real dmin = clampv((real)solimp[0], (real)0.0001, (real)0.9999), dmax = clampv((real)solimp[1], (real)0.0001, (real)0.9999);
     real width = (real)solimp[2], mid = (real)solimp[3], power = (real)solimp[4];
@@ -1019,8 +1038,8 @@ template <class real, int NV_> struct Engine {
     if (x <= 0) return dmin;
     real y;
     if (power == 1) y = x;
-    else if (x <= mid) y = pow(x / mid, power) * mid;
-    else y = 1 - pow((1 - x) / (1 - mid), power) * (1 - mid);
+    else if (x <= mid) y = powr(x / mid, power) * mid;
+    else y = 1 - powr((1 - x) / (1 - mid), power) * (1 - mid);
     return dmin + y * (dmax - dmin);
   }
   UR5_FN void kbi(const double* solref, const double* solimp, real imp, real* K, real* B) const {
@@ -1228,12 +1247,15 @@ template <class real, int NV_> struct Engine {
   }
   // unit twist [rot; lin] of dof-local index i of cbody b (zero when the dof does not move the body)
   UR5_FN bool unit_twist(int b, int i, real* tw) const {
-    for (int k = 0; k < 6; k++) tw[k] = 0;
     if (b < M.nrd) {
-      if (!(M.rd_anc[b] >> i & 1u)) return false;
-      for (int k = 0; k < 6; k++) tw[k] = S.cdof[i][k];
-    } else if (i < 3) tw[3 + i] = 1;
-    else { m3 R; R.load(S.bmat[b]); v3 cc = R.col(i - 3); tw[0] = cc.x; tw[1] = cc.y; tw[2] = cc.z; }
+      if (!(M.rd_anc[b] >> i & 1u)) { tw[0] = tw[1] = tw[2] = tw[3] = tw[4] = tw[5] = 0; return false; }
+      tw[0] = S.cdof[i][0]; tw[1] = S.cdof[i][1]; tw[2] = S.cdof[i][2]; tw[3] = S.cdof[i][3]; tw[4] = S.cdof[i][4]; tw[5] = S.cdof[i][5];
+    } else {
+      m3 R; R.load(S.bmat[b]);
+      v3 cc = R.col(i < 3 ? 0 : i - 3);
+      tw[0] = i < 3 ? (real)0 : cc.x; tw[1] = i < 3 ? (real)0 : cc.y; tw[2] = i < 3 ? (real)0 : cc.z;
+      tw[3] = i == 0 ? (real)1 : (real)0; tw[4] = i == 1 ? (real)1 : (real)0; tw[5] = i == 2 ? (real)1 : (real)0;
+    }
     return true;
   }
   // (J e_ia)^T W (J e_ib) for side-A dof ia and side-B dof ib of contact c
@@ -1350,9 +1372,14 @@ template <class real, int NV_> struct Engine {
       int j = ent - i * (i + 1) / 2;  // dof-local indices, i >= j; 0-2 lin, 3-5 rot
       m3 R; R.load(S.bmat[b]);
       // twist per unit dof: lin j -> [0; e_j], rot j -> [R col_j; 0]
-      real ti[6] = {0, 0, 0, 0, 0, 0}, tj[6] = {0, 0, 0, 0, 0, 0};
-      if (i < 3) ti[3 + i] = 1; else { v3 cI = R.col(i - 3); ti[0] = cI.x; ti[1] = cI.y; ti[2] = cI.z; }
-      if (j < 3) tj[3 + j] = 1; else { v3 cJ = R.col(j - 3); tj[0] = cJ.x; tj[1] = cJ.y; tj[2] = cJ.z; }
+      real ti[6], tj[6];
+      {
+        v3 cI = R.col(i < 3 ? 0 : i - 3), cJ = R.col(j < 3 ? 0 : j - 3);
+        ti[0] = i < 3 ? (real)0 : cI.x; ti[1] = i < 3 ? (real)0 : cI.y; ti[2] = i < 3 ? (real)0 : cI.z;
+        ti[3] = i == 0 ? (real)1 : (real)0; ti[4] = i == 1 ? (real)1 : (real)0; ti[5] = i == 2 ? (real)1 : (real)0;
+        tj[0] = j < 3 ? (real)0 : cJ.x; tj[1] = j < 3 ? (real)0 : cJ.y; tj[2] = j < 3 ? (real)0 : cJ.z;
+        tj[3] = j == 0 ? (real)1 : (real)0; tj[4] = j == 1 ? (real)1 : (real)0; tj[5] = j == 2 ? (real)1 : (real)0;
+      }
       real v = 0;
       for (int a = 0; a < 6; a++) { real t = 0; for (int bb = 0; bb < 6; bb++) t += S.G[M.nrg + k][sym6(a, bb)] * tj[bb]; v += ti[a] * t; }
       int di = M.nrd + 6 * k + i, dj = M.nrd + 6 * k + j;
@@ -1434,8 +1461,12 @@ template <class real, int NV_> struct Engine {
       const int k = (lane - UR5_MAXRD) / 6, loc = (lane - UR5_MAXRD) % 6, body = UR5_MAXRD + k;
       b.base = UR5_MAXRD + 6 * k; b.loc = loc; b.size = 6;
       m3 R; R.load(S.bmat[body]);
-      real ti[6] = {0, 0, 0, 0, 0, 0};
-      if (loc < 3) ti[3 + loc] = 1; else { v3 c = R.col(loc - 3); ti[0] = c.x; ti[1] = c.y; ti[2] = c.z; }
+      real ti[6];
+      {
+        v3 c = R.col(loc < 3 ? 0 : loc - 3);
+        ti[0] = loc < 3 ? (real)0 : c.x; ti[1] = loc < 3 ? (real)0 : c.y; ti[2] = loc < 3 ? (real)0 : c.z;
+        ti[3] = loc == 0 ? (real)1 : (real)0; ti[4] = loc == 1 ? (real)1 : (real)0; ti[5] = loc == 2 ? (real)1 : (real)0;
+      }
       real t[6];
 #pragma unroll
       for (int i = 0; i < 6; i++) { real a = 0; for (int j = 0; j < 6; j++) a += S.G[M.nrg + k][sym6(i, j)] * ti[j]; t[i] = a; }

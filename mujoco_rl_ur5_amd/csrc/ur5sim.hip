@@ -7,8 +7,14 @@
 #include "ur5_engine.h"
 #include "ur5sim_host.h"
 
+// Register budget: with no hint the compiler takes all 512 registers of a SIMD lane for this one-wave workgroup (occupancy 1).
+// The scene's LDS footprint allows 8 scenes per CU = 2 waves per SIMD, and two resident waves hide each other's LDS / scalar
+// latency: 256 registers + some spill is 22 % faster than 512 registers (measured, profiles/); 3 waves (168) is slower.
+#ifndef UR5_WAVES_PER_EU
+#define UR5_WAVES_PER_EU 2
+#endif
 template <int NV>
-__global__ void __launch_bounds__(64) ur5_run_kernel(double* __restrict__ rec, Ur5Launch P) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(UR5_WAVES_PER_EU))) ur5_run_kernel(double* __restrict__ rec, Ur5Launch P) {
   const int env = blockIdx.x;
   if (env >= P.n_env) return;
   ur5::Engine<double, NV> eng;

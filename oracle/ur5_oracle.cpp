@@ -881,6 +881,7 @@ struct Sim {
   }
 
   // ------------------------------------------------------------------ constraint rows  [3P, SURVEY C.4]
+  static double powr(double x, double p) { return p == 2.0 ? x * x : std::pow(x, p); }   // p = 2 is MuJoCo's default
   static double impedance(const double* solimp, double x_abs) {
     double dmin = solimp[0], dmax = solimp[1], width = solimp[2], mid = solimp[3], power = solimp[4];
     dmin = std::min(std::max(dmin, 0.0001), 0.9999);
@@ -891,8 +892,8 @@ struct Sim {
     if (x <= 0) return dmin;
     double y;
     if (power == 1) y = x;
-    else if (x <= mid) y = std::pow(x / mid, power) * mid;  // a x^p with a = 1/mid^(p-1)
-    else y = 1 - std::pow((1 - x) / (1 - mid), power) * (1 - mid);
+    else if (x <= mid) y = powr(x / mid, power) * mid;  // a x^p with a = 1/mid^(p-1)
+    else y = 1 - powr((1 - x) / (1 - mid), power) * (1 - mid);
     return dmin + y * (dmax - dmin);
   }
   void jac_point(int body, V3 p, std::vector<double>& jp, std::vector<double>& jr) const {
