@@ -7,19 +7,40 @@
 #pragma once
 
 #define UR5_MAXRD 8                                // robot dofs == robot weld groups ("cbodies")
-#define UR5_MAXOBJ 6                               // free objects handled by one wavefront
-#define UR5_MAXB (UR5_MAXRD + UR5_MAXOBJ)          // cbodies
-#define UR5_MAXNV (UR5_MAXRD + 6 * UR5_MAXOBJ)     // 44
-#define UR5_MAXNQ (UR5_MAXRD + 7 * UR5_MAXOBJ)     // 50
 #define UR5_MAXNU 8
 #define UR5_MAXRG 4                                // robot weld groups that carry collision geoms (wrist_3 group, two knuckle groups)
+#define UR5_MAXSR 16                               // equality + limit rows
+#ifndef UR5_MANY
+// ---- small scenes (UR5gripper_2_finger.xml, IT1): one 64-lane wavefront per scene, everything in LDS
+#define UR5_MAXOBJ 6                               // free objects handled by one wavefront
 #define UR5_MAXG 48
 #define UR5_MAXDG 16                               // dynamic (robot / object) collidable geoms
 #define UR5_MAXPAIR 384
 #define UR5_MAXCON 30
-#define UR5_MAXSR 16                               // equality + limit rows
 #define UR5_MAXCAND 64
 #define UR5_MAXHV 1024                             // hull vertices of collidable meshes
+#define UR5_NB 4                                   // base directions per contact: normal, 2 tangents, torsion (condim <= 4)
+#define UR5_NT 64                                  // threads per scene
+typedef int ur5_pair_t;
+#else
+// ---- many-object piles (UR5gripper_2_finger_many_objects.xml, IT5: 40 objects, condim 6): one multi-wave workgroup per
+// scene, state in LDS (~110 KB: one scene per CU), Newton Hessian in envelope (skyline) storage in global memory
+#define UR5_MAXOBJ 40
+#define UR5_MAXG 80
+#define UR5_MAXDG 56
+#define UR5_MAXPAIR 2560
+#define UR5_MAXCON 160
+#define UR5_MAXCAND 512
+#define UR5_MAXHV 512
+#define UR5_NB 6                                   // + 2 rolling directions (condim 6)
+#ifndef UR5_NT
+#define UR5_NT 256
+#endif
+typedef short ur5_pair_t;
+#endif
+#define UR5_MAXB (UR5_MAXRD + UR5_MAXOBJ)          // cbodies
+#define UR5_MAXNV (UR5_MAXRD + 6 * UR5_MAXOBJ)     // 44 / 248
+#define UR5_MAXNQ (UR5_MAXRD + 7 * UR5_MAXOBJ)     // 50 / 288
 
 enum { UR5_GEOM_PLANE = 0, UR5_GEOM_SPHERE = 2, UR5_GEOM_CAPSULE = 3, UR5_GEOM_CYLINDER = 5, UR5_GEOM_BOX = 6, UR5_GEOM_MESH = 7 };
 enum { UR5_KIND_STATIC = 0, UR5_KIND_ROBOT = 1, UR5_KIND_OBJECT = 2 };
@@ -34,7 +55,7 @@ enum { UR5_KIND_STATIC = 0, UR5_KIND_ROBOT = 1, UR5_KIND_OBJECT = 2 };
 #define UR5_REC_PIDOUT (UR5_REC_PIDIN + UR5_MAXNU)     // 162
 #define UR5_REC_KP (UR5_REC_PIDOUT + UR5_MAXNU)        // 170
 #define UR5_REC_MISC (UR5_REC_KP + UR5_MAXNU)          // 178: total_steps, last_steps, time, status, solver_iters, ncon_max, -, -
-#define UR5_REC_STRIDE 192
+#define UR5_REC_STRIDE ((UR5_REC_MISC + 8 + 63) / 64 * 64)   // 192 / 832
 
 // status bits (per env, sticky until reset)
 #define UR5_ST_CONTACT_OVERFLOW 1
@@ -69,7 +90,7 @@ struct Ur5DevModel {
   double g_size[UR5_MAXG][3], g_pos[UR5_MAXG][3], g_mat[UR5_MAXG][9], g_rbound[UR5_MAXG], g_margin[UR5_MAXG];
   double g_friction[UR5_MAXG][3], g_solref[UR5_MAXG][2], g_solimp[UR5_MAXG][5], g_invw[UR5_MAXG][2], g_center[UR5_MAXG][3];
   int dg_geom[UR5_MAXDG];
-  int pair_g1[UR5_MAXPAIR], pair_g2[UR5_MAXPAIR];
+  ur5_pair_t pair_g1[UR5_MAXPAIR], pair_g2[UR5_MAXPAIR];
   double hullvert[UR5_MAXHV][3];
   // ---- joint equality (robot dofs), actuators, options
   int eq_d1[2], eq_d2[2];
@@ -97,5 +118,12 @@ struct Ur5Launch {
   int* phase_result;            // [n][12]
   double* out;                  // [n][8] (IK: 5 joint angles)
   double* debug;                // optional [n][UR5_DEBUG_STRIDE] introspection dump (FORWARD)
+  double* hess;                 // many-object variant: [n][UR5_HESS_STRIDE] envelope storage of the Newton Hessian / its factor
 };
+#ifndef UR5_MANY
 #define UR5_DEBUG_STRIDE 2048
+#else
+#define UR5_DEBUG_STRIDE 4096
+#define UR5_HESS_STRIDE (UR5_MAXNV * (UR5_MAXNV + 1) / 2 + UR5_MAXNV)   // worst case: the full lower triangle
+#define UR5_HENV_CAP 3584                          // envelopes up to this many doubles stay in LDS
+#endif

@@ -58,7 +58,7 @@ extern __shared__ __attribute__((aligned(16))) double ur5_smem[];
 __constant__ Ur5DevModel ur5_cmodel;
 #define UR5_LDS_PTR(T) (reinterpret_cast<T*>(ur5_smem))
 #define UR5_MODEL ur5_cmodel
-#define PAR(i, n) for (int i = (int)threadIdx.x; i < (n); i += 64)
+#define PAR(i, n) for (int i = (int)threadIdx.x; i < (n); i += UR5_NT)
 #define SYNC() __syncthreads()
 #define UR5_LANE ((int)threadIdx.x)
 template <class T> __device__ __forceinline__ T ur5_wave_sum(T v) {
@@ -71,8 +71,13 @@ template <class T> __device__ __forceinline__ T ur5_wave_max(T v) {
   for (int o = 32; o > 0; o >>= 1) { T w = __shfl_xor(v, o, 64); v = w > v ? w : v; }
   return v;
 }
+#if UR5_NT == 64
 #define WAVE_SUM(v) ur5_wave_sum(v)
 #define WAVE_MAX(v) ur5_wave_max(v)
+#else   // several wavefronts per scene: Engine::block_sum / block_max combine the wave results through LDS in a fixed order
+#define WAVE_SUM(v) block_sum(v)
+#define WAVE_MAX(v) block_max(v)
+#endif
 #endif
 
 // optional per-phase cycle accounting (-DUR5_PROFILE builds libur5sim_prof.so; never defined for the product library)
@@ -91,7 +96,7 @@ enum { PF_KIN = 0, PF_CRB, PF_VEL, PF_BROAD, PF_NARROW, PF_ROWS, PF_NEWTON_INIT,
 namespace ur5 {
 
 enum { RES_NONE = -1, RES_SUCCESS = 0, RES_MAX_STEPS = 1, RES_IK_FAIL = 2 };
-constexpr int NB = 4;  // base directions per contact: normal, 2 tangents, torsion (condim <= 4; condim 6 would add 2 rolling)
+constexpr int NB = UR5_NB;  // base directions per contact: normal, 2 tangents, torsion (+ 2 rolling directions for condim 6)
 
 // ---------------------------------------------------------------------------------------------- small maths
 template <class T> struct V3 {
@@ -197,13 +202,31 @@ template <class real, int NV_> struct Lds {
       real cvel[NBODY][6];                           // body twist velocity [rot; lin] about the body's reference point
       real dgpos[UR5_MAXDG][3], dgmat[UR5_MAXDG][9];
     };
+#ifndef UR5_MANY
     real H[HSIZE];
+#else
+    real panel[NV_][UR5_MAXRD];                      // current block column of the envelope factorisation (H itself: global memory)
+#endif
   };
+#ifdef UR5_MANY
+  // envelope (skyline) storage of the Newton Hessian in global memory, dofs permuted: objects sorted along x, robot last
+  double* hess;
+  int env_first[NV_], env_ptr[NV_ + 1];              // first stored column of a row, offset of the row
+  short obj_rank[UR5_MAXOBJ], obj_at[UR5_MAXOBJ];   // sorted position of an object and back
+  short blk_first[UR5_MAXOBJ + 1], blk_last[UR5_MAXOBJ + 1];   // per block (sorted position; robot = block nobj): first coupled block, last block reaching it
+  double henv[UR5_HENV_CAP];                         // the envelope itself when it fits (it does for settled 40-object piles)
+  int env_inlds, nseq, nreach;
+  short rowlist[NV_];                                // rows below the current panel that reach it
+  real dcache[UR5_MAXOBJ + 1][44];                   // factored diagonal blocks, packed lower triangle + 1/diagonal
+  short seq[UR5_MAXOBJ + 1];                         // blocks that take part in the sequential factorisation (the others are uncoupled)
+  real red[3 * 16];                                  // cross-wave reductions
+  int redi[16];
+#endif
   // dynamics vectors (dof space)
   real fs[NV_], as[NV_], x[NV_], Ma[NV_], grad[NV_], search[NV_], Mv[NV_], tmpv[NV_ + 4];
   // contacts
   int ncon, nsr, ncand, ncouple;
-  unsigned bodymask;   // cbodies that carry at least one contact
+  unsigned long long bodymask;   // cbodies that carry at least one contact
   int cA[UR5_MAXCON], cB[UR5_MAXCON], cdim[UR5_MAXCON], cg1[UR5_MAXCON], cg2[UR5_MAXCON];
   short cand[UR5_MAXCAND];
   int couple[UR5_MAXCON];
@@ -248,6 +271,39 @@ template <class real, int NV_> struct Engine {
   UR5_FN int nslot() const { return M.nrg + M.nobj; }
   UR5_FN int slot_of(int b) const { return b < M.nrd ? M.rd_gslot[b] : M.nrg + (b - M.nrd); }
   UR5_FN int body_of_slot(int sl) const { return sl < M.nrg ? M.rg_body[sl] : M.nrd + (sl - M.nrg); }
+#if !defined(UR5_EMUL) && UR5_NT > 64
+  // sums / maxima over all wavefronts of the scene: wave shuffle, then the per-wave results through LDS in wave order
+  UR5_FN real block_sum(real v) {
+    v = ur5_wave_sum(v);
+    SYNC();
+    if ((UR5_LANE & 63) == 0) S.red[UR5_LANE >> 6] = v;
+    SYNC();
+    real t = 0;
+#pragma unroll
+    for (int w = 0; w < UR5_NT / 64; w++) t += S.red[w];
+    return t;
+  }
+  UR5_FN void block_sum3(real& a, real& b, real& c) {
+    a = ur5_wave_sum(a); b = ur5_wave_sum(b); c = ur5_wave_sum(c);
+    SYNC();
+    if ((UR5_LANE & 63) == 0) { const int w = UR5_LANE >> 6; S.red[3 * w] = a; S.red[3 * w + 1] = b; S.red[3 * w + 2] = c; }
+    SYNC();
+    real ta = 0, tb = 0, tc = 0;
+#pragma unroll
+    for (int w = 0; w < UR5_NT / 64; w++) { ta += S.red[3 * w]; tb += S.red[3 * w + 1]; tc += S.red[3 * w + 2]; }
+    a = ta; b = tb; c = tc;
+  }
+  UR5_FN real block_max(real v) {
+    v = ur5_wave_max(v);
+    SYNC();
+    if ((UR5_LANE & 63) == 0) S.red[UR5_LANE >> 6] = v;
+    SYNC();
+    real t = S.red[0];
+#pragma unroll
+    for (int w = 1; w < UR5_NT / 64; w++) t = S.red[w] > t ? S.red[w] : t;
+    return t;
+  }
+#endif
 
   UR5_FN void load(const double* rec, real dt, int con) {
     PAR(i, UR5_REC_STRIDE) S.rec[i] = (real)rec[i];
@@ -259,6 +315,9 @@ template <class real, int NV_> struct Engine {
     SYNC();
     S.status = (int)S.rec[UR5_REC_MISC + 3];
   }
+#ifdef UR5_MANY
+  UR5_FN void set_hess(double* h) { if (UR5_LANE == 0) S.hess = h; SYNC(); }
+#endif
   UR5_FN void save(double* rec) {
     SYNC();
     if (UR5_LANE == 0) {
@@ -971,9 +1030,9 @@ template <class real, int NV_> struct Engine {
     PROF_T0();
     // broad phase: ordered compaction of the surviving pairs
     int ncand = 0;
-    for (int p0 = 0; p0 < M.npair; p0 += 64) {
+    for (int p0 = 0; p0 < M.npair; p0 += UR5_NT) {
 #ifdef UR5_EMUL
-      for (int p = p0; p < p0 + 64 && p < M.npair; p++) {
+      for (int p = p0; p < p0 + UR5_NT && p < M.npair; p++) {
         int g1 = M.pair_g1[p], g2 = M.pair_g2[p];
         real margin = maxv((real)M.g_margin[g1], (real)M.g_margin[g2]);
         if (!cull(g1, g2, margin) && ncand < UR5_MAXCAND) S.cand[ncand++] = (short)p;
@@ -987,9 +1046,21 @@ template <class real, int NV_> struct Engine {
         keep = !cull(g1, g2, margin);
       }
       unsigned long long mask = __ballot(keep);
+#if UR5_NT == 64
       int slot = ncand + __popcll(mask & ((1ull << UR5_LANE) - 1ull));
       if (keep && slot < UR5_MAXCAND) S.cand[slot] = (short)p;
       ncand += __popcll(mask);
+#else   // ordered compaction across the wavefronts of the scene
+      if ((UR5_LANE & 63) == 0) S.redi[UR5_LANE >> 6] = __popcll(mask);
+      SYNC();
+      int base = ncand, total = 0;
+#pragma unroll
+      for (int w = 0; w < UR5_NT / 64; w++) { if (w < (UR5_LANE >> 6)) base += S.redi[w]; total += S.redi[w]; }
+      int slot = base + __popcll(mask & ((1ull << (UR5_LANE & 63)) - 1ull));
+      if (keep && slot < UR5_MAXCAND) S.cand[slot] = (short)p;
+      ncand += total;
+      SYNC();
+#endif
       if (ncand > UR5_MAXCAND) ncand = UR5_MAXCAND;
 #endif
     }
@@ -999,8 +1070,7 @@ template <class real, int NV_> struct Engine {
 #ifdef UR5_EMUL
     for (int ci = 0; ci < ncand; ci++) {
 #else
-    {
-      const int ci = UR5_LANE;
+    for (int ci = UR5_LANE; ci < ncand; ci += UR5_NT) {
 #endif
       if (ci < ncand) {
         Sink sink;
@@ -1144,16 +1214,19 @@ template <class real, int NV_> struct Engine {
     SYNC();
     if (UR5_LANE == 0) {
       int nc = 0;
-      unsigned bm = 0;
+      unsigned long long bm = 0;
       for (int c = 0; c < S.ncon; c++) {
         if (S.cA[c] >= 0 && S.cB[c] >= 0) S.couple[nc++] = c;
-        if (S.cA[c] >= 0) bm |= 1u << S.cA[c];
-        if (S.cB[c] >= 0) bm |= 1u << S.cB[c];
+        if (S.cA[c] >= 0) bm |= 1ull << S.cA[c];
+        if (S.cB[c] >= 0) bm |= 1ull << S.cB[c];
       }
       S.ncouple = nc;
       S.bodymask = bm;
     }
     SYNC();
+#ifdef UR5_MANY
+    envelope_structure();
+#endif
   }
 
   // ------------------------------------------------------------------ Newton solver pieces
@@ -1219,7 +1292,12 @@ template <class real, int NV_> struct Engine {
       if (!S.sr_uni[s] || r < 0) { c0 += (real)0.5 * S.sr_D[s] * r * r; g1 += S.sr_D[s] * r * j; g2 += S.sr_D[s] * j * j; }
     }
     Cost3 r;
+#if !defined(UR5_EMUL) && UR5_NT > 64
+    block_sum3(c0, g1, g2);   // one pair of barriers for the three sums
+    r.c = c0; r.d1 = g1; r.d2 = g2;
+#else
     r.c = WAVE_SUM(c0); r.d1 = WAVE_SUM(g1); r.d2 = WAVE_SUM(g2);
+#endif
     return r;
   }
   UR5_FN real gauss_cost(const real* xv, const real* Ma) {
@@ -1336,6 +1414,18 @@ template <class real, int NV_> struct Engine {
       S.search[i] = S.grad[i];
     }
     PROF(PF_GRADG);
+#ifdef UR5_MANY
+    if (S.env_inlds) {
+      envelope_assemble<true>(); PROF(PF_HASM);
+      envelope_factor<true>(); PROF(PF_CHOL);
+      envelope_solve<true>(); PROF(PF_SOLVE);
+    } else {
+      envelope_assemble<false>(); PROF(PF_HASM);
+      envelope_factor<false>(); PROF(PF_CHOL);
+      envelope_solve<false>(); PROF(PF_SOLVE);
+    }
+    return;
+#else
 #ifndef UR5_EMUL
     if (S.ncouple == 0 && M.nrd == UR5_MAXRD) { newton_blockdiag(); PROF(PF_SOLVE); return; }
 #endif
@@ -1419,9 +1509,10 @@ template <class real, int NV_> struct Engine {
     factor_solve_rows<false>();
     PROF(PF_SOLVE);
 #endif
+#endif   // UR5_MANY
   }
 
-#ifndef UR5_EMUL
+#if !defined(UR5_EMUL) && !defined(UR5_MANY)
   // No contact couples two movable bodies: H = diag(robot 8x8, object 6x6, ...). Each lane builds ITS row of ITS block
   // straight into registers (robot row d: Mr + sum_b cdof_d^T G_b cdof_e + equality/limit rows; object row: M + T^T G T)
   // and the block-parallel Cholesky / solves above produce S.search = -H^-1 grad without any Hessian in LDS.
@@ -1491,7 +1582,7 @@ template <class real, int NV_> struct Engine {
   }
 #endif
 
-#ifndef UR5_EMUL
+#if !defined(UR5_EMUL) && !defined(UR5_MANY)
   // broadcast lane `src` (wave-uniform) of a double through two v_readlane
   static __device__ __forceinline__ real bcast(real v, int src) {
     double d = (double)v;
@@ -1545,6 +1636,359 @@ template <class real, int NV_> struct Engine {
     }
     if (lane < nv) S.search[lane] = -b;
     SYNC();
+  }
+#endif
+
+#ifdef UR5_MANY
+  // ------------------------------------------------------------------ many-object scenes: envelope (skyline) Newton Hessian
+  // H = blockdiag(robot 8x8, object 6x6 ...) + one coupling block per pair of movable bodies in contact. The blocks are
+  // ordered objects-sorted-along-x, robot last, so that touching bodies are close in the ordering; every row stores the
+  // columns from the first block it is coupled with up to the diagonal, and the Cholesky factor fills exactly that
+  // envelope. A settled 40-object pile needs 1.5-2.5 k doubles, so the envelope lives in LDS (S.henv); only when it does
+  // not fit (UR5_HENV_CAP) the same code runs on the scene's global-memory scratch (S.hess, INLDS = false).
+  // Blocks that are coupled to nothing are factored / solved all at once; the others go through a right-looking
+  // factorisation by block columns (one body = one panel, 2 barriers each) and panel-wise triangular solves.
+  UR5_FN int pdof(int i) const {   // engine dof -> permuted row
+    if (i < M.nrd) return 6 * M.nobj + i;
+    const int k = (i - M.nrd) / 6, j = (i - M.nrd) % 6;
+    return 6 * S.obj_rank[k] + j;
+  }
+  UR5_FN int edof(int I) const {   // permuted row -> engine dof
+    if (I >= 6 * M.nobj) return I - 6 * M.nobj;
+    return M.nrd + 6 * S.obj_at[I / 6] + I % 6;
+  }
+  UR5_FN int blk_of_body(int b) const { return b < M.nrd ? M.nobj : S.obj_rank[b - M.nrd]; }
+  UR5_FN int blk_width(int p) const { return p < M.nobj ? 6 : M.nrd; }
+  template <bool INLDS> UR5_FN double* hptr(int I, int J) { return (INLDS ? S.henv : S.hess) + S.env_ptr[I] + (J - S.env_first[I]); }
+  UR5_BIG void envelope_structure() {
+    static_assert(UR5_NT >= UR5_MAXNV, "one thread per Hessian row");
+    const int nobj = M.nobj, nblk = nobj + 1, nv = M.nv;
+    PAR(k, nobj) {
+      const real key = S.bpos[M.nrd + k][0];
+      int r = 0;
+      for (int j = 0; j < nobj; j++) { real kj = S.bpos[M.nrd + j][0]; if (kj < key || (kj == key && j < k)) r++; }
+      S.obj_rank[k] = (short)r; S.obj_at[r] = (short)k;
+    }
+    PAR(p2, nblk) S.blk_first[p2] = (short)p2;
+    SYNC();
+    if (UR5_LANE == 0) {
+      for (int q = 0; q < S.ncouple; q++) {
+        const int c = S.couple[q];
+        int pa = blk_of_body(S.cA[c]), pb = blk_of_body(S.cB[c]);
+        if (pa > pb) { int t = pa; pa = pb; pb = t; }
+        if (S.blk_first[pb] > pa) S.blk_first[pb] = (short)pa;
+      }
+    }
+    SYNC();
+    PAR(p2, nblk) { int last = p2; for (int q = p2 + 1; q < nblk; q++) if (S.blk_first[q] <= p2) last = q; S.blk_last[p2] = (short)last; }
+    PAR(i, nv) S.env_first[i] = 6 * S.blk_first[i < 6 * nobj ? i / 6 : nobj];
+    SYNC();
+    if (UR5_LANE == 0) {
+      int o = 0;
+      for (int i = 0; i < nv; i++) { S.env_ptr[i] = o; o += i - S.env_first[i] + 1; }
+      S.env_ptr[nv] = o;
+      S.env_inlds = o <= UR5_HENV_CAP;
+      int ns = 0;   // blocks that take part in the sequential factorisation: they reach an earlier block or are reached by a later one
+      for (int p2 = 0; p2 < nblk; p2++) if (S.blk_first[p2] != p2 || S.blk_last[p2] != p2) S.seq[ns++] = (short)p2;
+      S.nseq = ns;
+    }
+    SYNC();
+  }
+  UR5_FN bool blk_single(int p2) const { return S.blk_first[p2] == p2 && S.blk_last[p2] == p2; }
+  template <bool INLDS> UR5_BIG void envelope_assemble() {
+    const int tot = S.env_ptr[M.nv];
+    double* const hb = INLDS ? S.henv : S.hess;
+    PAR(idx, tot) hb[idx] = 0;
+    PAR(i, M.nv) S.Mv[pdof(i)] = S.grad[i];   // right-hand side in permuted order
+    SYNC();
+    PAR(idx, M.nrd * M.nrd) {   // robot block: Mr + sum_b cdof^T G_b cdof + equality / limit rows
+      int d = idx / M.nrd, e = idx % M.nrd;
+      if (e > d) continue;
+      real v = S.Mr[d][e];
+      unsigned common = M.rd_desc[d] & M.rd_desc[e];
+      for (int rg = 0; rg < M.nrg; rg++) {
+        const int b = M.rg_body[rg];
+        if (!(common >> b & 1u) || !(S.bodymask >> b & 1u)) continue;
+        for (int i = 0; i < 6; i++) {
+          real t = 0;
+          for (int j = 0; j < 6; j++) t += S.G[rg][sym6(i, j)] * S.cdof[e][j];
+          v += S.cdof[d][i] * t;
+        }
+      }
+      for (int s2 = 0; s2 < S.nsr; s2++) {
+        if (S.sr_uni[s2] && S.sr_jar[s2] >= 0) continue;
+        real cd = (S.sr_d1[s2] == d ? S.sr_c1[s2] : (real)0) + (S.sr_d2[s2] == d ? S.sr_c2[s2] : (real)0);
+        real ce = (S.sr_d1[s2] == e ? S.sr_c1[s2] : (real)0) + (S.sr_d2[s2] == e ? S.sr_c2[s2] : (real)0);
+        v += S.sr_D[s2] * cd * ce;
+      }
+      *hptr<INLDS>(pdof(d), pdof(e)) = (double)v;
+    }
+    PAR(idx, M.nobj * 21) {     // object blocks: M + T^T G T
+      int k = idx / 21, ent = idx % 21, b = M.nrd + k;
+      int i = 0;
+      while ((i + 1) * (i + 2) / 2 <= ent) i++;
+      int j = ent - i * (i + 1) / 2;
+      int di = M.nrd + 6 * k + i, dj = M.nrd + 6 * k + j;
+      real v = 0;
+      if (S.bodymask >> b & 1ull) {
+        real ti[6], tj[6];
+        unit_twist(b, i, ti); unit_twist(b, j, tj);
+        for (int a2 = 0; a2 < 6; a2++) { real t = 0; for (int bb = 0; bb < 6; bb++) t += S.G[M.nrg + k][sym6(a2, bb)] * tj[bb]; v += ti[a2] * t; }
+      }
+      if (i == j) {
+        v += S.Mobj[6 * k + i];
+        for (int s2 = 0; s2 < S.nsr; s2++) if (S.sr_d1[s2] == di && !(S.sr_uni[s2] && S.sr_jar[s2] >= 0)) v += S.sr_D[s2] * S.sr_c1[s2] * S.sr_c1[s2];
+      }
+      *hptr<INLDS>(pdof(di), pdof(dj)) = (double)v;
+    }
+    SYNC();
+    // coupling blocks: every (contact, entry) pair in parallel, summed with float atomics
+    PAR(idx, S.ncouple * 64) {
+      const int c = S.couple[idx >> 6], ent = idx & 63;
+      const int A = S.cA[c], B = S.cB[c];
+      const int nA = A < M.nrd ? M.nrd : 6, nBd = B < M.nrd ? M.nrd : 6;
+      if (ent >= nA * nBd) continue;
+      const int ia = ent / nBd, ib = ent % nBd;
+      const bool both_robot = A < M.nrd && B < M.nrd;
+      if (both_robot && ia < ib) continue;
+      real v = couple_term(c, A, ia, B, ib);
+      if (both_robot) v = ia == ib ? 2 * v : v + couple_term(c, A, ib, B, ia);
+      if (v == 0) continue;
+      int I = pdof(A < M.nrd ? ia : M.nrd + 6 * (A - M.nrd) + ia), J = pdof(B < M.nrd ? ib : M.nrd + 6 * (B - M.nrd) + ib);
+      if (I < J) { int t = I; I = J; J = t; }
+      UR5_ATOMIC_ADD(hptr<INLDS>(I, J), (double)v);
+    }
+    SYNC();
+  }
+  // lower Cholesky factor of a diagonal block (order W = 6 for an object, 8 for the robot) in registers
+  template <int W> struct Diag { real l[W][W]; real inv[W]; };
+  // unfactored block at row/column c0 from H -> factor in registers
+  template <bool INLDS, int W> UR5_FN void diag_factor(int c0, Diag<W>& d) {
+    double* const hb = INLDS ? S.henv : S.hess;
+    const int off = c0 - S.env_first[c0];
+#pragma unroll
+    for (int a = 0; a < W; a++) {
+      const double* row = hb + S.env_ptr[c0 + a] + off;
+#pragma unroll
+      for (int bb = 0; bb < W; bb++) d.l[a][bb] = bb <= a ? (real)row[bb] : (real)0;
+    }
+#pragma unroll
+    for (int j = 0; j < W; j++) {
+      real dj = d.l[j][j];
+#pragma unroll
+      for (int k = 0; k < j; k++) dj -= d.l[j][k] * d.l[j][k];
+      dj = dj < (real)1e-15 ? (real)1e-15 : dj;
+      const real sq = sqrt(dj), inv = (real)1 / sq;
+      d.l[j][j] = sq; d.inv[j] = inv;
+#pragma unroll
+      for (int a = j + 1; a < W; a++) {
+        real sacc = d.l[a][j];
+#pragma unroll
+        for (int k = 0; k < j; k++) sacc -= d.l[a][k] * d.l[j][k];
+        d.l[a][j] = sacc * inv;
+      }
+    }
+  }
+  // factored blocks are kept packed (lower triangle, then 1 / diagonal) in S.dcache for the triangular solves
+  template <int W> UR5_FN void diag_store(int p2, const Diag<W>& d) {
+    real* c = S.dcache[p2];
+#pragma unroll
+    for (int a = 0; a < W; a++) {
+#pragma unroll
+      for (int bb = 0; bb <= a; bb++) c[a * (a + 1) / 2 + bb] = d.l[a][bb];
+      c[36 + a] = d.inv[a];
+    }
+  }
+  template <int W> UR5_FN void diag_cached(int p2, Diag<W>& d) {
+    const real* c = S.dcache[p2];
+#pragma unroll
+    for (int a = 0; a < W; a++) {
+#pragma unroll
+      for (int bb = 0; bb < W; bb++) d.l[a][bb] = bb <= a ? c[a * (a + 1) / 2 + bb] : (real)0;
+      d.inv[a] = c[36 + a];
+    }
+  }
+  template <int W> UR5_FN static real pick(const real (&v)[W], int k) {   // v[k] without a run-time register index
+    real o = v[0];
+#pragma unroll
+    for (int a = 1; a < W; a++) o = a == k ? v[a] : o;
+    return o;
+  }
+  // x <- L^-1 x and x <- L^-T x for one block
+  template <int W> UR5_FN static void fwd_blk(const Diag<W>& d, real (&x)[W]) {
+#pragma unroll
+    for (int k = 0; k < W; k++) {
+      real sacc = x[k];
+#pragma unroll
+      for (int m = 0; m < k; m++) sacc -= d.l[k][m] * x[m];
+      x[k] = sacc * d.inv[k];
+    }
+  }
+  template <int W> UR5_FN static void bwd_blk(const Diag<W>& d, real (&x)[W]) {
+#pragma unroll
+    for (int k = W - 1; k >= 0; k--) {
+      real sacc = x[k];
+#pragma unroll
+      for (int m = k + 1; m < W; m++) sacc -= d.l[m][k] * x[m];
+      x[k] = sacc * d.inv[k];
+    }
+  }
+  // uncoupled blocks: every row factors its own diagonal block (redundantly per row); row 0 of the block files it in dcache
+  template <bool INLDS, int W> UR5_FN void factor_single_row(int i, int p2) {
+    const int c0 = 6 * p2, r = i - c0;
+    Diag<W> d;
+    diag_factor<INLDS, W>(c0, d);
+    if (r == 0) diag_store<W>(p2, d);
+  }
+  template <bool INLDS, int W> UR5_FN void factor_panel_row(int i, int ii, int p2, int c0) {
+    Diag<W> d;
+    diag_factor<INLDS, W>(c0, d);
+    real out[W];
+    if (ii < W) {
+#pragma unroll
+      for (int k = 0; k < W; k++) {
+        real v = 0;
+#pragma unroll
+        for (int a = 0; a < W; a++) if (a == ii && k <= a) v = d.l[a][k];
+        out[k] = v;
+      }
+      if (ii == 0) diag_store<W>(p2, d);
+    } else {
+      const double* row = hptr<INLDS>(i, c0);
+#pragma unroll
+      for (int k = 0; k < W; k++) {
+        real sacc = (real)row[k];
+#pragma unroll
+        for (int m = 0; m < k; m++) sacc -= out[m] * d.l[k][m];
+        out[k] = sacc * d.inv[k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < W; k++) S.panel[i][k] = out[k];
+  }
+  template <bool INLDS> UR5_BIG void envelope_factor() {
+    PAR(i, M.nv) {
+      const int p2 = i < 6 * M.nobj ? i / 6 : M.nobj;
+      if (!blk_single(p2)) continue;
+      if (p2 < M.nobj) factor_single_row<INLDS, 6>(i, p2); else factor_single_row<INLDS, UR5_MAXRD>(i, p2);
+    }
+    for (int q = 0; q < S.nseq; q++) {
+      const int p2 = S.seq[q];
+      const int c0 = 6 * p2, w = blk_width(p2);
+      const int lastb = S.blk_last[p2], rlast = 6 * lastb + blk_width(lastb);   // one past the last row that reaches this panel
+      // A1: every reaching row computes its entries of the block column (LDS panel); H is only read
+      PAR(ii, rlast - c0) {
+        const int i = c0 + ii;
+        if (S.env_first[i] > c0) continue;
+        if (p2 < M.nobj) factor_panel_row<INLDS, 6>(i, ii, p2, c0); else factor_panel_row<INLDS, UR5_MAXRD>(i, ii, p2, c0);
+        if (ii >= w) {   // compact list of the reaching rows below the block (its position = reaching rows before it)
+          int pos = 0;
+          const int bi = i < 6 * M.nobj ? i / 6 : M.nobj;
+          for (int qb = p2 + 1; qb < bi; qb++) if (S.blk_first[qb] <= p2) pos += 6;
+          pos += i - 6 * bi;
+          S.rowlist[pos] = (short)i;
+        }
+      }
+      if (UR5_LANE == 0) {
+        int cnt = 0;
+        for (int qb = p2 + 1; qb <= lastb; qb++) if (S.blk_first[qb] <= p2) cnt += blk_width(qb);
+        S.nreach = cnt;
+      }
+      SYNC();
+      // A2: the finished column entries of the rows below go back to H (the block itself lives on in dcache);
+      // B: trailing update of every pair of reaching rows below the block
+      const int nr = S.nreach;
+      PAR(ii, nr) {
+        const int i = S.rowlist[ii];
+        double* row = hptr<INLDS>(i, c0);
+        for (int k = 0; k < w; k++) row[k] = (double)S.panel[i][k];
+      }
+      PAR(idx, nr * nr) {
+        const int ii = idx / nr, jj = idx - ii * nr;
+        if (jj > ii) continue;
+        const int i = S.rowlist[ii], j = S.rowlist[jj];
+        real sacc = 0;
+        for (int k = 0; k < w; k++) sacc += S.panel[i][k] * S.panel[j][k];
+        *hptr<INLDS>(i, j) -= (double)sacc;
+      }
+      SYNC();
+    }
+  }
+  // S.search = -H^-1 grad with the factor in place: b = S.Mv (permuted right-hand side, consumed), y = S.tmpv
+  template <int W> UR5_FN void solve_single_row(int i, int p2, const real* b) {
+    const int c0 = 6 * p2;
+    Diag<W> d;
+    diag_cached<W>(p2, d);
+    real t[W];
+#pragma unroll
+    for (int k = 0; k < W; k++) t[k] = b[c0 + k];
+    fwd_blk<W>(d, t);
+    bwd_blk<W>(d, t);
+    S.search[edof(i)] = -pick<W>(t, i - c0);
+  }
+  template <bool INLDS, int W> UR5_FN void fwd_panel_row(int i, int ii, int p2, int c0, real* b, real* y) {
+    Diag<W> d;
+    diag_cached<W>(p2, d);
+    real yb[W];
+#pragma unroll
+    for (int k = 0; k < W; k++) yb[k] = b[c0 + k];
+    fwd_blk<W>(d, yb);
+    if (ii < W) y[i] = pick<W>(yb, ii);
+    else {
+      const double* row = hptr<INLDS>(i, c0);
+      real sacc = 0;
+#pragma unroll
+      for (int k = 0; k < W; k++) sacc += (real)row[k] * yb[k];
+      b[i] -= sacc;
+    }
+  }
+  template <bool INLDS, int W> UR5_FN void bwd_panel_col(int j, int p2, int c0, real* y) {
+    Diag<W> d;
+    diag_cached<W>(p2, d);
+    real xb[W];
+#pragma unroll
+    for (int k = 0; k < W; k++) xb[k] = y[c0 + k];
+    bwd_blk<W>(d, xb);
+    if (j >= c0) S.search[edof(j)] = -pick<W>(xb, j - c0);
+    else {
+      real sacc = 0;
+#pragma unroll
+      for (int k = 0; k < W; k++) sacc += (real)*hptr<INLDS>(c0 + k, j) * xb[k];
+      y[j] -= sacc;   // the lanes of this panel only read y inside the block, never left of it
+    }
+  }
+  template <bool INLDS> UR5_BIG void envelope_solve() {
+    static_assert(sizeof(S.tmpv) / sizeof(real) >= (size_t)NV_, "tmpv holds a dof vector");
+    real* b = S.Mv;
+    real* y = S.tmpv;
+    SYNC();   // dcache of the uncoupled blocks
+    PAR(i, M.nv) {   // uncoupled blocks: the whole solve at once
+      const int p2 = i < 6 * M.nobj ? i / 6 : M.nobj;
+      if (!blk_single(p2)) continue;
+      if (p2 < M.nobj) solve_single_row<6>(i, p2, b); else solve_single_row<UR5_MAXRD>(i, p2, b);
+    }
+    for (int q = 0; q < S.nseq; q++) {   // forward, column-oriented: y_blk = L_pp^-1 b_blk, then b_i -= L_i,blk y_blk for the rows below
+      const int p2 = S.seq[q];
+      const int c0 = 6 * p2;
+      const int lastb = S.blk_last[p2], rlast = 6 * lastb + blk_width(lastb);
+      PAR(ii, rlast - c0) {
+        const int i = c0 + ii;
+        if (S.env_first[i] > c0) continue;
+        if (p2 < M.nobj) fwd_panel_row<INLDS, 6>(i, ii, p2, c0, b, y); else fwd_panel_row<INLDS, UR5_MAXRD>(i, ii, p2, c0, b, y);
+      }
+      SYNC();
+    }
+    for (int q = S.nseq - 1; q >= 0; q--) {   // backward, row-oriented: x_blk = L_pp^-T y_blk, then y_j -= L_blk,j^T x_blk for the columns left of it
+      const int p2 = S.seq[q];
+      const int c0 = 6 * p2, w = blk_width(p2);
+      const int f0 = S.env_first[c0];
+      PAR(jj, c0 + w - f0) {
+        const int j = f0 + jj;
+        if (p2 < M.nobj) bwd_panel_col<INLDS, 6>(j, p2, c0, y); else bwd_panel_col<INLDS, UR5_MAXRD>(j, p2, c0, y);
+      }
+      SYNC();
+    }
+    SYNC();   // S.search of the uncoupled blocks (there may be no sequential block at all)
   }
 #endif
 
@@ -1617,7 +2061,11 @@ template <class real, int NV_> struct Engine {
       PROF(PF_IMAGES);
       real q1 = 0, q2 = 0, sn = 0;
       PAR(i, nv) { q1 += S.search[i] * (S.Ma[i] - S.fs[i]); q2 += S.search[i] * S.Mv[i]; sn += S.search[i] * S.search[i]; }
+#if !defined(UR5_EMUL) && UR5_NT > 64
+      block_sum3(q1, q2, sn); sn = sqrt(sn);
+#else
       q1 = WAVE_SUM(q1); q2 = WAVE_SUM(q2); sn = sqrt(WAVE_SUM(sn));
+#endif
       if (sn < (real)1e-15) break;
       real gtol = tolerance * (real)0.01 * sn / scale;
       real lo = 0, hi = -1, a = 0, d1, d2;
@@ -1986,6 +2434,10 @@ template <class real, int NV_> struct Engine {
     if (UR5_LANE != 0) return;
     int o = 0;
     out[o++] = S.ncon; out[o++] = S.nsr; out[o++] = S.solver_iters; out[o++] = S.status;
+#ifdef UR5_MANY
+    out[o++] = S.env_ptr[M.nv]; out[o++] = S.ncouple;   // envelope size (doubles), contacts between two movable bodies
+    { int ns = 0; for (int p2 = 0; p2 <= M.nobj; p2++) if (S.blk_first[p2] != p2 || S.blk_last[p2] != p2) ns++; out[o++] = ns; }   // coupled blocks
+#endif
     o = 8;
     for (int b = 0; b < UR5_MAXB; b++) for (int k = 0; k < 3; k++) out[o++] = b < nb() ? (double)S.bpos[b][k] : 0;      // 8   .. 50
     for (int d = 0; d < UR5_MAXRD; d++) for (int e = 0; e < UR5_MAXRD; e++) out[o++] = (double)S.Mr[d][e];               // 50  .. 114

@@ -2,7 +2,7 @@
 // + the two flips of MJ_Controller.get_image_data (gym_grasper/controller/MujocoController.py:708-727) and, in metric
 // mode, depth_2_meters (:729-740).
 //
-// The camera is fixed and the scene is a handful of convex shapes (plane, boxes, spheres, convex hulls of the meshes, as
+// The camera is fixed and the scene is a handful of convex shapes (plane, boxes, spheres, cylinders, capsules, convex hulls of the meshes, as
 // MuJoCo's collision geometry -- capped hulls), so the image is produced by casting one ray per pixel against
 // every geom (bounding-sphere reject first) instead of rasterising ~190 k visual triangles: one thread = one pixel, one block =
 // one 16x16 tile of one scene, geom poses of the scene staged in LDS by the block. Shading: flat albedo (geom rgba / material
@@ -154,6 +154,38 @@ UR5_RFN float shade_pixel(const Ur5RenderModel& R, const float (*gposes)[12], in
         if (tf < t1) t1 = tf;
       }
       if (!miss && t0 <= t1 && t0 > 0) { t = t0; nl = f3(ax == 0 ? sg : 0, ax == 1 ? sg : 0, ax == 2 ? sg : 0); }
+    } else if (type == UR5_GEOM_CYLINDER || type == UR5_GEOM_CAPSULE) {
+      // axis = local z, radius size[0], half length size[1]. Cylinder: (infinite side) n (slab |z| <= h), entry = later of the
+      // two entries. Capsule: side hit inside the slab, else the entering root of the end sphere the ray meets beyond it.
+      const float r = R.g_size[g][0], hl = R.g_size[g][1];
+      const float a = dl.x * dl.x + dl.y * dl.y, b = ol.x * dl.x + ol.y * dl.y, cc = ol.x * ol.x + ol.y * ol.y - r * r;
+      float ts0 = -1e30f, ts1 = 1e30f;
+      bool miss = false;
+      if (a > 1e-12f) { float disc = b * b - a * cc; if (disc < 0) miss = true; else { float sq = sqrtf(disc); ts0 = (-b - sq) / a; ts1 = (-b + sq) / a; } }
+      else if (cc > 0) miss = true;
+      if (!miss && type == UR5_GEOM_CYLINDER) {
+        float tz0 = -1e30f, tz1 = 1e30f;
+        if (fabsf(dl.z) > 1e-12f) { float ta = (-hl - ol.z) / dl.z, tb = (hl - ol.z) / dl.z; tz0 = ta < tb ? ta : tb; tz1 = ta < tb ? tb : ta; }
+        else if (fabsf(ol.z) > hl) miss = true;
+        float te = ts0 > tz0 ? ts0 : tz0, tx = ts1 < tz1 ? ts1 : tz1;
+        if (!miss && te <= tx && te > 0) {
+          t = te;
+          if (ts0 > tz0) { F3 p = ol + dl * t; nl = f3(p.x / r, p.y / r, 0); } else nl = f3(0, 0, dl.z > 0 ? -1.0f : 1.0f);
+        }
+      } else if (type == UR5_GEOM_CAPSULE) {
+        float tb2 = 1e30f;
+        if (!miss && a > 1e-12f) { float z = ol.z + dl.z * ts0; if (fabsf(z) <= hl && ts0 > 0) { tb2 = ts0; F3 p = ol + dl * ts0; nl = f3(p.x / r, p.y / r, 0); } }
+        for (int e = 0; e < 2; e++) {
+          const float zc = e == 0 ? hl : -hl;
+          const F3 oc = f3(ol.x, ol.y, ol.z - zc);
+          float bs = dot(oc, dl), cs = dot(oc, oc) - r * r, disc = bs * bs - dd * cs;
+          if (disc < 0) continue;
+          float ts = (-bs - sqrtf(disc)) / dd;
+          F3 p = oc + dl * ts;
+          if (ts > 0 && ts < tb2 && (e == 0 ? p.z >= 0 : p.z <= 0)) { tb2 = ts; nl = p * (1.0f / r); }
+        }
+        if (tb2 < 1e29f) t = tb2;
+      }
     } else if (type == UR5_GEOM_MESH) {
       float t0 = -1e30f, t1 = 1e30f;
       int kb = -1;

@@ -13,13 +13,21 @@
 #ifndef UR5_WAVES_PER_EU
 #define UR5_WAVES_PER_EU 2
 #endif
+#ifdef UR5_MANY
+#define UR5_KERNEL_ATTR __launch_bounds__(UR5_NT)
+#else
+#define UR5_KERNEL_ATTR __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(UR5_WAVES_PER_EU)))
+#endif
 template <int NV>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(UR5_WAVES_PER_EU))) ur5_run_kernel(double* __restrict__ rec, Ur5Launch P) {
+__global__ void UR5_KERNEL_ATTR ur5_run_kernel(double* __restrict__ rec, Ur5Launch P) {
   const int env = blockIdx.x;
   if (env >= P.n_env) return;
   ur5::Engine<double, NV> eng;
   double* r = rec + (size_t)env * UR5_REC_STRIDE;
   eng.load(r, P.pid_dt, P.contacts_enabled);
+#ifdef UR5_MANY
+  eng.set_hess(P.hess + (size_t)env * UR5_HESS_STRIDE);
+#endif
   eng.run(P, env);
   eng.save(r);
 }
@@ -114,9 +122,20 @@ static int be_launch(ur5_sim* h, const Ur5Launch& P) {
   HIPCHK(hipSetDevice(h->device));
   { int rcm = be_upload_model(h); if (rcm) return rcm; }
   HIPCHK(hipEventRecord(b->ev0, b->stream));
-  dim3 grid(h->n), block(64);
+  dim3 grid(h->n), block(UR5_NT);
+#ifdef UR5_MANY
+  {   // the scene needs more than the default 64 KB of dynamic LDS (one scene per CU)
+    static bool attr_set[64] = {false};
+    if (!attr_set[h->device & 63]) {
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ur5_run_kernel<UR5_MAXNV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ur5::Lds<double, UR5_MAXNV>)));
+      attr_set[h->device & 63] = true;
+    }
+  }
+  hipLaunchKernelGGL(ur5_run_kernel<UR5_MAXNV>, grid, block, sizeof(ur5::Lds<double, UR5_MAXNV>), b->stream, h->d_rec, P);
+#else
   if (h->nvt == 32) hipLaunchKernelGGL(ur5_run_kernel<32>, grid, block, sizeof(ur5::Lds<double, 32>), b->stream, h->d_rec, P);
   else hipLaunchKernelGGL(ur5_run_kernel<UR5_MAXNV>, grid, block, sizeof(ur5::Lds<double, UR5_MAXNV>), b->stream, h->d_rec, P);
+#endif
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(b->ev1, b->stream));
   b->timed = true;

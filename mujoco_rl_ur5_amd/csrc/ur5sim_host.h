@@ -15,7 +15,10 @@
 namespace ur5host {
 
 static thread_local std::string g_err;
-static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+static thread_local bool g_err_many = false;   // small-scene unit: the last failing call was forwarded to the many-object unit
+static int fail(int code, const std::string& msg) { g_err = msg; g_err_many = false; return code; }
+// number of free-floating top-level bodies in a model blob (-1: unreadable) -- decides which engine variant serves it
+static int count_objects(const void* data, size_t nbytes);
 
 // ------------------------------------------------------------------ blob reader (format: mujoco_rl_ur5_amd/model.py)
 struct Blob {
@@ -46,6 +49,16 @@ struct Blob {
 };
 
 // ------------------------------------------------------------------ tiny rigid-transform helpers (double)
+static int count_objects(const void* data, size_t nbytes) {
+  Blob B{(const char*)data, nbytes};
+  if (!B.ok()) return -1;
+  int nbody = 0;
+  const int* tree = B.I("body_treeid", &nbody);
+  if (!tree) return -1;
+  int n = 0;
+  for (int b = 1; b < nbody; b++) if (tree[b] > 0) n++;
+  return n;
+}
 struct Xf { double p[3]; double q[4]; };
 static void qmul(const double* a, const double* b, double* r) {
   double t[4] = {a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3], a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
@@ -203,7 +216,7 @@ static int build_model(const void* data, size_t nbytes, int ee_body, Ur5DevModel
   int nobj = 0;
   for (int b = 1; b < nbody; b++) {
     if (body_tree[b] <= 0) continue;
-    if (body_parent[b] != 0 || nobj >= UR5_MAXOBJ) return fail(UR5_ERR_MODEL, "objects must be top-level bodies, at most 6 per scene in this build");
+    if (body_parent[b] != 0 || nobj >= UR5_MAXOBJ) return fail(UR5_ERR_MODEL, "objects must be top-level bodies, at most " + std::to_string(UR5_MAXOBJ) + " per scene");
     int j = body_jntadr[b], k = nobj;
     if (body_jntnum[b] == 1 && jnt_type[j] == 0) D.obj_kind[k] = 1;
     else if (body_jntnum[b] == 4 && jnt_type[j] == 2 && jnt_type[j + 1] == 2 && jnt_type[j + 2] == 2 && jnt_type[j + 3] == 1) D.obj_kind[k] = 0;
@@ -245,7 +258,7 @@ static int build_model(const void* data, size_t nbytes, int ee_body, Ur5DevModel
     dev_of_geom[g] = k;
     dev2model_geom->push_back(g);
     D.g_type[k] = geom_type[g]; D.g_condim[k] = geom_condim[g];
-    if (geom_condim[g] > 4) return fail(UR5_ERR_MODEL, "condim 6 (rolling friction) is not compiled into this build (NB = 4)");
+    if (geom_condim[g] > (UR5_NB > 4 ? 6 : 4)) return fail(UR5_ERR_MODEL, "condim 6 (rolling friction) needs the many-object variant (NB = 6)");
     memcpy(D.g_size[k], geom_size + 3 * g, 24);
     D.g_rbound[k] = geom_rbound[g]; D.g_margin[k] = geom_margin[g];
     memcpy(D.g_friction[k], geom_friction + 3 * g, 24);
@@ -299,7 +312,7 @@ static int build_model(const void* data, size_t nbytes, int ee_body, Ur5DevModel
     if (a < 0 || b < 0) continue;
     if (np >= UR5_MAXPAIR) return fail(UR5_ERR_MODEL, "too many collision pairs");
     if (D.g_type[a] > D.g_type[b]) { int t = a; a = b; b = t; }
-    D.pair_g1[np] = a; D.pair_g2[np] = b; np++;
+    D.pair_g1[np] = (ur5_pair_t)a; D.pair_g2[np] = (ur5_pair_t)b; np++;
   }
   D.npair = np;
   // ---- render model: every geom (collidable or not) with its pose relative to the engine body that carries it
@@ -393,6 +406,7 @@ struct SplitMix {
 
 // ======================================================================================================= handle + C ABI
 struct ur5_sim {
+  int variant = 0;   // 0: wavefront-per-scene engine (<= 6 objects), 1: many-object engine; first member in both translation units
   Ur5DevModel hm;
   Ur5DevModel* dm = nullptr;
   int n = 0, nvt = 0, device = 0, contacts_enabled = 1;
@@ -406,7 +420,7 @@ struct ur5_sim {
   float* d_depth = nullptr;
   size_t img_cap = 0;
   unsigned* d_mask = nullptr;
-  double *d_target = nullptr, *d_tol = nullptr, *d_debug = nullptr;
+  double *d_target = nullptr, *d_tol = nullptr, *d_debug = nullptr, *d_hess = nullptr;
   int *d_max = nullptr, *d_result = nullptr, *d_steps = nullptr, *d_ps = nullptr, *d_pr = nullptr;
   std::vector<double> h_rec;
   double last_ms = 0;
@@ -431,6 +445,7 @@ static Ur5Launch base_launch(ur5_sim* h, int op) {
   Ur5Launch P;
   memset(&P, 0, sizeof P);
   P.op = op; P.n_env = h->n; P.contacts_enabled = h->contacts_enabled; P.pid_dt = h->pid_dt; P.table_height = 0.91;
+  P.hess = h->d_hess;
 #ifdef UR5_PROFILE
   if (!h->d_debug) h->d_debug = (double*)be_alloc(h, (size_t)h->n * UR5_DEBUG_STRIDE * 8);
   P.debug = h->d_debug;
@@ -440,18 +455,60 @@ static Ur5Launch base_launch(ur5_sim* h, int op) {
 template <class T> static int upload(ur5_sim* h, T* dst, const T* src, size_t count) { return be_h2d(h, dst, src, count * sizeof(T)); }
 }  // namespace ur5host
 
+// One library, two engines: this header is compiled twice. The many-object translation unit (-DUR5_MANY, ur5sim_many.hip)
+// renames its entry points ur5_* -> ur5m_* (ur5_many_names.h); the small-scene unit owns the public names and forwards any
+// handle whose variant tag is 1 -- and ur5_create for models with more than 6 objects -- to them.
+#ifdef UR5_MANY
+#define UR5_FWD(name, args)
+#define UR5_FWD_VOID(name, args)
+#else
+#define UR5_FWD(name, args) if (h && h->variant == 1) { ur5host::g_err_many = true; return ur5m_##name args; }
+#define UR5_FWD_VOID(name, args) if (h && h->variant == 1) { ur5m_##name args; return; }
 extern "C" {
+int ur5m_create(const void* blob, size_t nbytes, int n_env, int device_id, const ur5_config* cfg, ur5_sim** out);
+const char* ur5m_last_error(void);
+void ur5m_destroy(ur5_sim* h);
+int ur5m_num_envs(const ur5_sim* h); int ur5m_nq(const ur5_sim* h); int ur5m_nv(const ur5_sim* h); int ur5m_nu(const ur5_sim* h);
+int ur5m_set_state(ur5_sim* h, const double* qpos, const double* qvel, const double* warm, const double* pid);
+int ur5m_get_state(ur5_sim* h, double* qpos, double* qvel, double* warm, double* pid);
+int ur5m_set_ctrl(ur5_sim* h, const double* ctrl); int ur5m_get_ctrl(ur5_sim* h, double* ctrl);
+int ur5m_get_counters(ur5_sim* h, int64_t* c);
+int ur5m_stay(ur5_sim* h, double ms); int ur5m_reset(ur5_sim* h, const uint64_t* seeds, int mode, double settle_ms); int ur5m_step(ur5_sim* h, int nsteps);
+int ur5m_move_group(ur5_sim* h, const uint32_t* mask, const double* target, const double* tol, const int* max_steps, int* result, int* steps);
+int ur5m_move_ee(ur5_sim* h, const double* xyz, const double* tol, const int* max_steps, int* result, int* steps);
+int ur5m_grasp_attempt_dev(ur5_sim* h, const double* action_dev, int check_mode, double table_height, int* reward_dev);
+int ur5m_grasp_attempt(ur5_sim* h, const double* action, int check_mode, double table_height, int* reward, int* phase_steps, int* phase_result);
+int ur5m_ik(ur5_sim* h, const double* xyz, double* q5, int* result);
+int ur5m_render_dev(ur5_sim* h, int camera_id, int width, int height, int depth_mode, uint8_t* rgb_dev, float* depth_dev);
+int ur5m_render(ur5_sim* h, int camera_id, int width, int height, int depth_mode, uint8_t* rgb, float* depth);
+int ur5m_sync(ur5_sim* h); double ur5m_last_launch_ms(ur5_sim* h); void* ur5m_state_device_ptr(ur5_sim* h);
+int ur5m_forward_debug(ur5_sim* h, double* out); int ur5m_body_xpos(ur5_sim* h, double* out); int ur5m_profile_read(ur5_sim* h, double* out);
+}
+#endif
+
+extern "C" {
+#ifdef UR5_MANY
 const char* ur5_last_error(void) { return ur5host::g_err.c_str(); }
+#else
+// the two translation units keep separate thread-local messages: report whichever was set last
+const char* ur5_last_error(void) { return ur5host::g_err_many ? ur5m_last_error() : ur5host::g_err.c_str(); }
+#endif
 
 int ur5_create(const void* blob, size_t nbytes, int n_env, int device_id, const ur5_config* cfg, ur5_sim** out) {
   using namespace ur5host;
   if (!blob || !out || !cfg || n_env <= 0) return fail(UR5_ERR_ARG, "ur5_create: bad arguments");
+#ifndef UR5_MANY
+  if (ur5host::count_objects(blob, nbytes) > UR5_MAXOBJ) { ur5host::g_err_many = true; return ur5m_create(blob, nbytes, n_env, device_id, cfg, out); }
+#endif
   ur5_sim* h = new ur5_sim();
   int rc = build_model(blob, nbytes, cfg->ee_body, &h->hm, &h->dev2model_geom, &h->hrm);
   if (rc) { delete h; return rc; }
   h->n = n_env; h->device = device_id; h->contacts_enabled = cfg->contacts_enabled;
   h->pid_dt = cfg->pid_dt > 0 ? cfg->pid_dt : h->hm.timestep;
   h->nvt = h->hm.nv <= 32 ? 32 : UR5_MAXNV;
+#ifdef UR5_MANY
+  h->variant = 1; h->nvt = UR5_MAXNV;
+#endif
   Blob B{(const char*)blob, nbytes};
   int nq;
   const double* q0 = B.F("qpos0", &nq);
@@ -465,6 +522,10 @@ int ur5_create(const void* blob, size_t nbytes, int n_env, int device_id, const 
   h->d_mask = (unsigned*)be_alloc(h, n * 4); h->d_target = (double*)be_alloc(h, n * 8 * 8); h->d_tol = (double*)be_alloc(h, n * 8);
   h->d_max = (int*)be_alloc(h, n * 4); h->d_result = (int*)be_alloc(h, n * 4); h->d_steps = (int*)be_alloc(h, n * 4);
   h->d_ps = (int*)be_alloc(h, n * 12 * 4); h->d_pr = (int*)be_alloc(h, n * 12 * 4);
+#ifdef UR5_MANY
+  h->d_hess = (double*)be_alloc(h, n * (size_t)UR5_HESS_STRIDE * 8);
+  if (!h->d_hess) { ur5_destroy(h); return fail(UR5_ERR_DEVICE, "device allocation failed (Hessian scratch)"); }
+#endif
   if (!h->dm || !h->d_rec || !h->d_mask || !h->d_target || !h->d_tol || !h->d_max || !h->d_result || !h->d_steps || !h->d_ps || !h->d_pr) {
     ur5_destroy(h);
     return fail(UR5_ERR_DEVICE, "device allocation failed");
@@ -489,18 +550,24 @@ int ur5_create(const void* blob, size_t nbytes, int n_env, int device_id, const 
 }
 
 void ur5_destroy(ur5_sim* h) {
+  UR5_FWD_VOID(destroy, (h));
   if (!h) return;
-  void* ptrs[] = {h->dm, h->d_rec, h->d_mask, h->d_target, h->d_tol, h->d_max, h->d_result, h->d_steps, h->d_ps, h->d_pr, h->d_debug, h->d_rm, h->d_rgb, h->d_depth};
+  void* ptrs[] = {h->dm, h->d_rec, h->d_mask, h->d_target, h->d_tol, h->d_max, h->d_result, h->d_steps, h->d_ps, h->d_pr, h->d_debug, h->d_rm, h->d_rgb, h->d_depth, h->d_hess};
   for (void* p : ptrs) if (p) be_free(h, p);
   be_close(h);
   delete h;
 }
-int ur5_num_envs(const ur5_sim* h) { return h->n; }
-int ur5_nq(const ur5_sim* h) { return h->hm.nq; }
-int ur5_nv(const ur5_sim* h) { return h->hm.nv; }
-int ur5_nu(const ur5_sim* h) { return h->hm.nu; }
+int ur5_num_envs(const ur5_sim* h) {
+  UR5_FWD(num_envs, (h)); return h->n; }
+int ur5_nq(const ur5_sim* h) {
+  UR5_FWD(nq, (h)); return h->hm.nq; }
+int ur5_nv(const ur5_sim* h) {
+  UR5_FWD(nv, (h)); return h->hm.nv; }
+int ur5_nu(const ur5_sim* h) {
+  UR5_FWD(nu, (h)); return h->hm.nu; }
 
 int ur5_set_state(ur5_sim* h, const double* qpos, const double* qvel, const double* warm, const double* pid) {
+  UR5_FWD(set_state, (h, qpos, qvel, warm, pid));
   using namespace ur5host;
   int rc = pull(h);
   if (rc) return rc;
@@ -518,6 +585,7 @@ int ur5_set_state(ur5_sim* h, const double* qpos, const double* qvel, const doub
   return push(h);
 }
 int ur5_get_state(ur5_sim* h, double* qpos, double* qvel, double* warm, double* pid) {
+  UR5_FWD(get_state, (h, qpos, qvel, warm, pid));
   using namespace ur5host;
   int rc = pull(h);
   if (rc) return rc;
@@ -535,6 +603,7 @@ int ur5_get_state(ur5_sim* h, double* qpos, double* qvel, double* warm, double* 
   return 0;
 }
 int ur5_set_ctrl(ur5_sim* h, const double* ctrl) {
+  UR5_FWD(set_ctrl, (h, ctrl));
   using namespace ur5host;
   int rc = pull(h);
   if (rc) return rc;
@@ -542,6 +611,7 @@ int ur5_set_ctrl(ur5_sim* h, const double* ctrl) {
   return push(h);
 }
 int ur5_get_ctrl(ur5_sim* h, double* ctrl) {
+  UR5_FWD(get_ctrl, (h, ctrl));
   using namespace ur5host;
   int rc = pull(h);
   if (rc) return rc;
@@ -549,6 +619,7 @@ int ur5_get_ctrl(ur5_sim* h, double* ctrl) {
   return 0;
 }
 int ur5_get_counters(ur5_sim* h, int64_t* c) {
+  UR5_FWD(get_counters, (h, c));
   using namespace ur5host;
   int rc = pull(h);
   if (rc) return rc;
@@ -560,6 +631,7 @@ int ur5_get_counters(ur5_sim* h, int64_t* c) {
 }
 
 int ur5_stay(ur5_sim* h, double ms) {
+  UR5_FWD(stay, (h, ms));
   using namespace ur5host;
   int chunks = (int)std::ceil(ms / 1000.0 / h->hm.timestep / 10.0 - 1e-9);
   std::vector<int> mx(h->n, chunks);
@@ -572,6 +644,7 @@ int ur5_stay(ur5_sim* h, double ms) {
 }
 
 int ur5_reset(ur5_sim* h, const uint64_t* seeds, int mode, double settle_ms) {
+  UR5_FWD(reset, (h, seeds, mode, settle_ms));
   using namespace ur5host;
   (void)mode;
   if (!seeds) return fail(UR5_ERR_ARG, "ur5_reset: seeds is NULL");
@@ -605,6 +678,7 @@ int ur5_reset(ur5_sim* h, const uint64_t* seeds, int mode, double settle_ms) {
 }
 
 int ur5_step(ur5_sim* h, int nsteps) {
+  UR5_FWD(step, (h, nsteps));
   using namespace ur5host;
   std::vector<int> mx(h->n, nsteps);
   int rc = upload(h, h->d_max, mx.data(), mx.size());
@@ -616,6 +690,7 @@ int ur5_step(ur5_sim* h, int nsteps) {
 }
 
 int ur5_move_group(ur5_sim* h, const uint32_t* mask, const double* target, const double* tol, const int* max_steps, int* result, int* steps) {
+  UR5_FWD(move_group, (h, mask, target, tol, max_steps, result, steps));
   using namespace ur5host;
   if (!mask || !tol || !max_steps) return fail(UR5_ERR_ARG, "ur5_move_group: mask/tol/max_steps are required");
   int rc = upload(h, h->d_mask, (const unsigned*)mask, (size_t)h->n);
@@ -634,6 +709,7 @@ int ur5_move_group(ur5_sim* h, const uint32_t* mask, const double* target, const
 }
 
 int ur5_move_ee(ur5_sim* h, const double* xyz, const double* tol, const int* max_steps, int* result, int* steps) {
+  UR5_FWD(move_ee, (h, xyz, tol, max_steps, result, steps));
   using namespace ur5host;
   if (!xyz || !tol || !max_steps) return fail(UR5_ERR_ARG, "ur5_move_ee: xyz/tol/max_steps are required");
   std::vector<double> t((size_t)h->n * 8, 0.0);
@@ -652,6 +728,7 @@ int ur5_move_ee(ur5_sim* h, const double* xyz, const double* tol, const int* max
 }
 
 int ur5_grasp_attempt_dev(ur5_sim* h, const double* action_dev, int check_mode, double table_height, int* reward_dev) {
+  UR5_FWD(grasp_attempt_dev, (h, action_dev, check_mode, table_height, reward_dev));
   using namespace ur5host;
   if (!action_dev || !reward_dev) return fail(UR5_ERR_ARG, "ur5_grasp_attempt_dev: NULL pointer");
   Ur5Launch P = base_launch(h, UR5_OP_GRASP);
@@ -660,6 +737,7 @@ int ur5_grasp_attempt_dev(ur5_sim* h, const double* action_dev, int check_mode, 
   return be_launch(h, P);
 }
 int ur5_grasp_attempt(ur5_sim* h, const double* action, int check_mode, double table_height, int* reward, int* phase_steps, int* phase_result) {
+  UR5_FWD(grasp_attempt, (h, action, check_mode, table_height, reward, phase_steps, phase_result));
   using namespace ur5host;
   if (!action || !reward) return fail(UR5_ERR_ARG, "ur5_grasp_attempt: action/reward are required");
   std::vector<double> t((size_t)h->n * 8, 0.0);
@@ -674,6 +752,7 @@ int ur5_grasp_attempt(ur5_sim* h, const double* action, int check_mode, double t
   return rc;
 }
 int ur5_ik(ur5_sim* h, const double* xyz, double* q5, int* result) {
+  UR5_FWD(ik, (h, xyz, q5, result));
   using namespace ur5host;
   if (!xyz || !q5) return fail(UR5_ERR_ARG, "ur5_ik: xyz/q5 are required");
   std::vector<double> t((size_t)h->n * 8, 0.0);
@@ -690,12 +769,14 @@ int ur5_ik(ur5_sim* h, const double* xyz, double* q5, int* result) {
   return rc;
 }
 int ur5_render_dev(ur5_sim* h, int camera_id, int width, int height, int depth_mode, uint8_t* rgb_dev, float* depth_dev) {
+  UR5_FWD(render_dev, (h, camera_id, width, height, depth_mode, rgb_dev, depth_dev));
   using namespace ur5host;
   if (!rgb_dev || !depth_dev || width <= 0 || height <= 0) return fail(UR5_ERR_ARG, "ur5_render_dev: bad arguments");
   if (camera_id < 0 || camera_id >= h->hrm.ncam) return fail(UR5_ERR_ARG, "ur5_render: unknown camera id");
   return be_render(h, camera_id, width, height, depth_mode, rgb_dev, depth_dev);
 }
 int ur5_render(ur5_sim* h, int camera_id, int width, int height, int depth_mode, uint8_t* rgb, float* depth) {
+  UR5_FWD(render, (h, camera_id, width, height, depth_mode, rgb, depth));
   using namespace ur5host;
   if (!rgb || !depth || width <= 0 || height <= 0) return fail(UR5_ERR_ARG, "ur5_render: bad arguments");
   size_t px = (size_t)h->n * width * height;
@@ -711,11 +792,15 @@ int ur5_render(ur5_sim* h, int camera_id, int width, int height, int depth_mode,
   if (!rc) rc = be_d2h(h, depth, h->d_depth, px * 4);
   return rc;
 }
-int ur5_sync(ur5_sim* h) { return be_sync(h); }
-double ur5_last_launch_ms(ur5_sim* h) { return h->last_ms; }
-void* ur5_state_device_ptr(ur5_sim* h) { return h->d_rec; }
+int ur5_sync(ur5_sim* h) {
+  UR5_FWD(sync, (h)); return be_sync(h); }
+double ur5_last_launch_ms(ur5_sim* h) {
+  UR5_FWD(last_launch_ms, (h)); return h->last_ms; }
+void* ur5_state_device_ptr(ur5_sim* h) {
+  UR5_FWD(state_device_ptr, (h)); return h->d_rec; }
 
 int ur5_forward_debug(ur5_sim* h, double* out) {
+  UR5_FWD(forward_debug, (h, out));
   using namespace ur5host;
   if (!h->d_debug) h->d_debug = (double*)be_alloc(h, (size_t)h->n * UR5_DEBUG_STRIDE * 8);
   if (!h->d_debug) return fail(UR5_ERR_DEVICE, "debug buffer allocation failed");
@@ -729,6 +814,7 @@ int ur5_forward_debug(ur5_sim* h, double* out) {
 #ifdef UR5_PROFILE
 // profile build only: per-env, per-phase cycle totals of the last launch ([n][16] host)
 int ur5_profile_read(ur5_sim* h, double* out) {
+  UR5_FWD(profile_read, (h, out));
   std::vector<double> dbg((size_t)h->n * UR5_DEBUG_STRIDE);
   int rc = be_d2h(h, dbg.data(), h->d_debug, dbg.size() * 8);
   if (rc) return rc;
@@ -737,6 +823,7 @@ int ur5_profile_read(ur5_sim* h, double* out) {
 }
 #endif
 int ur5_body_xpos(ur5_sim* h, double* out) {
+  UR5_FWD(body_xpos, (h, out));
   std::vector<double> dbg((size_t)h->n * UR5_DEBUG_STRIDE);
   int rc = ur5_forward_debug(h, dbg.data());
   if (rc) return rc;

@@ -16,6 +16,8 @@ DEFAULT_LIB = os.path.join(_HERE, "csrc", "libur5sim.so")
 
 RES_NONE, RES_SUCCESS, RES_MAX_STEPS, RES_IK_FAIL = -1, 0, 1, 2
 DEBUG_STRIDE, REC_STRIDE, MAXB = 2048, 192, 14
+# limits of the two engine variants (csrc/ur5_devmodel.h): (max objects, debug stride, record stride, max contacts)
+_VARIANT = {0: (6, 2048, 192, 30), 1: (40, 4096, 832, 160)}
 EXPORTS = ["ur5_last_error", "ur5_create", "ur5_destroy", "ur5_num_envs", "ur5_nq", "ur5_nv", "ur5_nu", "ur5_reset",
            "ur5_set_state", "ur5_get_state", "ur5_set_ctrl", "ur5_get_ctrl", "ur5_step", "ur5_move_group", "ur5_stay",
            "ur5_move_ee", "ur5_ik", "ur5_grasp_attempt", "ur5_grasp_attempt_dev", "ur5_sync", "ur5_last_launch_ms",
@@ -92,6 +94,7 @@ class BatchSim:
             raise RuntimeError(f"ur5_create failed ({rc}): {self.lib.ur5_last_error().decode()}")
         self._h = h
         self.nq, self.nv, self.nu = model.nq, model.nv, model.nu
+        self.variant = 1 if (model.nv - 8) // 6 > _VARIANT[0][0] else 0   # which engine of libur5sim.so serves this model
 
     def close(self):
         if getattr(self, "_h", None):
@@ -209,7 +212,7 @@ class BatchSim:
         return self.lib.ur5_state_device_ptr(self._h)
 
     def body_xpos(self):
-        out = np.zeros((self.n, MAXB, 3))
+        out = np.zeros((self.n, 8 + _VARIANT[self.variant][0], 3))
         self._check(self.lib.ur5_body_xpos(self._h, _dp(out)), "ur5_body_xpos")
         return out
 
@@ -226,9 +229,15 @@ class BatchSim:
                                             C.c_void_p(depth_ptr)), "ur5_render_dev")
 
     def forward_debug(self):
-        out = np.zeros((self.n, DEBUG_STRIDE))
+        maxobj, stride, _, maxcon = _VARIANT[self.variant]
+        mb, mv = 8 + maxobj, 8 + 6 * maxobj
+        out = np.zeros((self.n, stride))
         self._check(self.lib.ur5_forward_debug(self._h, _dp(out)), "ur5_forward_debug")
-        d = dict(ncon=out[:, 0].astype(int), nsr=out[:, 1].astype(int), bpos=out[:, 8:50].reshape(self.n, 14, 3),
-                 Mr=out[:, 50:114].reshape(self.n, 8, 8), qfrc_smooth=out[:, 114:158], qacc_smooth=out[:, 158:202],
-                 qacc=out[:, 202:246], contacts=out[:, 246:246 + 300].reshape(self.n, 30, 10))
+        o = 8
+        d = dict(ncon=out[:, 0].astype(int), nsr=out[:, 1].astype(int))
+        d["bpos"] = out[:, o:o + 3 * mb].reshape(self.n, mb, 3); o += 3 * mb
+        d["Mr"] = out[:, o:o + 64].reshape(self.n, 8, 8); o += 64
+        for k in ("qfrc_smooth", "qacc_smooth", "qacc"):
+            d[k] = out[:, o:o + mv]; o += mv
+        d["contacts"] = out[:, o:o + 10 * maxcon].reshape(self.n, maxcon, 10)
         return d

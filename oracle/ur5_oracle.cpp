@@ -1433,6 +1433,35 @@ struct Sim {
             t1 = std::min(t1, tf);
           }
           if (!miss && t0 <= t1 && t0 > 0) { t = t0; nl = V3(); nl[ax] = sg; }
+        } else if (type == GEOM_CYLINDER || type == GEOM_CAPSULE) {   // axis = local z, radius s.x, half length s.y
+          double r = s.x, hl = s.y, dd = dot(dl, dl);
+          double a = dl.x * dl.x + dl.y * dl.y, b = ol.x * dl.x + ol.y * dl.y, cc = ol.x * ol.x + ol.y * ol.y - r * r;
+          double ts0 = -1e300, ts1 = 1e300; bool miss = false;
+          if (a > 1e-15) { double disc = b * b - a * cc; if (disc < 0) miss = true; else { double sq = std::sqrt(disc); ts0 = (-b - sq) / a; ts1 = (-b + sq) / a; } }
+          else if (cc > 0) miss = true;
+          if (!miss && type == GEOM_CYLINDER) {
+            double tz0 = -1e300, tz1 = 1e300;
+            if (std::fabs(dl.z) > 1e-15) { double ta = (-hl - ol.z) / dl.z, tb = (hl - ol.z) / dl.z; tz0 = std::min(ta, tb); tz1 = std::max(ta, tb); }
+            else if (std::fabs(ol.z) > hl) miss = true;
+            double te = std::max(ts0, tz0), tx = std::min(ts1, tz1);
+            if (!miss && te <= tx && te > 0) {
+              t = te;
+              if (ts0 > tz0) { V3 p = ol + dl * t; nl = V3(p.x / r, p.y / r, 0); } else nl = V3(0, 0, dl.z > 0 ? -1.0 : 1.0);
+            }
+          } else if (type == GEOM_CAPSULE) {
+            double tb2 = 1e300;
+            if (!miss && a > 1e-15) { double z = ol.z + dl.z * ts0; if (std::fabs(z) <= hl && ts0 > 0) { tb2 = ts0; V3 p = ol + dl * ts0; nl = V3(p.x / r, p.y / r, 0); } }
+            for (int e = 0; e < 2; e++) {
+              double zc = e == 0 ? hl : -hl;
+              V3 oc(ol.x, ol.y, ol.z - zc);
+              double bs = dot(oc, dl), cs = dot(oc, oc) - r * r, disc = bs * bs - dd * cs;
+              if (disc < 0) continue;
+              double ts = (-bs - std::sqrt(disc)) / dd;
+              V3 p = oc + dl * ts;
+              if (ts > 0 && ts < tb2 && (e == 0 ? p.z >= 0 : p.z <= 0)) { tb2 = ts; nl = p * (1.0 / r); }
+            }
+            if (tb2 < 1e299) t = tb2;
+          }
         } else if (type == GEOM_MESH) {
           int k0 = M.vis_planeadr[M.geom_meshid[g]], kn = M.vis_planenum[M.geom_meshid[g]];
           double t0 = -1e300, t1 = 1e300; int kb = -1; bool miss = false;

@@ -2,6 +2,7 @@
 // each wavefront run sequentially on the host. Lets `pytest -m "not gpu"` exercise the kernel source against the oracle
 // without a GPU. Built into tests/emul/_build/ by tests/conftest.py; the package loader (mujoco_rl_ur5_amd/native.py)
 // only ever opens csrc/libur5sim.so, so this can never stand in for the HIP path.
+// Like the product library it is two translation units: this one (small scenes) and ur5sim_emul_many.cpp (-DUR5_MANY).
 #define UR5_EMUL 1
 #include <cstdlib>
 #include "../../mujoco_rl_ur5_amd/csrc/ur5_engine.h"
@@ -24,6 +25,9 @@ template <int NV> static void run_all(ur5_sim* h, const Ur5Launch& P) {
     ur5_emul_model = h->dm;
     ur5::Engine<double, NV> eng;
     eng.load(h->d_rec + (size_t)e * UR5_REC_STRIDE, P.pid_dt, P.contacts_enabled);
+#ifdef UR5_MANY
+    eng.set_hess(P.hess + (size_t)e * UR5_HESS_STRIDE);
+#endif
     eng.run(P, e);
     eng.save(h->d_rec + (size_t)e * UR5_REC_STRIDE);
   }
@@ -43,6 +47,10 @@ static int be_render(ur5_sim* h, int cam, int W, int Hh, int mode, uint8_t* rgb,
   return 0;
 }
 static int be_launch(ur5_sim* h, const Ur5Launch& P) {
+#ifdef UR5_MANY
+  run_all<UR5_MAXNV>(h, P);
+#else
   if (h->nvt == 32) run_all<32>(h, P); else run_all<UR5_MAXNV>(h, P);
+#endif
   return 0;
 }

@@ -72,6 +72,16 @@ def test_batched_env_and_make(model_it1, emul_lib):
     assert reward.shape == (2,) and set(np.unique(reward)) <= {0, 1}
 
 
-def test_default_many_object_scene_is_rejected_loudly(emul_lib):
-    with pytest.raises(RuntimeError, match="at most 6 per scene"):
-        GraspEnv(n_envs=1, _lib_path=emul_lib)
+def test_default_env_is_the_many_object_scene(emul_lib):
+    """GraspEnv() with no file argument is the reference's 40-object pile (GraspingEnv.py:28); libur5sim serves it with its
+    many-object engine variant behind the same entry points."""
+    e = GraspEnv(n_envs=1, show_obs=False, observation="flat", _lib_path=emul_lib)
+    assert e.sim.variant == 1 and e.model.nv == 248 and e.sim.nq == 288
+    obs = e.reset()
+    assert obs["depth"].shape == (200, 200) and obs["rgb"].shape == (200, 200, 3)
+    z = e.sim.get_state()["qpos"][0][8:].reshape(-1, 7)[:, 2]
+    assert (z < 1.2).all() and (z > 0.6).all()                       # the pile has dropped into the bin (floor 0.89) or beside it
+    c = e.sim.counters()
+    assert c["status"][0] == 0 and 5 < c["ncon_max"][0] < 160
+    r = e.controller.move_group_to_joint_target(group="Gripper", target=[0.2], tolerance=0.05, max_steps=200, quiet=True)
+    assert r == "success"

@@ -1,0 +1,101 @@
+"""The many-object engine variant (csrc/ur5sim_many.hip, UR5gripper_2_finger_many_objects.xml: 40 free objects, condim 6,
+nv = 248) against the oracle: lane-emulation build on CPU, the real kernel with -m gpu.
+
+Parity horizon: piles of cylinders / capsules resting on single MPR contacts are chaotic, and MPR itself is discontinuous at
+its 1e-6 tolerance (a 1e-14 state difference can flip a portal step and move a normal by 5e-3), so trajectories are compared
+over the first contacts of the drop (tens of steps, 1e-9) and statistically afterwards.
+"""
+import numpy as np
+import pytest
+
+from mujoco_rl_ur5_amd.model import load_model
+from mujoco_rl_ur5_amd.native import BatchSim
+from oracle.oracle import Oracle, lib as olib
+
+MANY = "/UR5+gripper/UR5gripper_2_finger_many_objects.xml"
+
+
+@pytest.fixture(scope="module")
+def model_many():
+    return load_model(MANY)
+
+
+def _drop_parity(model, sim, scene, seed, nsteps, tol):
+    o = Oracle(model)
+    o.reset(seed, 1, False)
+    assert np.array_equal(o.get_state()["qpos"], sim.get_state()["qpos"][scene])   # same reset distribution (GraspingEnv.py:420-430)
+    worst, contacts_seen = 0.0, 0
+    for k in range(nsteps):
+        o.step(1)
+        sim.step(1)
+        contacts_seen = max(contacts_seen, olib().ur5o_ncon(o._h))
+        a, b = o.get_state(), sim.get_state()
+        worst = max(worst, np.abs(a["qpos"] - b["qpos"][scene]).max(), 1e-2 * np.abs(a["qvel"] - b["qvel"][scene]).max())
+    assert contacts_seen >= 2                                        # the comparison window does contain contacts
+    assert worst < tol, worst
+
+
+def test_drop_matches_oracle_emul(model_many, emul_lib):
+    sim = BatchSim(model_many, 1, lib_path=emul_lib)
+    sim.reset([20], 1, 0.0)
+    _drop_parity(model_many, sim, 0, 20, 30, 1e-9)
+
+
+def test_forward_quantities_match_oracle_in_a_settled_pile(model_many, emul_lib):
+    """After 0.6 s the pile is dense (30+ contacts, coupled bodies): one forward pass of both from the SAME state must agree on
+    contacts and on the constrained acceleration (envelope Cholesky vs the oracle's dense Newton)."""
+    sim = BatchSim(model_many, 1, lib_path=emul_lib)
+    sim.reset([21], 1, 0.0)
+    sim.step(300)
+    st = sim.get_state()
+    o = Oracle(model_many)
+    o.set_state(qpos=st["qpos"][0], qvel=st["qvel"][0], warmstart=st["warmstart"][0], pid=st["pid"][0])
+    o.forward()
+    d = sim.forward_debug()
+    oc = o.contacts()
+    assert d["ncon"][0] == len(oc) and len(oc) >= 20
+    ec = d["contacts"][0][:len(oc)]
+    for c in oc:                                                      # contact order differs (pair order vs slot claiming)
+        best = min(ec, key=lambda e: np.abs(e[1:4] - c[1:4]).sum())
+        assert np.abs(best[1:4] - c[1:4]).max() < 1e-9 and np.abs(best[4:7] - c[4:7]).max() < 1e-9 and abs(best[0] - c[0]) < 1e-9
+    qacc = o.vec("qacc")
+    assert np.abs(d["qacc"][0][:model_many.nv] - qacc).max() < 1e-6 * max(1.0, np.abs(qacc).max())
+    assert sim.counters()["status"][0] == 0
+
+
+def test_render_with_cylinders_and_capsules(model_many, emul_lib):
+    sim = BatchSim(model_many, 1, lib_path=emul_lib)
+    sim.reset([20], 1, 0.0)
+    sim.step(300)
+    st = sim.get_state()
+    o = Oracle(model_many)
+    o.set_state(qpos=st["qpos"][0], qvel=st["qvel"][0])
+    cam = model_many.camera_name2id("top_down")
+    rgb, depth = sim.render(cam, 120, 120, 0)
+    rgbo, deptho = o.render(cam, 120, 120, 0)
+    assert (np.abs(depth[0] - deptho) > 1e-4).mean() < 2e-3           # fp32 vs fp64: a few grazing-ray pixels on edge-on plates
+    assert (np.abs(rgb[0].astype(int) - rgbo.astype(int)).max(axis=2) > 2).mean() < 4e-3
+
+
+@pytest.mark.gpu
+def test_many_object_kernel_matches_oracle(model_many):
+    import torch
+    assert torch.cuda.is_available()
+    sim = BatchSim(model_many, 4)
+    assert sim.variant == 1
+    sim.reset(20 + np.arange(4, dtype=np.uint64), 1, 0.0)
+    _drop_parity(model_many, sim, 2, 22, 30, 1e-9)
+
+
+@pytest.mark.gpu
+def test_many_object_kernel_settles_piles(model_many):
+    sim = BatchSim(model_many, 64)
+    sim.reset(100 + np.arange(64, dtype=np.uint64), 1, 1000.0)         # reset_model: drop + stay(1000), GraspingEnv.py:473
+    c = sim.counters()
+    st = sim.get_state()
+    z = st["qpos"][:, 8:].reshape(64, -1, 7)[:, :, 2]
+    assert (c["status"] == 0).all() and (c["total_steps"] == 491).all()
+    assert np.isfinite(st["qpos"]).all() and (z > -0.01).all() and (z < 1.25).all()   # objects that miss the bins lie on the ground
+    assert (c["ncon_max"] > 20).all() and (c["ncon_max"] < 160).all()
+    r, steps = sim.move_group(1 << 6, [[0.2]], 0.05, 300)             # the gripper still obeys its PID with the pile present
+    assert (r == 0).all()

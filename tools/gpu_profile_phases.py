@@ -6,8 +6,9 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from mujoco_rl_ur5_amd.model import load_model
 from mujoco_rl_ur5_amd.native import BatchSim
 NAMES = ["kin", "crb", "vel", "broad", "narrow", "rows", "newton_init", "images", "linesearch", "grad+G", "H_asm", "chol", "solve", "integrate", "pid", "ik"]
-m = load_model("it1_4box")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+MANY = len(sys.argv) > 2 and sys.argv[2] == "many"        # the 40-object pile (many-object engine variant)
+m = load_model("/UR5+gripper/UR5gripper_2_finger_many_objects.xml" if MANY else "it1_4box")
 sim = BatchSim(m, n, lib_path=os.environ.get("UR5_PROF_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), "libur5sim_prof.so")))
 sim.lib.ur5_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
 def read():
@@ -19,6 +20,8 @@ steps = c0["total_steps"].astype(float)
 print("settle: kernel %.1f ms, %d steps/env; cycles per step by phase (mean over envs):" % (sim.last_launch_ms(), steps[0]))
 for k, nm in enumerate(NAMES): print("  %-12s %10.0f" % (nm, (p[:, k] / steps).mean()))
 print("  %-12s %10.0f  (wall: %.0f cycles/step @2.4GHz)" % ("sum", (p.sum(1) / steps).mean(), sim.last_launch_ms() * 1e-3 * 2.4e9 / steps[0]))
+if MANY:
+    sys.exit(0)
 st = sim.get_state(); acts = np.zeros((n, 3))
 for e in range(n):
     objs = st["qpos"][e][8:].reshape(-1, 7); k = e % 4
