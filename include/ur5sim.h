@@ -74,9 +74,11 @@ int ur5_grasp_attempt_dev(ur5_sim* h, const double* action_dev, int check_mode, 
 int ur5_sync(ur5_sim* h);
 /* duration of the last launch in ms, from HIP events recorded on the handle's stream around the kernel */
 double ur5_last_launch_ms(ur5_sim* h);
-/* counters[n][5] host: total physics steps, last_movement_steps, status bits, Newton iterations, max contacts seen in a step */
+/* counters[n][6] host: total physics steps, last_movement_steps, status bits, Newton iterations, max contacts seen in a step,
+   Newton iterations that reused the previous Cholesky factor (many-object engine; 0 otherwise) */
 int ur5_get_counters(ur5_sim* h, int64_t* counters);
-/* world positions of the engine's bodies [n][14][3]: 8 robot weld groups (dof order) then the objects */
+/* world positions of the engine's bodies [n][8 + max objects][3] (max objects: 6, or 40 for many-object models):
+   8 robot weld groups (dof order) then the objects */
 int ur5_body_xpos(ur5_sim* h, double* out);
 /* RGB-D image of every scene from model camera `camera_id` (1 = "top_down" in the reference's files): rgb[n][h][w][3] uint8,
  * depth[n][h][w] float32, already in the orientation get_image_data returns (both flips applied). depth_mode 0 = metres along

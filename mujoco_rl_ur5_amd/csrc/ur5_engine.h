@@ -29,6 +29,7 @@
 #define UR5_BIG inline
 #define UR5_CALL inline
 #define UR5_ATOMIC_ADD(p, v) (*(p) += (v))
+#define UR5_ATOMIC_MAX(p, v) (*(p) = *(p) > (v) ? *(p) : (v))
 #define UR5_MPR_ATTR inline
 #define UR5_BOXBOX_ATTR inline
 static void* ur5_emul_lds = nullptr;
@@ -46,6 +47,7 @@ static const Ur5DevModel* ur5_emul_model = nullptr;
 #define UR5_BIG __device__ __forceinline__  // phase routines: the interpreter in run() calls each of them from one place
 #define UR5_CALL __device__ __noinline__    // small helpers with many call sites: kept as real functions
 #define UR5_ATOMIC_ADD(p, v) __hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define UR5_ATOMIC_MAX(p, v) __hip_atomic_fetch_max((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #ifndef UR5_MPR_ATTR
 #define UR5_MPR_ATTR UR5_BIG
 #endif
@@ -213,10 +215,13 @@ template <class real, int NV_> struct Lds {
   double* hess;
   int env_first[NV_], env_ptr[NV_ + 1];              // first stored column of a row, offset of the row
   short obj_rank[UR5_MAXOBJ], obj_at[UR5_MAXOBJ];   // sorted position of an object and back
+  int island[UR5_MAXOBJ + 1];                        // island label of object k / of the robot (index nobj)
   short blk_first[UR5_MAXOBJ + 1], blk_last[UR5_MAXOBJ + 1];   // per block (sorted position; robot = block nobj): first coupled block, last block reaching it
   double henv[UR5_HENV_CAP];                         // the envelope itself when it fits (it does for settled 40-object piles)
-  int env_inlds, nseq, nreach;
-  short rowlist[NV_];                                // rows below the current panel that reach it
+  int env_inlds, nseq, act_changed, nskip;
+  short reach_ptr[UR5_MAXOBJ + 2], reach_list[(UR5_MAXOBJ + 1) * UR5_MAXOBJ / 2];   // per panel: the blocks below it whose rows reach it
+  unsigned short cact[UR5_MAXCON];                   // active-row signature of every contact at the previous Newton iteration
+  int sr_act[UR5_MAXSR];
   real dcache[UR5_MAXOBJ + 1][44];                   // factored diagonal blocks, packed lower triangle + 1/diagonal
   short seq[UR5_MAXOBJ + 1];                         // blocks that take part in the sequential factorisation (the others are uncoupled)
   real red[3 * 16];                                  // cross-wave reductions
@@ -309,6 +314,9 @@ template <class real, int NV_> struct Engine {
     PAR(i, UR5_REC_STRIDE) S.rec[i] = (real)rec[i];
     if (UR5_LANE == 0) { S.pid_dt = dt; S.contacts_enabled = con; S.last_steps = 0; S.total_steps = 0; }
     if (UR5_LANE == 0) { S.status = 0; S.solver_iters = 0; S.ncon_max = 0; S.ncon = 0; S.nsr = 0; }
+#ifdef UR5_MANY
+    if (UR5_LANE == 0) { S.nskip = 0; S.act_changed = 1; }
+#endif
 #if defined(UR5_PROFILE) && !defined(UR5_EMUL)
     if (UR5_LANE == 0) for (int i = 0; i < PF_COUNT; i++) S.prof[i] = 0;
 #endif
@@ -326,6 +334,9 @@ template <class real, int NV_> struct Engine {
       S.rec[UR5_REC_MISC + 3] = (real)S.status;
       S.rec[UR5_REC_MISC + 4] += (real)S.solver_iters;
       S.rec[UR5_REC_MISC + 5] = maxv(S.rec[UR5_REC_MISC + 5], (real)S.ncon_max);
+#ifdef UR5_MANY
+      S.rec[UR5_REC_MISC + 6] += (real)S.nskip;   // Newton iterations that reused the previous factor
+#endif
     }
     SYNC();
     PAR(i, UR5_REC_STRIDE) rec[i] = (double)S.rec[i];
@@ -1355,7 +1366,28 @@ template <class real, int NV_> struct Engine {
     // per-body wrench (gradient) and 6x6 twist-space Hessian accumulators: every contact lane scatters its two sides with
     // LDS float atomics (ds_add_f64). Only this wavefront touches these words, so the sums are reproducible run to run.
     PAR(idx, nslot() * 27) { int b = idx / 27, ent = idx % 27; if (ent < 6) S.WB[b][ent] = 0; else S.G[b][ent - 6] = 0; }
+#ifdef UR5_MANY
+    // The Newton Hessian depends on the iterate only through the SET of active rows (D is fixed within a step), so it is
+    // piecewise constant: when no row changed state since the previous iteration, the factor in LDS is still the factor
+    // of H and assembly + factorisation are skipped (MuJoCo's Newton updates its factor incrementally for the same reason).
+    PAR(c, S.ncon) {
+      const real e0 = S.ce[c][0];
+      unsigned mask = 0;
+      if (S.cdim[c] == 1) mask = e0 < 0 ? 1u : 0u;
+      else for (int k = 1; k < S.cdim[c]; k++) { real ek = row_mu(c, k) * S.ce[c][k]; mask |= (e0 + ek < 0 ? 1u : 0u) << (2 * k) | (e0 - ek < 0 ? 2u : 0u) << (2 * k); }
+      if (mask != S.cact[c]) { S.cact[c] = (unsigned short)mask; S.act_changed = 1; }
+    }
+    PAR(s2, S.nsr) {
+      const int on = !(S.sr_uni[s2] && S.sr_jar[s2] >= 0);
+      if (on != S.sr_act[s2]) { S.sr_act[s2] = on; S.act_changed = 1; }
+    }
+#endif
     SYNC();
+#ifdef UR5_MANY
+    const bool refactor = S.act_changed != 0;
+#else
+    const bool refactor = true;
+#endif
     PAR(c, S.ncon) {
       v3 ax[3] = {v3(S.cframe[c]), v3(S.cframe[c] + 3), cross(v3(S.cframe[c]), v3(S.cframe[c] + 3))};
       real fb[NB], w[2 * NB - 1];
@@ -1382,6 +1414,7 @@ template <class real, int NV_> struct Engine {
           Fk[k][0] = ra.x; Fk[k][1] = ra.y; Fk[k][2] = ra.z; Fk[k][3] = ax[k].x; Fk[k][4] = ax[k].y; Fk[k][5] = ax[k].z;
           if (3 + k < NB) { Fk[3 + k][0] = ax[k].x; Fk[3 + k][1] = ax[k].y; Fk[3 + k][2] = ax[k].z; Fk[3 + k][3] = 0; Fk[3 + k][4] = 0; Fk[3 + k][5] = 0; }
         }
+        if (!refactor) continue;
         int ent = 0;
         for (int gi = 0; gi < 6; gi++)
           for (int gj = 0; gj <= gi; gj++, ent++) {
@@ -1415,13 +1448,13 @@ template <class real, int NV_> struct Engine {
     }
     PROF(PF_GRADG);
 #ifdef UR5_MANY
+    if (UR5_LANE == 0) { S.act_changed = 0; if (!refactor) S.nskip++; }   // every lane read the flag before the barrier above
+    PAR(i, M.nv) S.Mv[pdof(i)] = S.grad[i];   // right-hand side in permuted order
     if (S.env_inlds) {
-      envelope_assemble<true>(); PROF(PF_HASM);
-      envelope_factor<true>(); PROF(PF_CHOL);
+      if (refactor) { envelope_assemble<true>(); PROF(PF_HASM); envelope_factor<true>(); PROF(PF_CHOL); }
       envelope_solve<true>(); PROF(PF_SOLVE);
     } else {
-      envelope_assemble<false>(); PROF(PF_HASM);
-      envelope_factor<false>(); PROF(PF_CHOL);
+      if (refactor) { envelope_assemble<false>(); PROF(PF_HASM); envelope_factor<false>(); PROF(PF_CHOL); }
       envelope_solve<false>(); PROF(PF_SOLVE);
     }
     return;
@@ -1663,10 +1696,29 @@ template <class real, int NV_> struct Engine {
   UR5_BIG void envelope_structure() {
     static_assert(UR5_NT >= UR5_MAXNV, "one thread per Hessian row");
     const int nobj = M.nobj, nblk = nobj + 1, nv = M.nv;
-    PAR(k, nobj) {
+    // islands of the coupling graph by label propagation (label = largest member; the robot counts as member nobj, so its
+    // island sorts last and the robot block stays the last block). A fixed number of rounds: if an island is not fully
+    // labelled the ordering is merely less compact -- the envelope below is computed from whatever order results.
+    PAR(p2, nblk) S.island[p2] = p2;
+    SYNC();
+    for (int round = 0; round < 6; round++) {
+      PAR(q, S.ncouple) {
+        const int c = S.couple[q];
+        const int ia = S.cA[c] < M.nrd ? nobj : S.cA[c] - M.nrd, ib = S.cB[c] < M.nrd ? nobj : S.cB[c] - M.nrd;
+        const int la = S.island[ia], lb = S.island[ib];
+        if (la < lb) UR5_ATOMIC_MAX(&S.island[ia], lb); else if (lb < la) UR5_ATOMIC_MAX(&S.island[ib], la);
+      }
+      SYNC();
+    }
+    PAR(k, nobj) {   // order: island, then x
       const real key = S.bpos[M.nrd + k][0];
+      const int lab = S.island[k];
       int r = 0;
-      for (int j = 0; j < nobj; j++) { real kj = S.bpos[M.nrd + j][0]; if (kj < key || (kj == key && j < k)) r++; }
+      for (int j = 0; j < nobj; j++) {
+        const real kj = S.bpos[M.nrd + j][0];
+        const int lj = S.island[j];
+        if (lj < lab || (lj == lab && (kj < key || (kj == key && j < k)))) r++;
+      }
       S.obj_rank[k] = (short)r; S.obj_at[r] = (short)k;
     }
     PAR(p2, nblk) S.blk_first[p2] = (short)p2;
@@ -1680,7 +1732,11 @@ template <class real, int NV_> struct Engine {
       }
     }
     SYNC();
-    PAR(p2, nblk) { int last = p2; for (int q = p2 + 1; q < nblk; q++) if (S.blk_first[q] <= p2) last = q; S.blk_last[p2] = (short)last; }
+    PAR(p2, nblk) {   // blocks below p2 whose rows reach it (their envelope starts at or before it)
+      int last = p2, cnt = 0;
+      for (int q = p2 + 1; q < nblk; q++) if (S.blk_first[q] <= p2) { last = q; cnt++; }
+      S.blk_last[p2] = (short)last; S.reach_ptr[p2 + 1] = (short)cnt;
+    }
     PAR(i, nv) S.env_first[i] = 6 * S.blk_first[i < 6 * nobj ? i / 6 : nobj];
     SYNC();
     if (UR5_LANE == 0) {
@@ -1688,18 +1744,31 @@ template <class real, int NV_> struct Engine {
       for (int i = 0; i < nv; i++) { S.env_ptr[i] = o; o += i - S.env_first[i] + 1; }
       S.env_ptr[nv] = o;
       S.env_inlds = o <= UR5_HENV_CAP;
-      int ns = 0;   // blocks that take part in the sequential factorisation: they reach an earlier block or are reached by a later one
-      for (int p2 = 0; p2 < nblk; p2++) if (S.blk_first[p2] != p2 || S.blk_last[p2] != p2) S.seq[ns++] = (short)p2;
+      int ns = 0;   // panels of the sequential sweep: only blocks that some later block reaches
+      for (int p2 = 0; p2 < nblk; p2++) if (S.blk_last[p2] != p2) S.seq[ns++] = (short)p2;
       S.nseq = ns;
+      S.reach_ptr[0] = 0;
+      for (int p2 = 0; p2 < nblk; p2++) S.reach_ptr[p2 + 1] = (short)(S.reach_ptr[p2 + 1] + S.reach_ptr[p2]);
     }
     SYNC();
+    PAR(p2, nblk) { int o = S.reach_ptr[p2]; for (int q = p2 + 1; q <= S.blk_last[p2]; q++) if (S.blk_first[q] <= p2) S.reach_list[o++] = (short)q; }
+    SYNC();
   }
+  // row number c (0 .. nr-1) among the rows below panel p2 that reach it; nrb = number of reaching blocks (only the last can be the 8-wide robot)
+  UR5_FN int reach_row(int p2, int nrb, int c) const {
+    int bl = c / 6;
+    bl = bl < nrb - 1 ? bl : nrb - 1;
+    return 6 * S.reach_list[S.reach_ptr[p2] + bl] + (c - 6 * bl);
+  }
+  UR5_FN int reach_rows(int p2, int nrb) const { return nrb == 0 ? 0 : 6 * (nrb - 1) + blk_width(S.reach_list[S.reach_ptr[p2] + nrb - 1]); }
   UR5_FN bool blk_single(int p2) const { return S.blk_first[p2] == p2 && S.blk_last[p2] == p2; }
+  // reaches earlier blocks, reached by none: factored / solved after (forward) resp. before (backward) the sequential sweep,
+  // all such blocks at once -- their column ranges cannot overlap
+  UR5_FN bool blk_terminal(int p2) const { return S.blk_first[p2] != p2 && S.blk_last[p2] == p2; }
   template <bool INLDS> UR5_BIG void envelope_assemble() {
     const int tot = S.env_ptr[M.nv];
     double* const hb = INLDS ? S.henv : S.hess;
     PAR(idx, tot) hb[idx] = 0;
-    PAR(i, M.nv) S.Mv[pdof(i)] = S.grad[i];   // right-hand side in permuted order
     SYNC();
     PAR(idx, M.nrd * M.nrd) {   // robot block: Mr + sum_b cdof^T G_b cdof + equality / limit rows
       int d = idx / M.nrd, e = idx % M.nrd;
@@ -1778,7 +1847,13 @@ template <class real, int NV_> struct Engine {
 #pragma unroll
       for (int k = 0; k < j; k++) dj -= d.l[j][k] * d.l[j][k];
       dj = dj < (real)1e-15 ? (real)1e-15 : dj;
+#ifdef UR5_EMUL
       const real sq = sqrt(dj), inv = (real)1 / sq;
+#else
+      real inv = rsqrt(dj);                                          // this chain is the critical path of a panel:
+      inv = inv * ((real)1.5 - (real)0.5 * dj * inv * inv);          // rsqrt + one Newton step instead of sqrt and a division
+      const real sq = dj * inv;
+#endif
       d.l[j][j] = sq; d.inv[j] = inv;
 #pragma unroll
       for (int a = j + 1; a < W; a++) {
@@ -1842,7 +1917,8 @@ template <class real, int NV_> struct Engine {
   }
   template <bool INLDS, int W> UR5_FN void factor_panel_row(int i, int ii, int p2, int c0) {
     Diag<W> d;
-    diag_factor<INLDS, W>(c0, d);
+    const bool prefactored = S.blk_first[p2] == p2;
+    if (prefactored) diag_cached<W>(p2, d); else diag_factor<INLDS, W>(c0, d);
     real out[W];
     if (ii < W) {
 #pragma unroll
@@ -1852,7 +1928,7 @@ template <class real, int NV_> struct Engine {
         for (int a = 0; a < W; a++) if (a == ii && k <= a) v = d.l[a][k];
         out[k] = v;
       }
-      if (ii == 0) diag_store<W>(p2, d);
+      if (ii == 0 && !prefactored) diag_store<W>(p2, d);
     } else {
       const double* row = hptr<INLDS>(i, c0);
 #pragma unroll
@@ -1867,51 +1943,45 @@ template <class real, int NV_> struct Engine {
     for (int k = 0; k < W; k++) S.panel[i][k] = out[k];
   }
   template <bool INLDS> UR5_BIG void envelope_factor() {
+    // a block that reaches no earlier block gets no trailing update: its diagonal block is final after assembly, so all
+    // of these (the uncoupled blocks among them) are factored at once, ahead of the sequential sweep
     PAR(i, M.nv) {
       const int p2 = i < 6 * M.nobj ? i / 6 : M.nobj;
-      if (!blk_single(p2)) continue;
+      if (S.blk_first[p2] != p2) continue;
       if (p2 < M.nobj) factor_single_row<INLDS, 6>(i, p2); else factor_single_row<INLDS, UR5_MAXRD>(i, p2);
     }
+    SYNC();
     for (int q = 0; q < S.nseq; q++) {
       const int p2 = S.seq[q];
       const int c0 = 6 * p2, w = blk_width(p2);
-      const int lastb = S.blk_last[p2], rlast = 6 * lastb + blk_width(lastb);   // one past the last row that reaches this panel
-      // A1: every reaching row computes its entries of the block column (LDS panel); H is only read
-      PAR(ii, rlast - c0) {
-        const int i = c0 + ii;
-        if (S.env_first[i] > c0) continue;
-        if (p2 < M.nobj) factor_panel_row<INLDS, 6>(i, ii, p2, c0); else factor_panel_row<INLDS, UR5_MAXRD>(i, ii, p2, c0);
-        if (ii >= w) {   // compact list of the reaching rows below the block (its position = reaching rows before it)
-          int pos = 0;
-          const int bi = i < 6 * M.nobj ? i / 6 : M.nobj;
-          for (int qb = p2 + 1; qb < bi; qb++) if (S.blk_first[qb] <= p2) pos += 6;
-          pos += i - 6 * bi;
-          S.rowlist[pos] = (short)i;
-        }
-      }
-      if (UR5_LANE == 0) {
-        int cnt = 0;
-        for (int qb = p2 + 1; qb <= lastb; qb++) if (S.blk_first[qb] <= p2) cnt += blk_width(qb);
-        S.nreach = cnt;
+      const int nrb = S.reach_ptr[p2 + 1] - S.reach_ptr[p2], nr = reach_rows(p2, nrb);
+      // A1: the block's own rows and every reaching row compute their entries of the block column (LDS panel); H is only read
+      PAR(t, w + nr) {
+        const int i = t < w ? c0 + t : reach_row(p2, nrb, t - w);
+        if (p2 < M.nobj) factor_panel_row<INLDS, 6>(i, t, p2, c0); else factor_panel_row<INLDS, UR5_MAXRD>(i, t, p2, c0);
       }
       SYNC();
       // A2: the finished column entries of the rows below go back to H (the block itself lives on in dcache);
       // B: trailing update of every pair of reaching rows below the block
-      const int nr = S.nreach;
-      PAR(ii, nr) {
-        const int i = S.rowlist[ii];
+      PAR(c, nr) {
+        const int i = reach_row(p2, nrb, c);
         double* row = hptr<INLDS>(i, c0);
         for (int k = 0; k < w; k++) row[k] = (double)S.panel[i][k];
       }
       PAR(idx, nr * nr) {
         const int ii = idx / nr, jj = idx - ii * nr;
         if (jj > ii) continue;
-        const int i = S.rowlist[ii], j = S.rowlist[jj];
+        const int i = reach_row(p2, nrb, ii), j = reach_row(p2, nrb, jj);
         real sacc = 0;
         for (int k = 0; k < w; k++) sacc += S.panel[i][k] * S.panel[j][k];
         *hptr<INLDS>(i, j) -= (double)sacc;
       }
       SYNC();
+    }
+    PAR(i, M.nv) {   // terminal blocks: every trailing update has landed
+      const int p2 = i < 6 * M.nobj ? i / 6 : M.nobj;
+      if (!blk_terminal(p2)) continue;
+      if (p2 < M.nobj) factor_single_row<INLDS, 6>(i, p2); else factor_single_row<INLDS, UR5_MAXRD>(i, p2);
     }
   }
   // S.search = -H^-1 grad with the factor in place: b = S.Mv (permuted right-hand side, consumed), y = S.tmpv
@@ -1925,6 +1995,19 @@ template <class real, int NV_> struct Engine {
     fwd_blk<W>(d, t);
     bwd_blk<W>(d, t);
     S.search[edof(i)] = -pick<W>(t, i - c0);
+  }
+  template <int W> UR5_FN void terminal_fwd_bwd(int i, int p2, const real* b, real* y) {
+    const int c0 = 6 * p2;
+    Diag<W> d;
+    diag_cached<W>(p2, d);
+    real t[W];
+#pragma unroll
+    for (int k = 0; k < W; k++) t[k] = b[c0 + k];
+    fwd_blk<W>(d, t);
+    bwd_blk<W>(d, t);
+    const real xi = pick<W>(t, i - c0);
+    S.search[edof(i)] = -xi;
+    y[i] = xi;   // x of the block, for the update of the columns to its left
   }
   template <bool INLDS, int W> UR5_FN void fwd_panel_row(int i, int ii, int p2, int c0, real* b, real* y) {
     Diag<W> d;
@@ -1969,15 +2052,32 @@ template <class real, int NV_> struct Engine {
     }
     for (int q = 0; q < S.nseq; q++) {   // forward, column-oriented: y_blk = L_pp^-1 b_blk, then b_i -= L_i,blk y_blk for the rows below
       const int p2 = S.seq[q];
-      const int c0 = 6 * p2;
-      const int lastb = S.blk_last[p2], rlast = 6 * lastb + blk_width(lastb);
-      PAR(ii, rlast - c0) {
-        const int i = c0 + ii;
-        if (S.env_first[i] > c0) continue;
-        if (p2 < M.nobj) fwd_panel_row<INLDS, 6>(i, ii, p2, c0, b, y); else fwd_panel_row<INLDS, UR5_MAXRD>(i, ii, p2, c0, b, y);
+      const int c0 = 6 * p2, w = blk_width(p2);
+      const int nrb = S.reach_ptr[p2 + 1] - S.reach_ptr[p2], nr = reach_rows(p2, nrb);
+      PAR(t, w + nr) {
+        const int i = t < w ? c0 + t : reach_row(p2, nrb, t - w);
+        if (p2 < M.nobj) fwd_panel_row<INLDS, 6>(i, t, p2, c0, b, y); else fwd_panel_row<INLDS, UR5_MAXRD>(i, t, p2, c0, b, y);
       }
       SYNC();
     }
+    PAR(t, M.nv) {   // terminal blocks: forward and backward substitution inside the block, then their share of y to the left
+      const int p2 = t < 6 * M.nobj ? t / 6 : M.nobj;
+      if (!blk_terminal(p2)) continue;
+      if (p2 < M.nobj) terminal_fwd_bwd<6>(t, p2, b, y); else terminal_fwd_bwd<UR5_MAXRD>(t, p2, b, y);
+    }
+    SYNC();
+    PAR(j, M.nv) {   // y_j -= L_blk,j^T x_blk for the columns j left of a terminal block (x_blk was left in y)
+      const int pj = j < 6 * M.nobj ? j / 6 : M.nobj;
+      for (int o = S.reach_ptr[pj]; o < S.reach_ptr[pj + 1]; o++) {   // the blocks whose rows reach column block pj
+        const int p2 = S.reach_list[o];
+        if (!blk_terminal(p2)) continue;
+        const int c0 = 6 * p2, w = blk_width(p2);
+        real sacc = 0;
+        for (int k = 0; k < w; k++) sacc += (real)*hptr<INLDS>(c0 + k, j) * y[c0 + k];
+        y[j] -= sacc;
+      }
+    }
+    SYNC();
     for (int q = S.nseq - 1; q >= 0; q--) {   // backward, row-oriented: x_blk = L_pp^-T y_blk, then y_j -= L_blk,j^T x_blk for the columns left of it
       const int p2 = S.seq[q];
       const int c0 = 6 * p2, w = blk_width(p2);
@@ -2000,6 +2100,9 @@ template <class real, int NV_> struct Engine {
       return;
     }
     PROF_T0();
+#ifdef UR5_MANY
+    if (UR5_LANE == 0) S.act_changed = 1;   // new contacts, new Hessian: the first iteration of a step always factors
+#endif
     // warm start: cheaper of qacc_warmstart and qacc_smooth
     real ccw;
     PAR(i, nv) S.x[i] = warm()[i];
