@@ -125,5 +125,7 @@ struct Ur5Launch {
 #else
 #define UR5_DEBUG_STRIDE 4096
 #define UR5_HESS_STRIDE (UR5_MAXNV * (UR5_MAXNV + 1) / 2 + UR5_MAXNV)   // worst case: the full lower triangle
-#define UR5_HENV_CAP 3584                          // envelopes up to this many doubles stay in LDS
+#ifndef UR5_HENV_CAP
+#define UR5_HENV_CAP 3584                          // envelopes up to this many doubles stay in LDS (tests shrink it to force the global path)
+#endif
 #endif

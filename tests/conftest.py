@@ -16,15 +16,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-def build_emul():
+def build_emul(flags=(), name="libur5sim_emul.so"):
     """Test-only lane-emulation build of the engine source (see tests/emul/ur5sim_emul.cpp)."""
+    lib = os.path.join(os.path.dirname(EMUL_LIB), name)
     srcs = [os.path.join(EMUL_DIR, f) for f in ("ur5sim_emul.cpp", "ur5sim_emul_many.cpp")]
     deps = srcs + [os.path.join(ROOT, "mujoco_rl_ur5_amd", "csrc", f)
                    for f in ("ur5_engine.h", "ur5sim_host.h", "ur5_devmodel.h", "ur5_raster.h", "ur5_many_names.h")]
-    if not os.path.exists(EMUL_LIB) or os.path.getmtime(EMUL_LIB) < max(os.path.getmtime(s) for s in deps):
-        os.makedirs(os.path.dirname(EMUL_LIB), exist_ok=True)
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", EMUL_LIB] + srcs)
-    return EMUL_LIB
+    if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(s) for s in deps):
+        os.makedirs(os.path.dirname(lib), exist_ok=True)
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", *flags, "-o", lib] + srcs)
+    return lib
 
 
 @pytest.fixture(scope="session")

@@ -63,6 +63,23 @@ def test_forward_quantities_match_oracle_in_a_settled_pile(model_many, emul_lib)
     assert sim.counters()["status"][0] == 0
 
 
+def test_envelope_in_global_memory_path(model_many):
+    """Envelopes larger than UR5_HENV_CAP doubles run the same factorisation on the scene's global-memory scratch; a build
+    with a tiny cap forces that path for every step."""
+    from conftest import build_emul
+    sim = BatchSim(model_many, 1, lib_path=build_emul(("-DUR5_HENV_CAP=8",), "libur5sim_emul_globalenv.so"))
+    sim.reset([20], 1, 0.0)
+    _drop_parity(model_many, sim, 0, 20, 30, 1e-9)
+    sim.step(270)
+    st = sim.get_state()
+    o = Oracle(model_many)
+    o.set_state(qpos=st["qpos"][0], qvel=st["qvel"][0], warmstart=st["warmstart"][0], pid=st["pid"][0])
+    o.forward()
+    d = sim.forward_debug()
+    qacc = o.vec("qacc")
+    assert d["ncon"][0] >= 20 and np.abs(d["qacc"][0][:model_many.nv] - qacc).max() < 1e-6 * max(1.0, np.abs(qacc).max())
+
+
 def test_render_with_cylinders_and_capsules(model_many, emul_lib):
     sim = BatchSim(model_many, 1, lib_path=emul_lib)
     sim.reset([20], 1, 0.0)
