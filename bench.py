@@ -36,45 +36,36 @@ def aimed_actions(qpos, first_id, round_idx, nobj=4):
     return a
 
 
-def cpu_baseline(model, budget_s=10.0):
+def aimed_actions_many(qpos, first_id, round_idx):
+    """--workload many (config 4 shape): scene g aims at one of the objects lying in the pick bin, 2 cm above its centre (what the
+    depth image would give), rotation index cycling through the 6 wrist angles (GraspingEnv.py:40)."""
+    n = qpos.shape[0]
+    a = np.zeros((n, 8))
+    for e in range(n):
+        objs = qpos[e][8:].reshape(-1, 7)
+        inbin = np.where((np.abs(objs[:, 0]) < 0.2) & (np.abs(objs[:, 1] + 0.6) < 0.13) & (objs[:, 2] > 0.85))[0]
+        k = inbin[(first_id + e + round_idx) % len(inbin)] if len(inbin) else 0
+        a[e, :3] = [objs[k, 0], objs[k, 1], objs[k, 2] + 0.02]
+        a[e, 3] = (first_id + e + round_idx) % 6
+    return a
+
+
+def cpu_baseline(model, budget_s=10.0, many=False):
     """The fp64 oracle (a port: the reference's own MuJoCo binary cannot exist here) on the host cores, same scenes/actions:
-    one scene per thread on every core (SURVEY.md section 8d ii; ctypes releases the GIL), plus the single-core rate."""
-    import threading
-    from oracle.oracle import Oracle
-
-    def worker(ids, deadline, out):
-        steps = attempts = 0
-        for g in ids:
-            if time.perf_counter() >= deadline:
-                break
-            o = Oracle(model)
-            o.reset(20 + g, 1, True)
-            a = aimed_actions(o.get_state()["qpos"][None, :], g, 0)[0]
-            o.grasp_attempt(a[:3], int(a[3]), 1)
-            steps += o.total_steps                      # reset settling (500 steps) + the attempt: all are timed
-            attempts += 1
-        out.append((steps, attempts))
-
-    def run(nthreads, budget):
-        out, threads = [], []
-        t0 = time.perf_counter()
-        for t in range(nthreads):
-            th = threading.Thread(target=worker, args=(range(t, 1 << 20, nthreads), t0 + budget, out))
-            th.start()
-            threads.append(th)
-        for th in threads:
-            th.join()
-        dt = time.perf_counter() - t0
-        return sum(o[0] for o in out), sum(o[1] for o in out), dt
-
+    one scene per native thread on every core (SURVEY.md section 8d ii; oracle/ur5_oracle.cpp ur5o_batch), plus the single-core rate.
+    IT1: reset settling + one aimed grasp attempt per scene (= aimed_actions() above); many: the first 100 steps of the drop."""
+    from oracle import oracle as O
     cores = os.cpu_count() or 1
-    s1, a1, t1 = run(1, 0.4 * budget_s)
-    sn, an, tn = run(cores, 0.6 * budget_s)
-    return dict(value=sn / tn, unit="env-steps/s", cores=cores, kind="port",
-                sample=f"{an} IT1 grasp attempts ({sn} physics steps incl. each scene's reset settling) "
-                       f"of scenes 0..{an - 1}, oracle/ur5_oracle.cpp, one scene per thread on {cores} threads for {tn:.1f} s wall",
-                grasp_attempts_per_s=an / tn,
-                single_core={"value": s1 / t1, "grasp_attempts_per_s": a1 / t1, "sample": f"{a1} attempts, {t1:.1f} s on one core"})
+    s1, a1, t1 = O.batch(model, 1, 0.3 * budget_s, 1 if many else 0, 100)
+    sn, an, tn = O.batch(model, cores, 0.7 * budget_s, 1 if many else 0, 100)
+    what = ("the first 100 steps of the 40-object drop of scenes 0..%d" % (an - 1)) if many else \
+           ("IT1 reset settling + one aimed grasp attempt of scenes 0..%d" % (an - 1))
+    out = dict(value=sn / tn, unit="env-steps/s", cores=cores, kind="port",
+               sample=f"{what} ({sn} physics steps), oracle/ur5_oracle.cpp, one scene per thread on {cores} threads for {tn:.1f} s wall",
+               single_core={"value": s1 / t1, "sample": f"{a1} scenes ({s1} steps), {t1:.1f} s on one core"})
+    if not many:
+        out["grasp_attempts_per_s"] = an / tn
+    return out
 
 
 def main():
@@ -82,7 +73,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--envs", type=int, default=4096, help="scenes per GPU")
+    ap.add_argument("--envs", type=int, default=None, help="scenes per GPU (default 4096; 2048 for --workload many)")
+    ap.add_argument("--workload", choices=("it1", "many"), default="it1",
+                    help="it1 = BASELINE.json configs[1] (the headline metric); many = configs[3] shape: 40-object piles, render + grasp round")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -102,20 +95,28 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
-    model = load_model("it1_4box")
-    n_local = args.envs
+    many = args.workload == "many"
+    model = load_model("/UR5+gripper/UR5gripper_2_finger_many_objects.xml" if many else "it1_4box")
+    n_local = args.envs if args.envs else (2048 if many else 4096)
     n_total = n_local * world
     lo, hi = sharding.shard_range(n_total, rank, world)
     sim = BatchSim(model, n_local, device_id=local_rank)
     sim.reset(sharding.global_seeds(20, n_total, rank, world), 1, 1000.0)          # GraspingEnv.py:409-477, untimed
     settled = sim.get_state()["qpos"]
     rounds = args.warmup + args.steps
-    actions = torch.from_numpy(np.stack([aimed_actions(settled, lo, r) for r in range(rounds)])).to(dev)   # [rounds, n, 8] f64 in HBM
+    mk = aimed_actions_many if many else aimed_actions
+    actions = torch.from_numpy(np.stack([mk(settled, lo, r) for r in range(rounds)])).to(dev)   # [rounds, n, 8] f64 in HBM
+    if many:                                                                      # the observation of every round stays on the device
+        img = torch.zeros((n_local, 200, 200, 3), dtype=torch.uint8, device=dev)
+        dep = torch.zeros((n_local, 200, 200), dtype=torch.float32, device=dev)
+        cam = model.camera_name2id("top_down")
     reward = torch.zeros((rounds, n_local), dtype=torch.int32, device=dev)
     ids = torch.arange(lo, hi, dtype=torch.int32, device=dev)
 
     def one_round(r):
-        sim.grasp_attempt_dev(actions[r].data_ptr(), reward[r].data_ptr(), check_mode=1, table_height=0.91)
+        if many:
+            sim.render_dev(img.data_ptr(), dep.data_ptr(), cam, 200, 200, 1)       # get_observation (GraspingEnv.py:390-406), same stream
+        sim.grasp_attempt_dev(actions[r].data_ptr(), reward[r].data_ptr(), check_mode=1 if not many else 0, table_height=0.91)
         sim.sync()                                                             # handle stream -> host; rewards now valid
         rec = torch.stack([ids, torch.zeros_like(ids), actions[r, :, 3].to(torch.int32), reward[r]], dim=1)
         return sharding.gather_outcomes(rec), sim.last_launch_ms()
@@ -156,13 +157,13 @@ def main():
         # measured HBM bytes per env-step from the rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this same command (profiles/)
         traffic, traffic_src = None, None
         tp = os.path.join(ROOT, "profiles", "r01_g_hbm_traffic.json")
-        if os.path.exists(tp):
+        if os.path.exists(tp) and not many:
             with open(tp) as f:
                 tj = json.load(f)
             traffic = tj["hbm_bytes_per_env_step"] * steps_local / args.steps
             traffic_src = "profiles/r01_g_hbm_traffic.json: (FETCH_SIZE + WRITE_SIZE) per env-step x env-steps of an average timed launch"
         out = {
-            "metric": "env-steps/sec (+ grasp-attempts/sec), 4096 parallel UR5 scenes per MI355X",
+            "metric": f"env-steps/sec (+ grasp-attempts/sec), {n_local} parallel UR5 scenes per MI355X",
             "value": steps_all / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
@@ -170,19 +171,21 @@ def main():
             "env_steps_per_attempt": steps_all / attempts,
             "newton_iters_per_step": float((c1["solver_iters"] - c0["solver_iters"]).sum()) / max(1, steps_local),
             "status_bits": int(np.bitwise_or.reduce(c1["status"])),
-            "config": {"workload": "BASELINE.json configs[1]: IT1 (UR5gripper_2_finger.xml robot + bins, 4 equal 4 cm boxes), physics only, "
-                                   "fixed z = 0.91, lift + 500-step closing check, one grasp-attempt round per step",
+            "config": {"workload": ("BASELINE.json configs[3] shape: IT5 many-object piles (UR5gripper_2_finger_many_objects.xml, 40 objects, "
+                                    "condim 6), 200x200 RGB-D render + multi-discrete rotation action + in-tree grasp script per step") if many else
+                                   ("BASELINE.json configs[1]: IT1 (UR5gripper_2_finger.xml robot + bins, 4 equal 4 cm boxes), physics only, "
+                                    "fixed z = 0.91, lift + 500-step closing check, one grasp-attempt round per step"),
                        "scenes_per_gpu": n_local, "scenes_total": n_total, "solver": "Newton (MuJoCo default), tol 1e-10",
                        "timestep_s": model.opt["timestep"], "parallelism": f"scenes sharded x{world}, 1 all_gather of 16 B outcome records per round"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "ur5_run_kernel<32>", "bytes_per_env_step": bytes_per_step,
+                         "kernel": "ur5m_run_kernel<248>" if many else "ur5_run_kernel<32>", "bytes_per_env_step": bytes_per_step,
                          "avg_launch_ms": float(np.mean(kernel_ms)), "env_steps_per_launch": steps_local / args.steps,
                          "note": "algorithmic state bytes x env-steps / HIP-event kernel time on the handle's stream (rank 0). The kernel keeps a "
                                  "scene in LDS for a whole grasp attempt, so real HBM traffic is far below the algorithmic figure; the step is "
                                  "latency/VALU bound (DESIGN.md)"},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(model)
+            out["cpu_baseline"] = cpu_baseline(model, many=many)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

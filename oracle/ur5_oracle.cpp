@@ -31,6 +31,9 @@
 #include <string>
 #include <vector>
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <thread>
 
 namespace {
 
@@ -1662,6 +1665,44 @@ int ur5o_move_ee(void* h, const double* xyz, double tol, int max_steps, int* ste
 }
 int ur5o_open_gripper(void* h, int half) { return ((Sim*)h)->open_gripper(half != 0); }
 int ur5o_close_gripper(void* h, int max_steps) { return ((Sim*)h)->close_gripper(max_steps); }
+// CPU baseline of bench.py: `nthreads` host threads, one scene each at a time, until `budget_s` of wall time has passed.
+// mode 0: IT1 round of scene g = reset(seed 20 + g, settle) + one grasp attempt aimed at object g % 4 (z = 0.91, check_mode 1),
+// i.e. exactly bench.py's aimed_actions(); mode 1: the first `nsteps` steps of the many-object drop of scene g. Returns the
+// physics steps executed by all threads; *scenes_out = scenes completed; *wall_out = seconds.
+long ur5o_batch(const void* blob, size_t nbytes, int ee_body, int base_body, int nthreads, double budget_s, int mode, int nsteps,
+                long* scenes_out, double* wall_out) {
+  std::atomic<long> steps{0}, scenes{0};
+  std::atomic<int> next{0};
+  auto t0 = std::chrono::steady_clock::now();
+  auto elapsed = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+  auto work = [&]() {
+    Sim s;
+    if (!s.init(blob, nbytes)) return;
+    s.ik_ee_body = ee_body; s.ik_base_body = base_body;
+    while (elapsed() < budget_s) {
+      int g = next.fetch_add(1);
+      long before = s.total_steps;
+      if (mode == 0) {
+        s.reset(20 + (uint64_t)g, 1, 1);
+        int nobj = (s.nq - 8) / 7, k = g % (nobj < 4 ? nobj : 4);
+        double xyz[3] = {s.qpos[8 + 7 * k], -0.6 + s.qpos[8 + 7 * k + 1], 0.91};
+        int ps[12], pr[12];
+        s.grasp_attempt(xyz, (g / 4) % 6, 1, 0.91, ps, pr);
+      } else {
+        s.reset(20 + (uint64_t)g, 1, 0);
+        for (int i = 0; i < nsteps; i++) s.step();
+      }
+      steps += s.total_steps - before;
+      scenes++;
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 0; t < nthreads; t++) th.emplace_back(work);
+  for (auto& t : th) t.join();
+  if (scenes_out) *scenes_out = scenes.load();
+  if (wall_out) *wall_out = elapsed();
+  return steps.load();
+}
 int ur5o_grasp_attempt(void* h, const double* xyz, int rot, int check_mode, double table_height, int* phase_steps, int* phase_result) {
   return ((Sim*)h)->grasp_attempt(xyz, rot, check_mode, table_height, phase_steps, phase_result);
 }
