@@ -69,7 +69,8 @@ int ur5_ik(ur5_sim* h, const double* xyz /* [n][3] */, double* q5, int* result);
 /* action[n][4] = world x, y, z, rotation index 0..5 (GraspingEnv.py:40). check_mode 0 = in-tree script, 1 = IT1. */
 int ur5_grasp_attempt(ur5_sim* h, const double* action, int check_mode, double table_height, int* reward,
                       int* phase_steps /* [n][12] or NULL */, int* phase_result /* [n][12] or NULL */);
-/* same with HIP device pointers: action_dev [n][8] doubles (x y z rot - - - -), reward_dev [n] int32; asynchronous */
+/* same with HIP device pointers: action_dev [n][8] doubles (x y z rot skip - - -), reward_dev [n] int32; asynchronous.
+   skip != 0: the scene sits the launch out with reward 0 -- GraspEnv.step's rule for targets off the table (GraspingEnv.py:124-131) */
 int ur5_grasp_attempt_dev(ur5_sim* h, const double* action_dev, int check_mode, double table_height, int* reward_dev);
 int ur5_sync(ur5_sim* h);
 /* duration of the last launch in ms, from HIP events recorded on the handle's stream around the kernel */

@@ -1,0 +1,127 @@
+"""Batched, device-resident version of the reference's DQN grasp agent (BASELINE.json config 5).
+
+Mirrors ``Grasp_Agent`` of ``Grasping_Agent_multidiscrete.py`` (:47-446): ``transform_observation`` (:301-368), ``epsilon_greedy``
+(:232-282) incl. the "resample until the pixel lies on the table" rule (:266-280), ``transform_action`` (:380-385), ``learn`` (:388-446:
+gamma = 0, binary cross entropy between Q(s, a) and the grasp outcome, Adam lr 1e-3, weight decay 2e-5, batch 12, the newest
+transition always in the batch) -- for N scenes per rank at once. Observations are rendered by the engine into torch tensors on the
+simulating GPU, the network runs there (PyTorch-ROCm / MIOpen), actions go back to the engine as a device tensor, rewards come back
+as one; per round only the 16-byte outcome records cross ranks (``sharding.gather_outcomes``, RCCL all_gather).
+
+Differences that follow from batching, all deliberate: epsilon decays per transition (``steps_done`` advances by N per round); one
+optimiser step per round on 12 sampled transitions (the reference learns once per env step); colour jitter (torchvision, :120-126) is
+not applied -- depth noise is.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import sharding
+from .envs import GraspEnv
+from .qnet import MULTIDISCRETE_RESNET, ReplayBuffer
+
+MEMORY_SIZE = 2000            # Grasping_Agent_multidiscrete.py:26-38
+BATCH_SIZE = 12
+LEARNING_RATE = 0.001
+EPS_START, EPS_END, EPS_DECAY = 1.0, 0.2, 8000
+
+
+class BatchedGraspAgent:
+    def __init__(self, env: GraspEnv = None, n_envs=1, device=None, learning_rate=LEARNING_RATE, mem_size=MEMORY_SIZE, eps_start=EPS_START,
+                 eps_end=EPS_END, eps_decay=EPS_DECAY, seed=20, load_path=None, first_scene_id=0, **env_kwargs):
+        torch.manual_seed(seed)                                                        # :76-79
+        np.random.seed(seed)
+        self.device = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
+        self.env = env if env is not None else GraspEnv(n_envs=n_envs, show_obs=False, observation="render", **env_kwargs)
+        self.N, self.H, self.W = self.env.n_envs, self.env.IMAGE_HEIGHT, self.env.IMAGE_WIDTH
+        self.n_actions_1, self.n_actions_2 = int(self.env.action_space.nvec[0]), int(self.env.action_space.nvec[1])   # :97-100
+        self.output = self.n_actions_1 * self.n_actions_2
+        self.policy_net = MULTIDISCRETE_RESNET(number_actions_dim_2=self.n_actions_2).to(self.device)     # :103
+        if load_path is not None:                                                      # :109-114
+            checkpoint = torch.load(load_path, map_location=self.device)
+            self.policy_net.load_state_dict(checkpoint["model_state_dict"])
+        self.depth_threshold = float(np.round(self.env.model.cam_pos0[self.env.model.camera_name2id("top_down")][2]
+                                              - self.env.TABLE_HEIGHT + 0.01, decimals=3))   # :131-136
+        self.memory = ReplayBuffer(mem_size, self.H, self.W, device=self.device)       # :140-142
+        self.optimizer = torch.optim.Adam(self.policy_net.parameters(), lr=learning_rate, weight_decay=0.00002)   # :153-156
+        self.eps_start, self.eps_end, self.eps_decay = eps_start, eps_end, eps_decay
+        self.steps_done, self.eps_threshold = 0, eps_start
+        self.first_scene_id = first_scene_id
+        self.last_loss = None
+        self._gen = torch.Generator(device=self.device).manual_seed(seed)
+
+    # ------------------------------------------------------------------ observation -> network input
+    def transform_observation(self, observation, normalize=True, jitter_and_noise=True):
+        """:301-368 for a batch: depth clipped at the table threshold, (noise,) negated and min-max normalised per image; rgb / 255.
+        observation = {"rgb": uint8 [N,H,W,3], "depth": float32 [N,H,W]} device tensors -> float32 [N,4,H,W]."""
+        depth = observation["depth"].to(self.device).float().clamp(max=self.depth_threshold)            # :311
+        if normalize:
+            if jitter_and_noise:
+                depth = depth + 0.001 * torch.randn(depth.shape, device=self.device, generator=self._gen)   # :317
+            depth = -depth
+            dmin = depth.amin(dim=(1, 2), keepdim=True)
+            dmax = depth.amax(dim=(1, 2), keepdim=True)
+            depth = (depth - dmin) / (dmax - dmin).clamp_min(1e-12)                                      # :319-321
+        rgb = observation["rgb"].to(self.device).permute(0, 3, 1, 2).float() / 255.0                    # ToTensor (:128)
+        return torch.cat((rgb, depth.unsqueeze(1)), dim=1)
+
+    # ------------------------------------------------------------------ action selection
+    def epsilon_greedy(self, state, observation):
+        """:232-282 per scene: greedy = argmax over the [6, H, W] Q maps; random = uniform over the (pixel, rotation) pairs whose pixel
+        lies on the table (world z >= TABLE_HEIGHT - 0.01, :266-280). Returns (action long [N], greedy bool [N])."""
+        self.eps_threshold = self.eps_end + (self.eps_start - self.eps_end) * math.exp(-1.0 * self.steps_done / self.eps_decay)   # :241-243
+        self.steps_done += self.N
+        explore = torch.rand(self.N, device=self.device, generator=self._gen) <= self.eps_threshold
+        with torch.no_grad():
+            q = self.policy_net(state).reshape(self.N, -1)                                               # [N, 6*H*W]
+        greedy_action = q.argmax(dim=1)
+        world = self.env.pixel_world_device(observation["depth"], self.device)                           # [N,H,W,3]
+        on_table = (world[..., 2] >= self.env.TABLE_HEIGHT - 0.01).reshape(self.N, -1).float()
+        on_table = torch.where(on_table.sum(dim=1, keepdim=True) > 0, on_table, torch.ones_like(on_table))
+        pixel = torch.multinomial(on_table, 1, generator=self._gen).squeeze(1)
+        rot = torch.randint(0, self.n_actions_2, (self.N,), device=self.device, generator=self._gen)
+        random_action = rot * self.n_actions_1 + pixel
+        return torch.where(explore, random_action, greedy_action), ~explore
+
+    def greedy(self, state):                                                                             # :284-299
+        with torch.no_grad():
+            q = self.policy_net(state).reshape(self.N, -1)
+        value, idx = q.max(dim=1)
+        return idx, value
+
+    def transform_action(self, action):
+        """:380-385: flat index -> [pixel, rotation] (the Q maps are laid out [rotation][pixel])."""
+        return torch.stack((action % self.n_actions_1, action // self.n_actions_1), dim=1)
+
+    # ------------------------------------------------------------------ learning
+    def learn(self):
+        """:388-446 with GAMMA = 0: one optimiser step on BATCH_SIZE transitions (the newest always included)."""
+        if len(self.memory) < 2 * BATCH_SIZE:                                                            # :396-398
+            return None
+        state, action, reward = self.memory.sample(BATCH_SIZE)
+        self.policy_net.train()
+        q_pred = self.policy_net(state).reshape(BATCH_SIZE, -1).gather(1, action)                        # :424-426
+        loss = F.binary_cross_entropy(q_pred, reward.float())                                            # :439
+        loss.backward()
+        self.optimizer.step()
+        self.optimizer.zero_grad()
+        self.last_loss = float(loss.detach())
+        return self.last_loss
+
+    # ------------------------------------------------------------------ one round of the episode loop (:540-560)
+    def round(self, learn=True):
+        """observe -> act -> grasp -> store -> learn, for every scene of this rank; outcomes gathered over ranks (X1)."""
+        obs = self.env.observation_device(self.device)
+        state = self.transform_observation(obs)
+        action, greedy = self.epsilon_greedy(state, obs)
+        env_action = self.transform_action(action)
+        reward, skipped = self.env.step_device(env_action, obs["depth"], self.device)
+        self.memory.push(state, action, reward)                                                          # :551-554
+        ids = self.first_scene_id + torch.arange(self.N, dtype=torch.int32, device=self.device)
+        rec = torch.stack([ids, env_action[:, 0].int(), env_action[:, 1].int(), reward.int()], dim=1)
+        outcomes = sharding.gather_outcomes(rec)
+        loss = self.learn() if learn else None
+        return {"reward": reward, "skipped": skipped, "greedy": greedy, "loss": loss, "outcomes": outcomes, "epsilon": self.eps_threshold}

@@ -2405,7 +2405,9 @@ template <class real, int NV_> struct Engine {
         while (!chosen) {
           chosen = true;
           switch (pc) {
-            case 0:   // :212 move above the target
+            case 0:   // GraspEnv.step's skip rule (GraspingEnv.py:124-131): the caller flags targets it must not act on
+              if (P.target[8 * env + 4] != 0) { result = 0; pr.done = true; break; }
+              // :212 move above the target
               pr.need_ik = true; pr.xyz = v3(coord.x, coord.y, (real)1.1); pr.mask = 0x1fu; pr.tol = (real)0.05; pr.max_steps = 1000; slot = 0; break;
             case 1:   // :227-239 centre fallback when the IK failed
               result1 = last_res;

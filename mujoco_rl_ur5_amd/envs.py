@@ -155,6 +155,66 @@ class GraspEnv(object):
         observation["depth"] = self._one(depth)
         return observation
 
+    # ------------------------------------------------------------------ device-resident variants
+    # The agent loop of Grasping_Agent_multidiscrete.py needs, per step, the RGB-D observation as a network input and the depth under
+    # the chosen pixel. With thousands of scenes the 280 KB observation per scene must not cross PCIe: these two methods keep
+    # observations, actions and rewards in torch tensors on the simulating GPU (host tensors for the CPU lane-emulation build).
+    def _torch_setup(self, device):
+        import torch
+        if getattr(self, "_tdev", None) == str(device):
+            return torch
+        self._tdev = str(device)
+        n, H, W = self.n_envs, self.IMAGE_HEIGHT, self.IMAGE_WIDTH
+        self._t_rgb = torch.zeros((n, H, W, 3), dtype=torch.uint8, device=device)
+        self._t_gl = torch.zeros((n, H, W), dtype=torch.float32, device=device)
+        self._t_act = torch.zeros((n, 8), dtype=torch.float64, device=device)
+        self._t_rew = torch.zeros((n,), dtype=torch.int32, device=device)
+        self.controller.create_camera_data(W, H, "top_down")
+        Kinv, Rinv = np.linalg.inv(self.controller.cam_matrix), np.linalg.inv(self.controller.cam_rot_mat)
+        ys, xs = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+        rays = (Rinv @ Kinv @ np.stack([xs.ravel(), ys.ravel(), np.ones(H * W)])).T           # pos_w = t - depth * ray (pixel_2_world, :783-806)
+        self._t_rays = torch.from_numpy(rays.reshape(H, W, 3)).to(device)
+        self._t_t = torch.from_numpy(Rinv @ self.controller.cam_pos).to(device)
+        return torch
+
+    def observation_device(self, device="cuda"):
+        """get_observation (:390-406) without leaving the device: {"rgb": uint8 [N,H,W,3], "depth": float32 [N,H,W] metres}."""
+        torch = self._torch_setup(device)
+        cam = self.model.camera_name2id("top_down")
+        if self._t_rgb.is_cuda:
+            torch.cuda.synchronize()
+        self.sim.render_dev(self._t_rgb.data_ptr(), self._t_gl.data_ptr(), cam, self.IMAGE_WIDTH, self.IMAGE_HEIGHT, 1)
+        self.sim.sync()
+        ext = self.model.opt["extent"]
+        near, far = self.model.opt["znear"] * ext, self.model.opt["zfar"] * ext
+        return {"rgb": self._t_rgb, "depth": near / (1 - self._t_gl * (1 - near / far))}          # depth_2_meters (:729-740)
+
+    def pixel_world_device(self, depth, device="cuda"):
+        """World coordinates [N,H,W,3] (float64) of every pixel given the metric depth image: pixel_2_world for all pixels at once."""
+        self._torch_setup(device)
+        return self._t_t - depth.double().unsqueeze(-1) * self._t_rays
+
+    def step_device(self, action, depth, device="cuda"):
+        """GraspEnv.step (:62-156) with ``action`` long [N,2] = [pixel, rotation] and the current metric ``depth`` [N,H,W] on the device.
+        Returns (reward int32 [N], skipped bool [N]) as device tensors; the caller asks for the next observation when it needs one."""
+        torch = self._torch_setup(device)
+        a = action.to(self._t_act.device).long().reshape(self.n_envs, 2)
+        x, y = a[:, 0] % self.IMAGE_WIDTH, a[:, 0] // self.IMAGE_WIDTH                           # :95-96
+        e = torch.arange(self.n_envs, device=a.device)
+        d = depth[e, y, x].double()                                                              # :100
+        coords = self._t_t - d.unsqueeze(-1) * self._t_rays[y, x]                                # :102-104
+        skip = (coords[:, 2] < 0.8) | (coords[:, 1] > -0.3)                                      # :124
+        self._t_act.zero_()
+        self._t_act[:, :3] = coords
+        self._t_act[:, 3] = a[:, 1].double()
+        self._t_act[:, 4] = skip.double()
+        if self._t_act.is_cuda:
+            torch.cuda.synchronize()
+        self.sim.grasp_attempt_dev(self._t_act.data_ptr(), self._t_rew.data_ptr(), check_mode=self.check_mode, table_height=self.TABLE_HEIGHT)
+        self.sim.sync()
+        self.step_called += 1
+        return self._t_rew.clone(), skip
+
     def close(self):
         self.sim.close()
 

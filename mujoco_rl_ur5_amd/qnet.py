@@ -1,0 +1,152 @@
+"""Pixel-wise grasp-Q network and replay buffer of the reference, for the device-resident rollout loop.
+
+Architecture = ``Modules.py`` of the reference: ``Perception_Module`` (:159-193) + ``Grasping_Module_multidiscrete`` (:243-287),
+assembled by ``MULTIDISCRETE_RESNET`` (:308-311); ``RESNET`` / ``POLICY_RESNET`` (:300-305) are the single-map heads. Module and
+parameter names are the reference's, so its checkpoints (``checkpoint["model_state_dict"]``) load unchanged, and layers are created
+in the reference's order, so a given ``torch.manual_seed`` yields the same initial weights (``tests/test_qnet.py`` checks both
+against vectors produced by the reference's own file, ``tools/gen_golden_qnet.py``).
+
+This is plain PyTorch-ROCm (MIOpen convolutions), as BASELINE.json's north_star prescribes for the CNN; what this module adds is
+that everything stays on the GPU that simulates: the raster writes straight into torch tensors, the replay buffer is a set of
+preallocated device tensors, and one forward pass serves all scenes of the rank.
+"""
+from __future__ import annotations
+
+import random
+
+import torch
+import torch.nn as nn
+
+
+def _conv3x3(cin, cout):
+    return nn.Conv2d(cin, cout, kernel_size=3, stride=1, padding=1, bias=False)
+
+
+class BasicBlock(nn.Module):
+    """Modules.py:92-142 -- two 3x3 convolutions with batch norm; a 1x1 convolution (with bias) on the skip path when the channel
+    count changes. No stride, no down-sampling in this network."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes):
+        super().__init__()
+        self.conv1 = _conv3x3(inplanes, planes)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = _conv3x3(planes, planes)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = None
+        self.stride = 1
+        self.conv3 = nn.Conv2d(inplanes, planes, kernel_size=1, stride=1) if inplanes != planes else None
+
+    def forward(self, x):
+        out = self.bn2(self.conv2(self.relu(self.bn1(self.conv1(x)))))
+        skip = x if self.conv3 is None else self.conv3(x)
+        return self.relu(out + skip)
+
+
+class Perception_Module(nn.Module):
+    """Modules.py:159-193 -- 4-channel RGB-D in, 512 channels at 1/4 resolution out."""
+
+    def __init__(self):
+        super().__init__()
+        self.C1 = _conv3x3(4, 64)
+        self.MP1 = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.RB1 = BasicBlock(64, 128)
+        self.MP2 = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.RB2 = BasicBlock(128, 256)
+        self.RB3 = BasicBlock(256, 512)
+
+    def forward(self, x, verbose=0):
+        return self.RB3(self.RB2(self.MP2(self.RB1(self.MP1(self.C1(x))))))
+
+
+class _GraspingHead(nn.Module):
+    def __init__(self, out_channels, output_activation):
+        super().__init__()
+        self.RB1 = BasicBlock(512, 256)
+        self.RB2 = BasicBlock(256, 128)
+        self.UP1 = nn.UpsamplingBilinear2d(scale_factor=2)
+        self.RB3 = BasicBlock(128, 64)
+        self.UP2 = nn.UpsamplingBilinear2d(scale_factor=2)
+        self.C1 = nn.Conv2d(64, out_channels, kernel_size=1)
+        self.output_activation = output_activation
+        if output_activation is not None:
+            self.sigmoid = nn.Sigmoid()
+
+    def forward(self, x, verbose=0):
+        x = self.C1(self.UP2(self.RB3(self.UP1(self.RB2(self.RB1(x))))))
+        x = x.squeeze()                                   # the reference squeezes in place (:230,:277): batch 1 loses its batch axis
+        return self.sigmoid(x) if self.output_activation is not None else x
+
+
+class Grasping_Module(_GraspingHead):
+    """Modules.py:196-240 -- one Q map."""
+
+    def __init__(self, output_activation="Sigmoid"):
+        super().__init__(1, output_activation)
+
+
+class Grasping_Module_multidiscrete(_GraspingHead):
+    """Modules.py:243-287 -- one Q map per wrist rotation."""
+
+    def __init__(self, output_activation="Sigmoid", act_dim_2=6):
+        super().__init__(act_dim_2, output_activation)
+
+
+def RESNET():
+    return nn.Sequential(Perception_Module(), Grasping_Module())
+
+
+def POLICY_RESNET():
+    return nn.Sequential(Perception_Module(), Grasping_Module(output_activation=None))
+
+
+def MULTIDISCRETE_RESNET(number_actions_dim_2):
+    return nn.Sequential(Perception_Module(), Grasping_Module_multidiscrete(act_dim_2=number_actions_dim_2))
+
+
+def count_parameters(model):
+    return sum(p.numel() for p in model.parameters() if p.requires_grad)
+
+
+class ReplayBuffer:
+    """``ReplayBuffer(size, simple=True)`` of Modules.py:28-55 as preallocated tensors on ``device``: ring overwrite, ``sample(b)`` =
+    b-1 transitions drawn without replacement plus the most recent one (:46-49), python ``random`` seeded with 20 (:33).
+
+    Batched use: ``push`` takes N transitions at once (one per scene of the rank) and stores them in scene order, which is what N
+    consecutive pushes of the reference would do. States are kept as uint8 RGB + float16 normalised depth (5 bytes per pixel instead of
+    the reference's 16) and expanded to the 4-channel float tensor on ``sample``."""
+
+    def __init__(self, size, height=200, width=200, device="cpu", simple=True, seed=20):
+        if not simple:
+            raise NotImplementedError("GAMMA = 0 in the reference (Grasping_Agent_multidiscrete.py:32): only simple transitions are stored")
+        self.size, self.position, self.count = int(size), 0, 0
+        self.device = torch.device(device)
+        self.rgb = torch.zeros((self.size, 3, height, width), dtype=torch.uint8, device=self.device)
+        self.depth = torch.zeros((self.size, 1, height, width), dtype=torch.float16, device=self.device)
+        self.action = torch.zeros((self.size, 1), dtype=torch.long, device=self.device)
+        self.reward = torch.zeros((self.size, 1), dtype=torch.float32, device=self.device)
+        self._rng = random.Random(seed)
+
+    def __len__(self):
+        return self.count
+
+    def push(self, state, action, reward):
+        """state [N,4,H,W] float in [0,1] (rgb/255, normalised depth), action [N] or [N,1] long, reward [N] or [N,1]."""
+        n = state.shape[0]
+        idx = (self.position + torch.arange(n, device=self.device)) % self.size
+        self.rgb[idx] = (state[:, :3].to(self.device) * 255.0).round().clamp(0, 255).to(torch.uint8)
+        self.depth[idx] = state[:, 3:4].to(self.device).to(torch.float16)
+        self.action[idx] = action.reshape(n, 1).to(self.device).long()
+        self.reward[idx] = reward.reshape(n, 1).to(self.device).float()
+        self.position = (self.position + n) % self.size
+        self.count = min(self.size, self.count + n)
+
+    def sample(self, batch_size):
+        if self.count < batch_size:
+            raise ValueError("not enough transitions")
+        last = (self.position - 1) % self.size
+        picks = self._rng.sample(range(self.count), batch_size - 1) + [last]
+        idx = torch.tensor(picks, device=self.device)
+        state = torch.cat((self.rgb[idx].float() / 255.0, self.depth[idx].float()), dim=1)
+        return state, self.action[idx], self.reward[idx]

@@ -1,0 +1,82 @@
+"""The batched DQN loop (mujoco_rl_ur5_amd/agent.py): CPU run on the lane-emulation engine with host
+tensors; the same code on cuda:0 with -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+from mujoco_rl_ur5_amd.agent import BATCH_SIZE, BatchedGraspAgent
+from mujoco_rl_ur5_amd.envs import GraspEnv
+
+
+def _checks(agent, out):
+    N = agent.N
+    assert out["reward"].shape == (N,) and set(out["reward"].tolist()) <= {0, 1}
+    assert out["outcomes"].shape == (N, 4) and out["outcomes"].dtype == torch.int32
+    assert (out["outcomes"][:, 1] >= 0).all() and (out["outcomes"][:, 1] < agent.n_actions_1).all() and (out["outcomes"][:, 2] < 6).all()
+
+
+def test_device_observation_equals_host_observation(model_it1, emul_lib):
+    env = GraspEnv(file=model_it1, n_envs=2, show_obs=False, observation="render", image_width=40, image_height=40, _lib_path=emul_lib)
+    host = env.reset()
+    dev = env.observation_device("cpu")
+    assert np.array_equal(dev["rgb"].numpy(), host["rgb"]) and np.allclose(dev["depth"].numpy(), host["depth"], rtol=0, atol=1e-6)
+    # pixel_2_world for every pixel at once == the controller's scalar version (MujocoController.py:783-806)
+    w = env.pixel_world_device(dev["depth"], "cpu")
+    ref = env.controller.pixel_2_world(pixel_x=7, pixel_y=31, depth=float(host["depth"][1, 31, 7]), height=40, width=40)
+    assert np.allclose(w[1, 31, 7].numpy(), ref, atol=1e-9)
+    # step_device == step on the same action
+    a = np.array([[20 * 40 + 20, 1], [5 * 40 + 33, 4]])
+    env2 = GraspEnv(file=model_it1, n_envs=2, show_obs=False, observation="render", image_width=40, image_height=40, _lib_path=emul_lib)
+    env2.reset()
+    _, r_host, _, info = env2.step(a)
+    r_dev, skipped = env.step_device(torch.from_numpy(a), dev["depth"], "cpu")
+    assert np.array_equal(r_dev.numpy(), r_host) and np.array_equal(skipped.numpy(), info["skipped"])
+    assert np.allclose(env.sim.get_state()["qpos"], env2.sim.get_state()["qpos"], atol=1e-12)
+
+
+def test_agent_rounds_on_cpu(model_it1, emul_lib):
+    env = GraspEnv(file=model_it1, n_envs=2, show_obs=False, observation="render", image_width=24, image_height=24, check_mode=1, _lib_path=emul_lib)
+    env.reset()
+    agent = BatchedGraspAgent(env=env, device="cpu", mem_size=64)
+    obs = env.observation_device("cpu")
+    state = agent.transform_observation(obs, jitter_and_noise=False)
+    assert state.shape == (2, 4, 24, 24) and float(state.min()) >= 0 and float(state.max()) <= 1
+    d = obs["depth"].clamp(max=agent.depth_threshold)                       # transform_observation of the reference, one image
+    ref = (-d[0] - (-d[0]).min()) / ((-d[0]).max() - (-d[0]).min())
+    assert torch.allclose(state[0, 3], ref, atol=1e-6) and torch.allclose(state[0, :3], obs["rgb"][0].permute(2, 0, 1).float() / 255)
+    action, greedy = agent.epsilon_greedy(state, obs)                       # epsilon = 1 at the start: every action is a random table pixel
+    assert not greedy.any() and agent.steps_done == 2
+    pa = agent.transform_action(action)
+    world = env.pixel_world_device(obs["depth"], "cpu")
+    for e in range(2):
+        assert world[e, pa[e, 0] // 24, pa[e, 0] % 24, 2] >= env.TABLE_HEIGHT - 0.01
+    agent.eps_start = agent.eps_end = 0.0                                   # greedy: argmax of the Q maps
+    action, greedy = agent.epsilon_greedy(state, obs)
+    with torch.no_grad():
+        q = agent.policy_net(state)
+    assert greedy.all() and int(action[1]) == int(q[1].reshape(-1).argmax())
+    agent.eps_start = agent.eps_end = 1.0
+    losses = []
+    for r in range(2 * BATCH_SIZE // 2 + 1):
+        out = agent.round()
+        _checks(agent, out)
+        losses.append(out["loss"])
+    assert losses[0] is None and losses[-1] is not None and np.isfinite(losses[-1]) and len(agent.memory) == 26
+
+
+@pytest.mark.gpu
+def test_agent_rounds_on_gpu(model_it1):
+    assert torch.cuda.is_available()
+    env = GraspEnv(file=model_it1, n_envs=8, show_obs=False, observation="render", check_mode=1)
+    env.reset()
+    agent = BatchedGraspAgent(env=env, device="cuda", mem_size=64)
+    obs = env.observation_device("cuda")
+    assert obs["rgb"].is_cuda and obs["depth"].is_cuda and obs["depth"].shape == (8, 200, 200)
+    host = env.get_observation(show=False)
+    assert np.array_equal(obs["rgb"].cpu().numpy(), host["rgb"]) and np.allclose(obs["depth"].cpu().numpy(), host["depth"], atol=1e-6)
+    for r in range(4):
+        out = agent.round()
+        _checks(agent, out)
+        assert out["reward"].is_cuda
+    assert out["loss"] is not None and np.isfinite(out["loss"]) and len(agent.memory) == 32
+    assert env.sim.counters()["status"].max() == 0

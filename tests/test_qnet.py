@@ -1,0 +1,63 @@
+"""The grasp-Q CNN and replay buffer against vectors produced by the reference's own Modules.py
+(tools/gen_golden_qnet.py -> tests/golden/qnet_reference.json)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from mujoco_rl_ur5_amd import qnet
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "qnet_reference.json")))
+
+
+@pytest.mark.parametrize("tag,make", [("MULTIDISCRETE_RESNET_6", lambda: qnet.MULTIDISCRETE_RESNET(6)), ("RESNET", qnet.RESNET),
+                                      ("POLICY_RESNET", qnet.POLICY_RESNET)])
+def test_network_equals_the_reference(tag, make):
+    g = GOLD[tag]
+    torch.manual_seed(0)
+    net = make().eval()
+    assert [[k, list(v.shape)] for k, v in net.state_dict().items()] == g["keys"]      # the reference's checkpoints load unchanged
+    assert qnet.count_parameters(net) == g["n_params"]
+    x = torch.randn(2, 4, 40, 40, generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        y = net(x)
+    assert list(y.shape) == g["out_shape"]
+    flat = y.reshape(-1)
+    assert np.allclose(flat[torch.tensor(g["sample_idx"])].numpy(), g["sample"], rtol=1e-5, atol=1e-6)
+    assert abs(float(flat.double().sum()) - g["sum"]) < 1e-3 * max(1.0, abs(g["sum"]))
+    assert abs(float(flat.double().abs().sum()) - g["abs_sum"]) < 1e-3 * g["abs_sum"]
+
+
+def test_train_mode_forward_equals_the_reference():
+    torch.manual_seed(0)
+    net = qnet.MULTIDISCRETE_RESNET(6).train()
+    y = net(torch.randn(3, 4, 40, 40, generator=torch.Generator().manual_seed(2)))
+    assert abs(float(y.double().sum()) - GOLD["train_mode"]["sum"]) < 1e-3 * abs(GOLD["train_mode"]["sum"])
+
+
+def test_single_image_loses_its_batch_axis_like_the_reference():
+    net = qnet.MULTIDISCRETE_RESNET(6).eval()
+    with torch.no_grad():
+        assert net(torch.zeros(1, 4, 40, 40)).shape == (6, 40, 40)            # x.squeeze_() in Modules.py:277
+
+
+def test_replay_buffer_semantics():
+    g = GOLD["replay"]
+    buf = qnet.ReplayBuffer(5, height=4, width=4)
+    for i in range(8):                                                           # the reference pushed states 0..7 into a buffer of 5
+        s = torch.zeros(1, 4, 4, 4)
+        s[0, 0, 0, 0] = i / 255.0
+        buf.push(s, torch.tensor([10 * i]), torch.tensor([i % 2]))
+    assert len(buf) == g["len"] and buf.position == g["position"]
+    assert [int(round(float(v) * 255)) for v in (buf.rgb[:, 0, 0, 0].float() / 255.0)] == g["stored_states"]
+    for _ in range(4):
+        state, action, reward = buf.sample(3)
+        assert state.shape == (3, 4, 4, 4) and action.shape == (3, 1) and reward.shape == (3, 1)
+        assert int(round(float(state[-1, 0, 0, 0]) * 255)) == g["sample_last"][0]   # the newest transition is always in the batch
+        assert int(action[-1]) == 10 * g["sample_last"][0]
+    nb = qnet.ReplayBuffer(6, height=4, width=4)                                  # batched push = consecutive pushes in scene order
+    nb.push(torch.zeros(4, 4, 4, 4), torch.arange(4), torch.zeros(4))
+    nb.push(torch.zeros(4, 4, 4, 4), 4 + torch.arange(4), torch.ones(4))
+    assert nb.position == 2 and len(nb) == 6 and nb.action[:, 0].tolist() == [6, 7, 2, 3, 4, 5]

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Golden vectors for mujoco_rl_ur5_amd/qnet.py from the reference's own Modules.py (run in the build container, where
+/root/reference exists; the GPU box only sees the committed JSON).
+
+Modules.py imports torchvision.transforms and prettytable at module level (neither is installed here, neither is used by the
+network classes), so both are stubbed before the import. Weights: torch.manual_seed(0) before construction -- qnet.py creates its
+layers in the same order, so the same seed gives the same initial weights and the outputs can be compared directly.
+"""
+import json
+import os
+import sys
+import types
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+for name in ("torchvision", "torchvision.transforms", "prettytable"):
+    sys.modules[name] = types.ModuleType(name)
+sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+sys.modules["prettytable"].PrettyTable = object
+sys.path.insert(0, REF)
+import Modules as R  # noqa: E402
+
+out = {}
+for tag, make in (("MULTIDISCRETE_RESNET_6", lambda: R.MULTIDISCRETE_RESNET(6)), ("RESNET", R.RESNET), ("POLICY_RESNET", R.POLICY_RESNET)):
+    torch.manual_seed(0)
+    net = make().eval()
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 4, 40, 40, generator=g)
+    with torch.no_grad():
+        y = net(x)
+    flat = y.reshape(-1)
+    idx = torch.linspace(0, flat.numel() - 1, 24).long()
+    out[tag] = {"keys": [[k, list(v.shape)] for k, v in net.state_dict().items()], "n_params": sum(p.numel() for p in net.parameters()),
+                "out_shape": list(y.shape), "sum": float(flat.double().sum()), "abs_sum": float(flat.double().abs().sum()),
+                "sample_idx": idx.tolist(), "sample": [float(v) for v in flat[idx]]}
+# train-mode forward (batch-norm batch statistics), the mode learn() runs in
+torch.manual_seed(0)
+net = R.MULTIDISCRETE_RESNET(6).train()
+g = torch.Generator().manual_seed(2)
+x = torch.randn(3, 4, 40, 40, generator=g)
+y = net(x)
+out["train_mode"] = {"sum": float(y.double().sum()), "abs_sum": float(y.double().abs().sum())}
+# ReplayBuffer semantics (Modules.py:28-55): ring overwrite, the most recent transition is always part of a sample
+buf = R.ReplayBuffer(5, simple=True)
+for i in range(8):
+    buf.push(i, 10 * i, i % 2)
+out["replay"] = {"len": len(buf), "position": buf.position, "stored_states": [t.state for t in buf.memory],
+                 "sample_last": [buf.sample(3)[-1].state for _ in range(4)]}
+with open(os.path.join(ROOT, "tests", "golden", "qnet_reference.json"), "w") as f:
+    json.dump(out, f, indent=1)
+print({k: (v.get("n_params"), v.get("out_shape")) for k, v in out.items() if "keys" in v})
