@@ -1,0 +1,29 @@
+"""Offline-RL data files in the reference's layout (Offline RL/generate_data.py, grasping_dataset.py)."""
+import numpy as np
+import torch
+
+from mujoco_rl_ur5_amd.dataset import FILE_SIZE, GraspingDataWriter, Grasping_Dataset
+
+
+def test_files_have_the_reference_layout(tmp_path):
+    w = GraspingDataWriter(str(tmp_path / "Data"))
+    rng = np.random.default_rng(0)
+    for r in range(5):                                                       # 5 rounds of 5 scenes -> 2 full files + 1 pending
+        obs = {"rgb": rng.integers(0, 255, (5, 8, 8, 3), dtype=np.uint8), "depth": (0.9 + 0.3 * rng.random((5, 8, 8))).astype(np.float32)}
+        w.add(obs, torch.tensor([[3, 1], [7, 0], [63, 5], [0, 0], [9, 2]]), np.array([0, 1, 0, 0, 1]))
+    assert [f.split("/")[-1] for f in w.files] == ["grasping_data_1.pt", "grasping_data_2.pt"]
+    w.flush()
+    assert w.files[-1].endswith("grasping_data_3.pt")
+    d = torch.load(w.files[0], weights_only=False)                          # exactly what generate_data.py:69-84 saves
+    assert sorted(d.keys()) == ["actions", "rewards", "states"] and len(d["states"]) == len(d["actions"]) == len(d["rewards"]) == FILE_SIZE
+    assert d["states"][0]["rgb"].shape == (8, 8, 3) and d["states"][0]["rgb"].dtype == np.uint8 and d["states"][0]["depth"].dtype == np.float32
+    assert d["actions"][:5] == [1 * 64 + 3, 7, 5 * 64 + 63, 0, 2 * 64 + 9] and d["rewards"][:5] == [0, 1, 0, 0, 1]
+    ds = Grasping_Dataset(w.files[0], seed=1)
+    x, a, r = ds[2]
+    assert len(ds) == FILE_SIZE and x.shape == (4, 8, 8) and x.dtype == torch.float32 and a == 5 * 64 + 63 and r == 0
+    assert float(x[3].min()) == 0.0 and float(x[3].max()) == 1.0 and float(x[:3].max()) <= 1.0
+    clean = ds.transform_observation(ds.state_list[2], jitter_and_noise=False)[3].numpy()
+    dep = np.minimum(d["states"][2]["depth"].astype(np.float64), 1.1) * -1
+    assert np.allclose(clean, (dep - dep.min()) / (dep.max() - dep.min()), atol=1e-6)
+    batch = next(iter(torch.utils.data.DataLoader(ds, batch_size=4)))       # train.py:73
+    assert batch[0].shape == (4, 4, 8, 8) and batch[1].shape == (4,)
