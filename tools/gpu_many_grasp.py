@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """BASELINE.json config 4 shape on one MI355X: N many-object piles (UR5gripper_2_finger_many_objects.xml, the reference's default
 GraspEnv), rendered 200x200 RGB-D observation, multi-discrete [pixel, rotation] actions aimed at an object, full grasp script.
-    python tools/gpu_many_grasp.py [n_scenes] [rounds]"""
+    python tools/gpu_many_grasp.py [n_scenes] [rounds] [many|it4]
+it4 = BASELINE.json config 3 shape: the in-tree UR5gripper_2_finger.xml (3 boxes + 3 spheres), same rendered observation + depth-based z."""
 import os
 import sys
 import time
@@ -14,15 +15,17 @@ from mujoco_rl_ur5_amd.envs import GraspEnv
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 t0 = time.perf_counter()
-env = GraspEnv(n_envs=n, show_obs=False, observation="render")
+which = sys.argv[3] if len(sys.argv) > 3 else "many"
+env = GraspEnv(n_envs=n, show_obs=False, observation="render") if which == "many" else \
+    GraspEnv(file="/UR5+gripper/UR5gripper_2_finger.xml", n_envs=n, show_obs=False, observation="render")
 obs = env.reset()
 print(f"create + reset (drop, settle 1000 ms, render): {time.perf_counter() - t0:.2f} s; depth range {obs['depth'].min():.3f} .. {obs['depth'].max():.3f} m")
 c0 = env.sim.counters()
 for r in range(rounds):
-    q = env.sim.get_state()["qpos"]
+    xp = env.sim.body_xpos()[:, 8:8 + (env.model.nv - 8) // 6]            # world positions of the objects
     acts = np.zeros((n, 2), dtype=np.int64)
     for e in range(n):
-        objs = q[e][8:].reshape(-1, 7)
+        objs = xp[e]
         inbin = np.where((np.abs(objs[:, 0]) < 0.2) & (np.abs(objs[:, 1] + 0.6) < 0.13) & (objs[:, 2] > 0.85))[0]
         k = inbin[(e + r) % len(inbin)] if len(inbin) else 0
         px, py = env.controller.world_2_pixel(objs[k, :3])
