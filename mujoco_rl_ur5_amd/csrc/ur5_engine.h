@@ -1390,8 +1390,50 @@ template <class real, int NV_> struct Engine {
     for (int k = 1; k < NB; k++) v += w[k] * (ea[0] * eb[k] + ea[k] * eb[0]) + w[NB - 1 + k] * ea[k] * eb[k];
     return v;
   }
-  // gradient and Newton direction at S.x (images in S.ce / S.sr_jar must be current): S.search = -H^-1 grad
-  UR5_PHASE_H void newton_direction() {
+  // every contact lane scatters its two sides: doW -> body wrenches WB (the gradient), doG -> twist-space Hessians G
+  UR5_FN void contact_scatter(const bool doW, const bool doG) {
+    PAR(c, S.ncon) {
+      v3 ax[3] = {v3(S.cframe[c]), v3(S.cframe[c] + 3), cross(v3(S.cframe[c]), v3(S.cframe[c] + 3))};
+      real fb[NB], w[2 * NB - 1];
+      contact_weights(c, fb, w);
+#ifdef UR5_EMUL
+      S.cfn[c] = fb[0];
+#endif
+      v3 F = ax[0] * fb[0] + ax[1] * fb[1] + ax[2] * fb[2];
+      v3 T = ax[0] * fb[3];
+      if constexpr (NB > 4) T = T + ax[1] * fb[NB - 2] + ax[2] * fb[NB - 1];
+      for (int side = 0; side < 2; side++) {
+        int b = side == 0 ? S.cA[c] : S.cB[c];
+        if (b < 0) continue;
+        real sg = side == 0 ? (real)-1 : (real)1;
+        v3 r = v3(S.cpos[c]) - body_ref(b);
+        v3 Mo = cross(r, F) + T;
+        const int sl = slot_of(b);
+        if (doW) {
+          UR5_ATOMIC_ADD(&S.WB[sl][0], sg * Mo.x); UR5_ATOMIC_ADD(&S.WB[sl][1], sg * Mo.y); UR5_ATOMIC_ADD(&S.WB[sl][2], sg * Mo.z);
+          UR5_ATOMIC_ADD(&S.WB[sl][3], sg * F.x); UR5_ATOMIC_ADD(&S.WB[sl][4], sg * F.y); UR5_ATOMIC_ADD(&S.WB[sl][5], sg * F.z);
+        }
+        if (!doG) continue;
+        // F_k (6-vector [rot; lin]): k<3 -> [r x a_k ; a_k], k>=3 -> [a_{k-3} ; 0];  G += sum_kl W_kl F_k F_l^T (arrow-shaped W)
+        real Fk[NB][6];
+        for (int k = 0; k < 3; k++) {
+          v3 ra = cross(r, ax[k]);
+          Fk[k][0] = ra.x; Fk[k][1] = ra.y; Fk[k][2] = ra.z; Fk[k][3] = ax[k].x; Fk[k][4] = ax[k].y; Fk[k][5] = ax[k].z;
+          if (3 + k < NB) { Fk[3 + k][0] = ax[k].x; Fk[3 + k][1] = ax[k].y; Fk[3 + k][2] = ax[k].z; Fk[3 + k][3] = 0; Fk[3 + k][4] = 0; Fk[3 + k][5] = 0; }
+        }
+        int ent = 0;
+        for (int gi = 0; gi < 6; gi++)
+          for (int gj = 0; gj <= gi; gj++, ent++) {
+            real v = w[0] * Fk[0][gi] * Fk[0][gj];
+            for (int k = 1; k < NB; k++) v += w[k] * (Fk[0][gi] * Fk[k][gj] + Fk[k][gi] * Fk[0][gj]) + w[NB - 1 + k] * Fk[k][gi] * Fk[k][gj];
+            if (v != 0) UR5_ATOMIC_ADD(&S.G[sl][ent], v);
+          }
+      }
+    }
+  }
+  // gradient at S.x (images in S.ce / S.sr_jar must be current) and, unless `check` finds it below the tolerance (returns true:
+  // converged, nothing else computed), the Newton direction S.search = -H^-1 grad
+  UR5_PHASE_H bool newton_direction(const bool check, const real scale, const real tolerance) {
     PROF_T0();
     const int nbod = nb();
     // per-body wrench (gradient) and 6x6 twist-space Hessian accumulators: every contact lane scatters its two sides with
@@ -1419,42 +1461,7 @@ template <class real, int NV_> struct Engine {
 #else
     const bool refactor = true;
 #endif
-    PAR(c, S.ncon) {
-      v3 ax[3] = {v3(S.cframe[c]), v3(S.cframe[c] + 3), cross(v3(S.cframe[c]), v3(S.cframe[c] + 3))};
-      real fb[NB], w[2 * NB - 1];
-      contact_weights(c, fb, w);
-#ifdef UR5_EMUL
-      S.cfn[c] = fb[0];
-#endif
-      v3 F = ax[0] * fb[0] + ax[1] * fb[1] + ax[2] * fb[2];
-      v3 T = ax[0] * fb[3];
-      if constexpr (NB > 4) T = T + ax[1] * fb[NB - 2] + ax[2] * fb[NB - 1];
-      for (int side = 0; side < 2; side++) {
-        int b = side == 0 ? S.cA[c] : S.cB[c];
-        if (b < 0) continue;
-        real sg = side == 0 ? (real)-1 : (real)1;
-        v3 r = v3(S.cpos[c]) - body_ref(b);
-        v3 Mo = cross(r, F) + T;
-        const int sl = slot_of(b);
-        UR5_ATOMIC_ADD(&S.WB[sl][0], sg * Mo.x); UR5_ATOMIC_ADD(&S.WB[sl][1], sg * Mo.y); UR5_ATOMIC_ADD(&S.WB[sl][2], sg * Mo.z);
-        UR5_ATOMIC_ADD(&S.WB[sl][3], sg * F.x); UR5_ATOMIC_ADD(&S.WB[sl][4], sg * F.y); UR5_ATOMIC_ADD(&S.WB[sl][5], sg * F.z);
-        // F_k (6-vector [rot; lin]): k<3 -> [r x a_k ; a_k], k>=3 -> [a_{k-3} ; 0];  G += sum_kl W_kl F_k F_l^T (arrow-shaped W)
-        real Fk[NB][6];
-        for (int k = 0; k < 3; k++) {
-          v3 ra = cross(r, ax[k]);
-          Fk[k][0] = ra.x; Fk[k][1] = ra.y; Fk[k][2] = ra.z; Fk[k][3] = ax[k].x; Fk[k][4] = ax[k].y; Fk[k][5] = ax[k].z;
-          if (3 + k < NB) { Fk[3 + k][0] = ax[k].x; Fk[3 + k][1] = ax[k].y; Fk[3 + k][2] = ax[k].z; Fk[3 + k][3] = 0; Fk[3 + k][4] = 0; Fk[3 + k][5] = 0; }
-        }
-        if (!refactor) continue;
-        int ent = 0;
-        for (int gi = 0; gi < 6; gi++)
-          for (int gj = 0; gj <= gi; gj++, ent++) {
-            real v = w[0] * Fk[0][gi] * Fk[0][gj];
-            for (int k = 1; k < NB; k++) v += w[k] * (Fk[0][gi] * Fk[k][gj] + Fk[k][gi] * Fk[0][gj]) + w[NB - 1 + k] * Fk[k][gi] * Fk[k][gj];
-            if (v != 0) UR5_ATOMIC_ADD(&S.G[sl][ent], v);
-          }
-      }
-    }
+    contact_scatter(true, !check && refactor);   // first iteration: one pass does both
     SYNC();
     // gradient = Ma - fs - J^T f
     PAR(i, M.nv) {
@@ -1477,6 +1484,13 @@ template <class real, int NV_> struct Engine {
       S.grad[i] = S.Ma[i] - S.fs[i] - jf;
       S.search[i] = S.grad[i];
     }
+    if (check) {   // iterations after the first: the Hessian is only worth building when the gradient says "not converged"
+      real gn = 0;
+      PAR(i, M.nv) gn += S.grad[i] * S.grad[i];
+      gn = WAVE_SUM(gn);
+      if (scale * sqrt(gn) < tolerance) return true;
+      if (refactor) { contact_scatter(false, true); SYNC(); }
+    }
     PROF(PF_GRADG);
 #ifdef UR5_MANY
     if (UR5_LANE == 0) { S.act_changed = 0; if (!refactor) S.nskip++; }   // every lane read the flag before the barrier above
@@ -1488,10 +1502,10 @@ template <class real, int NV_> struct Engine {
       if (refactor) { envelope_assemble<false>(); PROF(PF_HASM); envelope_factor<false>(); PROF(PF_CHOL); }
       envelope_solve<false>(); PROF(PF_SOLVE);
     }
-    return;
+    return false;
 #else
 #ifndef UR5_EMUL
-    if (S.ncouple == 0 && M.nrd == UR5_MAXRD) { newton_blockdiag(); PROF(PF_SOLVE); return; }
+    if (S.ncouple == 0 && M.nrd == UR5_MAXRD) { newton_blockdiag(); PROF(PF_SOLVE); return false; }
 #endif
     // Hessian, lower triangle
     const int nv = M.nv, LD = L::LD;
@@ -1574,6 +1588,7 @@ template <class real, int NV_> struct Engine {
     PROF(PF_SOLVE);
 #endif
 #endif   // UR5_MANY
+    return false;
   }
 
 #if !defined(UR5_EMUL) && !defined(UR5_MANY)
@@ -2180,13 +2195,10 @@ template <class real, int NV_> struct Engine {
     int iters = 0;
     real improvement = 1;
     for (int it = 0;; it++) {
-      newton_direction();   // gradient + search direction at the current point (single call site)
-      if (it > 0) {
-        real gn = 0;
-        PAR(i, nv) gn += S.grad[i] * S.grad[i];
-        gn = WAVE_SUM(gn);
-        if (improvement < tolerance || scale * sqrt(gn) < tolerance) break;
-      }
+      // MuJoCo evaluates gradient + Hessian, then tests (improvement < tol || |grad| < tol) and the iteration cap; the tests that do
+      // not need the new gradient come first here, the gradient test sits inside newton_direction before the Hessian is built
+      if (it > 0 && improvement < tolerance) break;
+      if (newton_direction(it > 0, scale, tolerance)) break;   // single call site
       if (it >= M.iterations) break;
       iters = it + 1;
       PROF_T0();
