@@ -94,10 +94,28 @@ __constant__ Ur5DevModel ur5_cmodel;
 #define PAR(i, n) for (int i = (int)threadIdx.x; i < (n); i += UR5_NT)
 #define SYNC() __syncthreads()
 #define UR5_LANE ((int)threadIdx.x)
-template <class T> __device__ __forceinline__ T ur5_wave_sum(T v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+// Wave-wide sum / max with DPP (data-parallel primitives: the adder reads a neighbour lane's register directly) instead of
+// __shfl_xor, which goes through the LDS crossbar (ds_bpermute) six times per value: quad swaps, row mirrors, then the two
+// row broadcasts of GFX9 leave the total in lane 63, which v_readlane hands to every lane.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ double ur5_dpp(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double ur5_lane63(double v) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
+}
+template <class T> __device__ __forceinline__ T ur5_wave_sum(T v0) {
+  double v = (double)v0;
+  v += ur5_dpp<0xb1, 0xf>(v);    // quad_perm [1,0,3,2]
+  v += ur5_dpp<0x4e, 0xf>(v);    // quad_perm [2,3,0,1]
+  v += ur5_dpp<0x141, 0xf>(v);   // row_half_mirror
+  v += ur5_dpp<0x140, 0xf>(v);   // row_mirror: every lane of a 16-lane row holds the row sum
+  v += ur5_dpp<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3 (other rows add the 0 of `old`)
+  v += ur5_dpp<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3: lane 63 = total
+  return (T)ur5_lane63(v);
 }
 template <class T> __device__ __forceinline__ T ur5_wave_max(T v) {
 #pragma unroll
@@ -1106,6 +1124,7 @@ template <class real, int NV_> struct Engine {
       if (ncand > UR5_MAXCAND) ncand = UR5_MAXCAND;
 #endif
     }
+    if (UR5_LANE == 0) S.ncand = ncand;
     SYNC();
     PROF(PF_BROAD);
     // narrow phase: one candidate per lane, single pass
@@ -2586,6 +2605,8 @@ template <class real, int NV_> struct Engine {
     out[o++] = S.env_ptr[M.nv]; out[o++] = S.ncouple;   // envelope size (doubles), contacts between two movable bodies
     { int ns = 0; for (int p2 = 0; p2 <= M.nobj; p2++) if (S.blk_first[p2] != p2 || S.blk_last[p2] != p2) ns++; out[o++] = ns; }   // coupled blocks
 #endif
+    out[7] = S.ncand;
+    for (int i = 0; i < S.ncand && i < UR5_MAXCAND; i++) out[UR5_DEBUG_STRIDE - UR5_MAXCAND + i] = S.cand[i];   // broad-phase survivors (pair indices)
     o = 8;
     for (int b = 0; b < UR5_MAXB; b++) for (int k = 0; k < 3; k++) out[o++] = b < nb() ? (double)S.bpos[b][k] : 0;      // 8   .. 50
     for (int d = 0; d < UR5_MAXRD; d++) for (int e = 0; e < UR5_MAXRD; e++) out[o++] = (double)S.Mr[d][e];               // 50  .. 114
