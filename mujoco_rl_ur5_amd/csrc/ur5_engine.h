@@ -2168,35 +2168,69 @@ template <class real, int NV_> struct Engine {
 #ifdef UR5_MANY
     if (UR5_LANE == 0) S.act_changed = 1;   // new contacts, new Hessian: the first iteration of a step always factors
 #endif
-    // warm start: cheaper of qacc_warmstart and qacc_smooth
-    real ccw;
-    PAR(i, nv) S.x[i] = warm()[i];
+    // warm start: cheaper of qacc_warmstart and qacc_smooth. Both candidates go through the same three passes together: M v and
+    // body twists (tw <- warm start, WB <- qacc_smooth; WB is free until the gradient is built), contact / row images, costs.
+    PAR(i, nv) {
+      S.x[i] = warm()[i];
+      if (i < M.nrd) {
+        real sw = 0, ss = 0;
+        for (int e = 0; e < M.nrd; e++) { sw += S.Mr[i][e] * warm()[e]; ss += S.Mr[i][e] * S.as[e]; }
+        S.Ma[i] = sw; S.Mv[i] = ss;
+      } else { S.Ma[i] = S.Mobj[i - M.nrd] * warm()[i]; S.Mv[i] = S.Mobj[i - M.nrd] * S.as[i]; }
+    }
+    PAR(sl, nslot()) {
+      const int b = body_of_slot(sl);
+      if (b < M.nrd) {
+        real vw[6] = {0, 0, 0, 0, 0, 0}, vs[6] = {0, 0, 0, 0, 0, 0};
+        for (int e = 0; e < M.nrd; e++) if (M.rd_anc[b] >> e & 1u) {
+          const real qw = warm()[e], qs = S.as[e];
+          for (int i = 0; i < 6; i++) { vw[i] += S.cdof[e][i] * qw; vs[i] += S.cdof[e][i] * qs; }
+        }
+        for (int i = 0; i < 6; i++) { S.tw[sl][i] = vw[i]; S.WB[sl][i] = vs[i]; }
+      } else {
+        const int va = M.nrd + 6 * (b - M.nrd);
+        m3 R; R.load(S.bmat[b]);
+        mul(R, v3(warm()[va + 3], warm()[va + 4], warm()[va + 5])).store(S.tw[sl]);
+        v3(warm()[va], warm()[va + 1], warm()[va + 2]).store(S.tw[sl] + 3);
+        mul(R, v3(S.as[va + 3], S.as[va + 4], S.as[va + 5])).store(S.WB[sl]);
+        v3(S.as[va], S.as[va + 1], S.as[va + 2]).store(S.WB[sl] + 3);
+      }
+    }
     SYNC();
-    mat_vec_M(S.x, S.Ma);
-    images(S.x, true, S.ce, S.sr_jar);
-    PAR(c, S.ncon) for (int k = 0; k < NB; k++) S.cde[c][k] = 0;
-    PAR(s, S.nsr) S.sr_jv[s] = 0;
-    SYNC();
-    ccw = constraint_cost(0).c;
-    real cw = gauss_cost(S.x, S.Ma) + ccw;
-    SYNC();
-    mat_vec_M(S.as, S.Mv);
-    images(S.as, true, S.cde, S.tmpv);  // scratch: cde / tmpv hold the images at qacc_smooth
-    // cost at qacc_smooth: Gauss term vanishes
-    real cs;
+    real cw, cs;
     {
-      real c0 = 0;
+      real c_w = 0, c_s = 0;
       PAR(c, S.ncon) {
-        real D = S.cD[c], e0 = S.cde[c][0];
-        if (S.cdim[c] == 1) { if (e0 < 0) c0 += (real)0.5 * D * e0 * e0; }
-        else for (int k = 1; k < S.cdim[c]; k++) {
-          real ek = row_mu(c, k) * S.cde[c][k], rp = e0 + ek, rm = e0 - ek;
-          if (rp < 0) c0 += (real)0.5 * D * rp * rp;
-          if (rm < 0) c0 += (real)0.5 * D * rm * rm;
+        const bool hasA = S.cA[c] >= 0, hasB = S.cB[c] >= 0;
+        const int slA = hasA ? slot_of(S.cA[c]) : 0, slB = hasB ? slot_of(S.cB[c]) : 0;
+        real ew[NB], es[NB];
+        contact_image(c, S.tw[slA], S.tw[slB], hasA, hasB, ew);
+        contact_image(c, S.WB[slA], S.WB[slB], hasA, hasB, es);
+        for (int k = 0; k < NB; k++) { ew[k] += S.ceoff[c][k]; es[k] += S.ceoff[c][k]; S.ce[c][k] = ew[k]; S.cde[c][k] = es[k]; }
+        const real D = S.cD[c];
+        if (S.cdim[c] == 1) {
+          if (ew[0] < 0) c_w += (real)0.5 * D * ew[0] * ew[0];
+          if (es[0] < 0) c_s += (real)0.5 * D * es[0] * es[0];
+        } else for (int k = 1; k < S.cdim[c]; k++) {
+          const real mu = row_mu(c, k);
+          real rp = ew[0] + mu * ew[k], rm = ew[0] - mu * ew[k];
+          if (rp < 0) c_w += (real)0.5 * D * rp * rp;
+          if (rm < 0) c_w += (real)0.5 * D * rm * rm;
+          rp = es[0] + mu * es[k]; rm = es[0] - mu * es[k];
+          if (rp < 0) c_s += (real)0.5 * D * rp * rp;
+          if (rm < 0) c_s += (real)0.5 * D * rm * rm;
         }
       }
-      PAR(s, S.nsr) { real r = S.tmpv[s]; if (!S.sr_uni[s] || r < 0) c0 += (real)0.5 * S.sr_D[s] * r * r; }
-      cs = WAVE_SUM(c0);
+      PAR(s2, S.nsr) {
+        real vw = S.sr_c1[s2] * warm()[S.sr_d1[s2]], vs = S.sr_c1[s2] * S.as[S.sr_d1[s2]];
+        if (S.sr_d2[s2] >= 0) { vw += S.sr_c2[s2] * warm()[S.sr_d2[s2]]; vs += S.sr_c2[s2] * S.as[S.sr_d2[s2]]; }
+        vw -= S.sr_aref[s2]; vs -= S.sr_aref[s2];
+        S.sr_jar[s2] = vw; S.tmpv[s2] = vs;
+        if (!S.sr_uni[s2] || vw < 0) c_w += (real)0.5 * S.sr_D[s2] * vw * vw;
+        if (!S.sr_uni[s2] || vs < 0) c_s += (real)0.5 * S.sr_D[s2] * vs * vs;
+      }
+      PAR(i, nv) c_w += (real)0.5 * (S.Ma[i] - S.fs[i]) * (S.x[i] - S.as[i]);   // Gauss term; it vanishes at qacc_smooth
+      cw = WAVE_SUM(c_w); cs = WAVE_SUM(c_s);
     }
     SYNC();
     real cost;
