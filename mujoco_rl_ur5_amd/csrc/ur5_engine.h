@@ -1192,7 +1192,60 @@ template <class real, int NV_> struct Engine {
     if constexpr (NB > 4) { e[NB - 2] = dot(t1, w); e[NB - 1] = dot(t2, w); }
   }
   UR5_PHASE_B void make_constraints() {
-    // special rows are few and depend on wave-uniform data only: lane 0 builds them
+#if !defined(UR5_EMUL) && UR5_NT == 64
+    // special rows (joint equality, violated joint / slide limits): one candidate per lane -- [0, neq) equalities, then 2 sides of
+    // every robot joint, then 2 sides of every object slide -- compacted in candidate order (= the serial order below) with a ballot
+    const int ncand_rows = M.neq + 2 * M.nrd + 6 * M.nobj;
+    if (ncand_rows <= 64) {
+      const int t = UR5_LANE;
+      bool on = false;
+      int d1 = 0, d2 = -1, uni = 1;
+      real c1 = 0, c2 = 0, Dr = 0, aref = 0;
+      if (t < M.neq) {
+        const int e = t;
+        d1 = M.eq_d1[e]; d2 = M.eq_d2[e];
+        const double* pc = M.eq_poly[e];
+        real xq = qpos()[d2] - (real)M.rd_qpos0[d2];
+        real poly = (real)pc[0] + xq * ((real)pc[1] + xq * ((real)pc[2] + xq * ((real)pc[3] + xq * (real)pc[4])));
+        real dpoly = (real)pc[1] + xq * (2 * (real)pc[2] + xq * (3 * (real)pc[3] + xq * 4 * (real)pc[4]));
+        real pos = (qpos()[d1] - (real)M.rd_qpos0[d1]) - poly;
+        real imp = impedance(M.eq_solimp[e], fabs(pos)), K, B;
+        kbi(M.eq_solref[e], M.eq_solimp[e], imp, &K, &B);
+        real dA = (real)M.rd_invweight[d1] + (real)M.rd_invweight[d2];
+        real R = maxv((real)1e-15, (1 - imp) * dA / imp);
+        real vel = qvel()[d1] - dpoly * qvel()[d2];
+        on = true; c1 = 1; c2 = -dpoly; uni = 0; Dr = (real)1 / R; aref = -B * vel - K * imp * pos;
+      } else if (t < ncand_rows) {
+        const int u = t - M.neq;
+        const bool robot = u < 2 * M.nrd;
+        const int v = robot ? u : u - 2 * M.nrd;
+        const int side = v & 1, jj = v >> 1;                    // robot: jj = dof; object: jj = 3 * k + slide
+        const int k = robot ? 0 : jj / 3, j = robot ? 0 : jj % 3;
+        const bool limited = robot ? M.rd_limited[jj] != 0 : (M.obj_kind[k] == 0 && M.obj_limited[k][j] != 0);
+        if (limited) {
+          const int qa = robot ? jj : M.nrd + 7 * k + j;
+          d1 = robot ? jj : M.nrd + 6 * k + j;
+          const real lo = robot ? (real)M.rd_lo[jj] : (real)M.obj_lo[k][j], hi = robot ? (real)M.rd_hi[jj] : (real)M.obj_hi[k][j];
+          const real dist = side == 0 ? qpos()[qa] - lo : hi - qpos()[qa];
+          if (dist < 0) {
+            const real sg = side == 0 ? (real)1 : (real)-1;
+            real imp = impedance(M.jnt_solimp, fabs(dist)), K, B;
+            kbi(M.jnt_solref, M.jnt_solimp, imp, &K, &B);
+            const real iw = robot ? (real)M.rd_invweight[jj] : (real)M.obj_invweight[k][0];
+            real R = maxv((real)1e-15, (1 - imp) * iw / imp);
+            on = true; c1 = sg; Dr = (real)1 / R; aref = -B * sg * qvel()[d1] - K * imp * dist;
+          }
+        }
+      }
+      const unsigned long long mask = __ballot(on);
+      const int slot = __popcll(mask & ((1ull << t) - 1ull));
+      if (on && slot < UR5_MAXSR) {
+        S.sr_d1[slot] = d1; S.sr_d2[slot] = d2; S.sr_c1[slot] = c1; S.sr_c2[slot] = c2; S.sr_uni[slot] = uni; S.sr_D[slot] = Dr; S.sr_aref[slot] = aref;
+      }
+      if (t == 0) { const int n = __popcll(mask); S.nsr = n < UR5_MAXSR ? n : UR5_MAXSR; }
+    } else
+#endif
+    // ... or lane 0 builds them one after the other (lane emulation, scenes with more candidates than lanes)
     if (UR5_LANE == 0) {
       int ns = 0;
       for (int e = 0; e < M.neq; e++) {
