@@ -61,6 +61,7 @@ enum { UR5_KIND_STATIC = 0, UR5_KIND_ROBOT = 1, UR5_KIND_OBJECT = 2 };
 #define UR5_ST_CONTACT_OVERFLOW 1
 #define UR5_ST_NAN 2
 #define UR5_ST_ROW_OVERFLOW 4
+#define UR5_ST_CAND_OVERFLOW 8                       // more broad-phase survivors than UR5_MAXCAND: pairs were dropped
 
 struct Ur5DevModel {
   int nrd, nobj, nv, nq, nu, ngeom, npair, neq, ndg, iterations, ee_cbody, nrg;

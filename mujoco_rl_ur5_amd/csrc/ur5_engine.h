@@ -1095,7 +1095,7 @@ template <class real, int NV_> struct Engine {
       for (int p = p0; p < p0 + UR5_NT && p < M.npair; p++) {
         int g1 = M.pair_g1[p], g2 = M.pair_g2[p];
         real margin = maxv((real)M.g_margin[g1], (real)M.g_margin[g2]);
-        if (!cull(g1, g2, margin) && ncand < UR5_MAXCAND) S.cand[ncand++] = (short)p;
+        if (!cull(g1, g2, margin)) { if (ncand < UR5_MAXCAND) S.cand[ncand] = (short)p; ncand++; }
       }
 #else
       int p = p0 + UR5_LANE;
@@ -1121,10 +1121,10 @@ template <class real, int NV_> struct Engine {
       ncand += total;
       SYNC();
 #endif
-      if (ncand > UR5_MAXCAND) ncand = UR5_MAXCAND;
 #endif
     }
-    if (UR5_LANE == 0) S.ncand = ncand;
+    if (UR5_LANE == 0) { S.ncand = ncand < UR5_MAXCAND ? ncand : UR5_MAXCAND; if (ncand > UR5_MAXCAND) S.status |= UR5_ST_CAND_OVERFLOW; }
+    if (ncand > UR5_MAXCAND) ncand = UR5_MAXCAND;
     SYNC();
     PROF(PF_BROAD);
     // narrow phase: one candidate per lane, single pass
