@@ -377,6 +377,12 @@ template <class real, int NV_> struct Engine {
 #endif
   UR5_FN void save(double* rec) {
     SYNC();
+    {   // a non-finite state is flagged, never silently written back as if it were a result
+      bool bad = false;
+      PAR(i, M.nq + M.nv) { real v = S.rec[i < M.nq ? UR5_REC_QPOS + i : UR5_REC_QVEL + (i - M.nq)]; if (!(v - v == 0)) bad = true; }
+      if (bad) S.status |= UR5_ST_NAN;   // benign race: every writer ORs the same bit into a word nobody else changes here
+    }
+    SYNC();
     if (UR5_LANE == 0) {
       S.rec[UR5_REC_MISC + 0] += (real)S.total_steps;
       S.rec[UR5_REC_MISC + 1] = (real)S.last_steps;
@@ -1242,7 +1248,7 @@ template <class real, int NV_> struct Engine {
       if (on && slot < UR5_MAXSR) {
         S.sr_d1[slot] = d1; S.sr_d2[slot] = d2; S.sr_c1[slot] = c1; S.sr_c2[slot] = c2; S.sr_uni[slot] = uni; S.sr_D[slot] = Dr; S.sr_aref[slot] = aref;
       }
-      if (t == 0) { const int n = __popcll(mask); S.nsr = n < UR5_MAXSR ? n : UR5_MAXSR; }
+      if (t == 0) { const int n = __popcll(mask); S.nsr = n < UR5_MAXSR ? n : UR5_MAXSR; if (n > UR5_MAXSR) S.status |= UR5_ST_ROW_OVERFLOW; }
     } else
 #endif
     // ... or lane 0 builds them one after the other (lane emulation, scenes with more candidates than lanes)
@@ -1268,7 +1274,8 @@ template <class real, int NV_> struct Engine {
         if (!M.rd_limited[d]) continue;
         for (int side = 0; side < 2; side++) {
           real dist = side == 0 ? qpos()[d] - (real)M.rd_lo[d] : (real)M.rd_hi[d] - qpos()[d];
-          if (dist >= 0 || ns >= UR5_MAXSR) continue;
+          if (dist >= 0) continue;
+          if (ns >= UR5_MAXSR) { S.status |= UR5_ST_ROW_OVERFLOW; continue; }
           real sg = side == 0 ? (real)1 : (real)-1;
           real imp = impedance(M.jnt_solimp, fabs(dist)), K, B;
           kbi(M.jnt_solref, M.jnt_solimp, imp, &K, &B);
@@ -1285,7 +1292,8 @@ template <class real, int NV_> struct Engine {
           int qa = M.nrd + 7 * k + j, d = M.nrd + 6 * k + j;
           for (int side = 0; side < 2; side++) {
             real dist = side == 0 ? qpos()[qa] - (real)M.obj_lo[k][j] : (real)M.obj_hi[k][j] - qpos()[qa];
-            if (dist >= 0 || ns >= UR5_MAXSR) continue;
+            if (dist >= 0) continue;
+          if (ns >= UR5_MAXSR) { S.status |= UR5_ST_ROW_OVERFLOW; continue; }
             real sg = side == 0 ? (real)1 : (real)-1;
             real imp = impedance(M.jnt_solimp, fabs(dist)), K, B;
             kbi(M.jnt_solref, M.jnt_solimp, imp, &K, &B);

@@ -136,3 +136,15 @@ def test_two_finger_six_object_scene_runs(model_2f, emul_lib):
     assert sim.counters()["status"][0] == 0
     quats = s["qpos"][0][8:].reshape(-1, 7)[:, 3:]
     assert np.abs(np.linalg.norm(quats, axis=1) - 1).max() < 1e-12
+
+
+def test_non_finite_state_is_flagged(model_it1, emul_lib):
+    """A NaN must never come back looking like a result: status bit 2 (include/ur5sim.h) is set for that scene only."""
+    sim = BatchSim(model_it1, 2, lib_path=emul_lib)
+    sim.reset([20, 21], 1, 0.0)
+    st = sim.get_state()
+    st["qvel"][1, 3] = np.nan
+    sim.set_state(qvel=st["qvel"])
+    sim.step(2)
+    c = sim.counters()
+    assert c["status"][0] == 0 and c["status"][1] & 2
