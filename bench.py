@@ -36,13 +36,14 @@ def aimed_actions(qpos, first_id, round_idx, nobj=4):
     return a
 
 
-def aimed_actions_many(qpos, first_id, round_idx):
-    """--workload many (config 4 shape): scene g aims at one of the objects lying in the pick bin, 2 cm above its centre (what the
-    depth image would give), rotation index cycling through the 6 wrist angles (GraspingEnv.py:40)."""
-    n = qpos.shape[0]
+def aimed_actions_rendered(xpos, first_id, round_idx):
+    """--workload many / it4 (configs[3] / configs[2] shape): scene g aims at one of the objects lying in the pick bin, 2 cm above its
+    centre (what the depth image gives for these object sizes), rotation index cycling through the 6 wrist angles (GraspingEnv.py:40).
+    xpos: world positions of the objects [n, nobj, 3]."""
+    n = xpos.shape[0]
     a = np.zeros((n, 8))
     for e in range(n):
-        objs = qpos[e][8:].reshape(-1, 7)
+        objs = xpos[e]
         inbin = np.where((np.abs(objs[:, 0]) < 0.2) & (np.abs(objs[:, 1] + 0.6) < 0.13) & (objs[:, 2] > 0.85))[0]
         k = inbin[(first_id + e + round_idx) % len(inbin)] if len(inbin) else 0
         a[e, :3] = [objs[k, 0], objs[k, 1], objs[k, 2] + 0.02]
@@ -74,8 +75,9 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--envs", type=int, default=None, help="scenes per GPU (default 4096; 2048 for --workload many)")
-    ap.add_argument("--workload", choices=("it1", "many"), default="it1",
-                    help="it1 = BASELINE.json configs[1] (the headline metric); many = configs[3] shape: 40-object piles, render + grasp round")
+    ap.add_argument("--workload", choices=("it1", "it4", "many"), default="it1",
+                    help="it1 = BASELINE.json configs[1] (the headline metric); it4 = configs[2] shape: in-tree 6-object scene, render + in-tree "
+                         "grasp script; many = configs[3] shape: 40-object piles, render + grasp round")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -95,8 +97,9 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
-    many = args.workload == "many"
-    model = load_model("/UR5+gripper/UR5gripper_2_finger_many_objects.xml" if many else "it1_4box")
+    many, rendered = args.workload == "many", args.workload in ("many", "it4")
+    model = load_model({"many": "/UR5+gripper/UR5gripper_2_finger_many_objects.xml", "it4": "/UR5+gripper/UR5gripper_2_finger.xml",
+                        "it1": "it1_4box"}[args.workload])
     n_local = args.envs if args.envs else (2048 if many else 4096)
     n_total = n_local * world
     lo, hi = sharding.shard_range(n_total, rank, world)
@@ -104,9 +107,12 @@ def main():
     sim.reset(sharding.global_seeds(20, n_total, rank, world), 1, 1000.0)          # GraspingEnv.py:409-477, untimed
     settled = sim.get_state()["qpos"]
     rounds = args.warmup + args.steps
-    mk = aimed_actions_many if many else aimed_actions
-    actions = torch.from_numpy(np.stack([mk(settled, lo, r) for r in range(rounds)])).to(dev)   # [rounds, n, 8] f64 in HBM
-    if many:                                                                      # the observation of every round stays on the device
+    if rendered:
+        xpos = sim.body_xpos()[:, 8:8 + (model.nv - 8) // 6]
+        actions = torch.from_numpy(np.stack([aimed_actions_rendered(xpos, lo, r) for r in range(rounds)])).to(dev)
+    else:
+        actions = torch.from_numpy(np.stack([aimed_actions(settled, lo, r) for r in range(rounds)])).to(dev)   # [rounds, n, 8] f64 in HBM
+    if rendered:                                                                  # the observation of every round stays on the device
         img = torch.zeros((n_local, 200, 200, 3), dtype=torch.uint8, device=dev)
         dep = torch.zeros((n_local, 200, 200), dtype=torch.float32, device=dev)
         cam = model.camera_name2id("top_down")
@@ -114,9 +120,9 @@ def main():
     ids = torch.arange(lo, hi, dtype=torch.int32, device=dev)
 
     def one_round(r):
-        if many:
+        if rendered:
             sim.render_dev(img.data_ptr(), dep.data_ptr(), cam, 200, 200, 1)       # get_observation (GraspingEnv.py:390-406), same stream
-        sim.grasp_attempt_dev(actions[r].data_ptr(), reward[r].data_ptr(), check_mode=1 if not many else 0, table_height=0.91)
+        sim.grasp_attempt_dev(actions[r].data_ptr(), reward[r].data_ptr(), check_mode=0 if rendered else 1, table_height=0.91)
         sim.sync()                                                             # handle stream -> host; rewards now valid
         rec = torch.stack([ids, torch.zeros_like(ids), actions[r, :, 3].to(torch.int32), reward[r]], dim=1)
         return sharding.gather_outcomes(rec), sim.last_launch_ms()
@@ -157,7 +163,7 @@ def main():
         # measured HBM bytes per env-step from the rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this same command (profiles/)
         traffic, traffic_src = None, None
         tp = os.path.join(ROOT, "profiles", "r01_i_hbm_traffic.json")
-        if os.path.exists(tp) and not many:
+        if os.path.exists(tp) and not rendered:
             with open(tp) as f:
                 tj = json.load(f)
             traffic = tj["hbm_bytes_per_env_step"] * steps_local / args.steps
@@ -173,12 +179,14 @@ def main():
             "status_bits": int(np.bitwise_or.reduce(c1["status"])),
             "config": {"workload": ("BASELINE.json configs[3] shape: IT5 many-object piles (UR5gripper_2_finger_many_objects.xml, 40 objects, "
                                     "condim 6), 200x200 RGB-D render + multi-discrete rotation action + in-tree grasp script per step") if many else
+                                   ("BASELINE.json configs[2] shape: IT4 (in-tree UR5gripper_2_finger.xml, 3 boxes + 3 spheres), 200x200 RGB-D render + "
+                                    "grasp height from the object top + in-tree grasp script (closing check at the drop position) per step") if rendered else
                                    ("BASELINE.json configs[1]: IT1 (UR5gripper_2_finger.xml robot + bins, 4 equal 4 cm boxes), physics only, "
                                     "fixed z = 0.91, lift + 500-step closing check, one grasp-attempt round per step"),
                        "scenes_per_gpu": n_local, "scenes_total": n_total, "solver": "Newton (MuJoCo default), tol 1e-10",
                        "timestep_s": model.opt["timestep"], "parallelism": f"scenes sharded x{world}, 1 all_gather of 16 B outcome records per round"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "ur5m_run_kernel<248>" if many else "ur5_run_kernel<32>", "bytes_per_env_step": bytes_per_step,
+                         "kernel": "ur5m_run_kernel<248>" if many else ("ur5_run_kernel<44>" if rendered else "ur5_run_kernel<32>"), "bytes_per_env_step": bytes_per_step,
                          "avg_launch_ms": float(np.mean(kernel_ms)), "env_steps_per_launch": steps_local / args.steps,
                          "note": "algorithmic state bytes x env-steps / HIP-event kernel time on the handle's stream (rank 0). The kernel keeps a "
                                  "scene in LDS for a whole grasp attempt, so real HBM traffic is far below the algorithmic figure; the step is "
