@@ -996,6 +996,32 @@ template <class real, int NV_> struct Engine {
     UR5_EDGE(q0, u0, w0, q1, u1, w1) UR5_EDGE(q1, u1, w1, q2, u2, w2) UR5_EDGE(q2, u2, w2, q3, u3, w3) UR5_EDGE(q3, u3, w3, q0, u0, w0)
 #undef UR5_EDGE
   }
+  // ---- capsule helpers (same restatements as oracle collide_plane_capsule / sphere_capsule / capsule_capsule / capsule_box)
+  UR5_FN void sphere_sphere_at(Sink& out, v3 p1, real r1, v3 p2, real r2, real margin) const {
+    v3 d = p2 - p1;
+    real len = norm(d), dist = len - r1 - r2;
+    if (dist >= margin) return;
+    v3 n = len > (real)1e-12 ? d * ((real)1 / len) : v3(1, 0, 0);
+    emit(out, p1 + n * (r1 + (real)0.5 * dist), n, dist);
+  }
+  // sphere (centre c, radius r) against box (B, s): signed distance; emits the contact when asked to and closer than margin
+  UR5_FN real sphere_box_at(Sink& out, v3 c, real r, const GeomPose& B, v3 s, real margin, bool do_emit) const {
+    v3 cl = mulT(B.mat, c - B.pos);
+    v3 p(clampv(cl.x, -s.x, s.x), clampv(cl.y, -s.y, s.y), clampv(cl.z, -s.z, s.z));
+    v3 d = p - cl;
+    real len = norm(d);
+    if (len > (real)1e-12) {
+      real dist = len - r;
+      if (do_emit && dist < margin) { v3 n = mul(B.mat, d * ((real)1 / len)); emit(out, c + n * (r + (real)0.5 * dist), n, dist); }
+      return dist;
+    }
+    int ax = 0; real best = 1e300;
+    for (int i = 0; i < 3; i++) { real g = s[i] - fabs(cl[i]); if (g < best) { best = g; ax = i; } }
+    v3 el; el.set(ax, cl[ax] >= 0 ? (real)1 : (real)-1);
+    v3 e = mul(B.mat, el);
+    if (do_emit) emit(out, c + e * ((real)0.5 * (best - r)), -e, -best - r);
+    return -best - r;
+  }
   UR5_BIG void narrow(int g1, int g2, real margin, Sink& out, Single& keep) const {
     int t1 = M.g_type[g1], t2 = M.g_type[g2];
     GeomPose A = geom_pose(g1), B = geom_pose(g2);
@@ -1014,11 +1040,64 @@ template <class real, int NV_> struct Engine {
           real d = dot(v - A.pos, n);
           if (d < margin) { emit(out, v - n * ((real)0.5 * d), n, d); cnt++; }
         }
+      } else if (t2 == UR5_GEOM_CAPSULE) {
+        const real r = (real)M.g_size[g2][0], h = (real)M.g_size[g2][1];
+        const v3 ax = B.mat.col(2);
+        for (int e = 0; e < 2; e++) {
+          v3 c = B.pos + ax * (e == 0 ? h : -h);
+          real d = dot(c - A.pos, n) - r;
+          if (d < margin) emit(out, c - n * (r + (real)0.5 * d), n, d);
+        }
       } else {
         Shape s = make_shape(g2, 0);
         v3 v = support(s, -n);
         real d = dot(v - A.pos, n);
         if (d < margin) emit(out, v - n * ((real)0.5 * d), n, d);
+      }
+    } else if (t1 == UR5_GEOM_SPHERE && t2 == UR5_GEOM_CAPSULE) {
+      const v3 ax = B.mat.col(2);
+      const real h = (real)M.g_size[g2][1];
+      const real t = clampv(dot(A.pos - B.pos, ax), -h, h);
+      sphere_sphere_at(out, A.pos, (real)M.g_size[g1][0], B.pos + ax * t, (real)M.g_size[g2][0], margin);
+    } else if (t1 == UR5_GEOM_CAPSULE && t2 == UR5_GEOM_CAPSULE) {
+      const v3 a1 = A.mat.col(2), a2 = B.mat.col(2), w = A.pos - B.pos;
+      const real h1 = (real)M.g_size[g1][1], h2 = (real)M.g_size[g2][1], r1 = (real)M.g_size[g1][0], r2 = (real)M.g_size[g2][0];
+      const real b = dot(a1, a2), d = dot(a1, w), e = dot(a2, w), den = (real)1 - b * b;
+      if (den < (real)1e-6) {   // parallel axes: the overlap of the two segments, one contact at each of its ends
+        const real sgn = b >= 0 ? (real)1 : (real)-1, c2 = -d;
+        real t_lo = maxv(-h1, c2 - h2), t_hi = minv(h1, c2 + h2);
+        if (t_lo > t_hi) { real tm = clampv(c2, -h1, h1); t_lo = t_hi = tm; }
+        const int cnt = t_hi - t_lo > (real)1e-9 ? 2 : 1;
+        for (int k = 0; k < cnt; k++) {
+          real t1p = k == 0 ? t_lo : t_hi;
+          real t2p = clampv(sgn * (t1p - c2), -h2, h2);
+          sphere_sphere_at(out, A.pos + a1 * t1p, r1, B.pos + a2 * t2p, r2, margin);
+        }
+      } else {
+        real t1p = clampv((b * e - d) / den, -h1, h1);
+        real t2p = clampv(e + b * t1p, -h2, h2);
+        t1p = clampv(b * t2p - d, -h1, h1);
+        sphere_sphere_at(out, A.pos + a1 * t1p, r1, B.pos + a2 * t2p, r2, margin);
+      }
+    } else if (t1 == UR5_GEOM_CAPSULE && t2 == UR5_GEOM_BOX) {
+      const v3 ax = A.mat.col(2), s(M.g_size[g2]);
+      const real r = (real)M.g_size[g1][0], h = (real)M.g_size[g1][1];
+      const real d_hi = sphere_box_at(out, A.pos + ax * h, r, B, s, margin, false), d_lo = sphere_box_at(out, A.pos - ax * h, r, B, s, margin, false);
+      if (d_hi < margin && d_lo < margin) {   // lying against a face: the two end spheres
+        sphere_box_at(out, A.pos + ax * h, r, B, s, margin, true);
+        sphere_box_at(out, A.pos - ax * h, r, B, s, margin, true);
+      } else {   // the point of the segment nearest to the box (the distance is convex along the segment: golden-section search)
+        const real gr = (real)0.6180339887498949;
+        real lo = -h, hi = h, x1 = hi - gr * (hi - lo), x2 = lo + gr * (hi - lo);
+        real f1 = sphere_box_at(out, A.pos + ax * x1, r, B, s, margin, false), f2 = sphere_box_at(out, A.pos + ax * x2, r, B, s, margin, false);
+        for (int it = 0; it < 40; it++) {
+          if (f1 < f2) { hi = x2; x2 = x1; f2 = f1; x1 = hi - gr * (hi - lo); f1 = sphere_box_at(out, A.pos + ax * x1, r, B, s, margin, false); }
+          else { lo = x1; x1 = x2; f1 = f2; x2 = lo + gr * (hi - lo); f2 = sphere_box_at(out, A.pos + ax * x2, r, B, s, margin, false); }
+        }
+        real t = (real)0.5 * (lo + hi);
+        const real fm = minv(f1, f2);
+        if (d_hi <= fm) t = h; else if (d_lo <= fm) t = -h;
+        sphere_box_at(out, A.pos + ax * t, r, B, s, margin, true);
       }
     } else if (t1 == UR5_GEOM_SPHERE && t2 == UR5_GEOM_SPHERE) {
       v3 d = B.pos - A.pos;

@@ -755,6 +755,96 @@ struct Sim {
     }
   }
 
+  // ---- capsules: a segment of half length size[1] along local z with radius size[0]. MuJoCo treats plane / sphere / capsule /
+  // box partners analytically [3P: mjc_PlaneCapsule, mjc_SphereCapsule, mjc_CapsuleCapsule, mjc_CapsuleBox]; only their results'
+  // shape is documented (two contacts for a capsule lying on a plane or a box face, one otherwise), so the routines below are own
+  // restatements built from sphere tests at points of the segment. Other partners (cylinder, mesh) go through MPR as in MuJoCo.
+  void sphere_at_vs_sphere_at(int g1, int g2, V3 p1, double r1, V3 p2, double r2, double margin) {
+    V3 d = p2 - p1;
+    double len = norm(d), dist = len - r1 - r2;
+    if (dist >= margin) return;
+    V3 n = len > 1e-12 ? d * (1.0 / len) : V3(1, 0, 0);
+    add_contact(g1, g2, dist, p1 + n * (r1 + 0.5 * dist), n, margin);
+  }
+  // sphere (centre c, radius r, geom g1) against box g2; returns the signed distance (1e300 when the pair was not evaluated)
+  double sphere_at_vs_box(int g1, int g2, V3 c, double r, double margin, bool emit) {
+    V3 s = v3(M.geom_size + 3 * g2);
+    V3 cl = mulT(gxmat[g2], c - gxpos[g2]);
+    V3 p(std::min(std::max(cl.x, -s.x), s.x), std::min(std::max(cl.y, -s.y), s.y), std::min(std::max(cl.z, -s.z), s.z));
+    V3 d = p - cl;
+    double len = norm(d);
+    if (len > 1e-12) {
+      double dist = len - r;
+      if (emit && dist < margin) { V3 n = mul(gxmat[g2], d * (1.0 / len)); add_contact(g1, g2, dist, c + n * (r + 0.5 * dist), n, margin); }
+      return dist;
+    }
+    int ax = 0;
+    double best = 1e300;
+    for (int i = 0; i < 3; i++) { double g = s[i] - std::fabs(cl[i]); if (g < best) { best = g; ax = i; } }
+    V3 el; el[ax] = cl[ax] >= 0 ? 1.0 : -1.0;
+    V3 e = mul(gxmat[g2], el);
+    if (emit) add_contact(g1, g2, -best - r, c + e * (0.5 * (best - r)), -e, margin);
+    return -best - r;
+  }
+  void collide_plane_capsule(int g1, int g2, double margin) {   // both end spheres
+    V3 n = gxmat[g1].col(2), ax = gxmat[g2].col(2);
+    double r = M.geom_size[3 * g2], h = M.geom_size[3 * g2 + 1];
+    for (int e = 0; e < 2; e++) {
+      V3 c = gxpos[g2] + ax * (e == 0 ? h : -h);
+      double d = dot(c - gxpos[g1], n) - r;
+      if (d < margin) add_contact(g1, g2, d, c - n * (r + 0.5 * d), n, margin);
+    }
+  }
+  void collide_sphere_capsule(int g1, int g2, double margin) {  // sphere against the nearest point of the segment
+    V3 ax = gxmat[g2].col(2);
+    double h = M.geom_size[3 * g2 + 1];
+    double t = std::min(std::max(dot(gxpos[g1] - gxpos[g2], ax), -h), h);
+    sphere_at_vs_sphere_at(g1, g2, gxpos[g1], M.geom_size[3 * g1], gxpos[g2] + ax * t, M.geom_size[3 * g2], margin);
+  }
+  void collide_capsule_capsule(int g1, int g2, double margin) {
+    V3 a1 = gxmat[g1].col(2), a2 = gxmat[g2].col(2), w = gxpos[g1] - gxpos[g2];
+    double h1 = M.geom_size[3 * g1 + 1], h2 = M.geom_size[3 * g2 + 1], r1 = M.geom_size[3 * g1], r2 = M.geom_size[3 * g2];
+    double b = dot(a1, a2), d = dot(a1, w), e = dot(a2, w), den = 1.0 - b * b;
+    if (den < 1e-6) {   // parallel axes: the overlap of the two segments, one contact at each of its ends (or one if it is a point)
+      // parameters on segment 1 of the projections of segment 2's ends
+      double sgn = b >= 0 ? 1.0 : -1.0;
+      double c2 = -d;                          // projection of centre 2 on axis 1, relative to centre 1
+      double t_lo = std::max(-h1, c2 - h2), t_hi = std::min(h1, c2 + h2);
+      if (t_lo > t_hi) { double tm = std::min(std::max(c2, -h1), h1); t_lo = t_hi = tm; }
+      for (int k = 0; k < (t_hi - t_lo > 1e-9 ? 2 : 1); k++) {
+        double t1 = k == 0 ? t_lo : t_hi;
+        double t2 = std::min(std::max(sgn * (t1 - c2), -h2), h2);
+        sphere_at_vs_sphere_at(g1, g2, gxpos[g1] + a1 * t1, r1, gxpos[g2] + a2 * t2, r2, margin);
+      }
+      return;
+    }
+    double t1 = std::min(std::max((b * e - d) / den, -h1), h1);
+    double t2 = std::min(std::max(e + b * t1, -h2), h2);
+    t1 = std::min(std::max(b * t2 - d, -h1), h1);           // re-project after clamping
+    sphere_at_vs_sphere_at(g1, g2, gxpos[g1] + a1 * t1, r1, gxpos[g2] + a2 * t2, r2, margin);
+  }
+  void collide_capsule_box(int g1, int g2, double margin) {
+    V3 ax = gxmat[g1].col(2);
+    double r = M.geom_size[3 * g1], h = M.geom_size[3 * g1 + 1];
+    double d_hi = sphere_at_vs_box(g1, g2, gxpos[g1] + ax * h, r, margin, false), d_lo = sphere_at_vs_box(g1, g2, gxpos[g1] - ax * h, r, margin, false);
+    if (d_hi < margin && d_lo < margin) {   // lying against a face: the two end spheres
+      sphere_at_vs_box(g1, g2, gxpos[g1] + ax * h, r, margin, true);
+      sphere_at_vs_box(g1, g2, gxpos[g1] - ax * h, r, margin, true);
+      return;
+    }
+    // otherwise the point of the segment nearest to the box: the distance is convex along the segment (golden-section search)
+    const double gr = 0.6180339887498949;
+    double lo = -h, hi = h, x1 = hi - gr * (hi - lo), x2 = lo + gr * (hi - lo);
+    double f1 = sphere_at_vs_box(g1, g2, gxpos[g1] + ax * x1, r, margin, false), f2 = sphere_at_vs_box(g1, g2, gxpos[g1] + ax * x2, r, margin, false);
+    for (int it = 0; it < 40; it++) {
+      if (f1 < f2) { hi = x2; x2 = x1; f2 = f1; x1 = hi - gr * (hi - lo); f1 = sphere_at_vs_box(g1, g2, gxpos[g1] + ax * x1, r, margin, false); }
+      else { lo = x1; x1 = x2; f1 = f2; x2 = lo + gr * (hi - lo); f2 = sphere_at_vs_box(g1, g2, gxpos[g1] + ax * x2, r, margin, false); }
+    }
+    double t = 0.5 * (lo + hi);
+    if (d_hi <= std::min(f1, f2)) t = h; else if (d_lo <= std::min(f1, f2)) t = -h;   // an end sphere is at least as close
+    sphere_at_vs_box(g1, g2, gxpos[g1] + ax * t, r, margin, true);
+  }
+
   // box-box: separating-axis test + reference-face clipping (own algorithm; MuJoCo's mjc_BoxBox [3P] likewise
   // returns up to 8 points for face contacts and 1 for edge-edge)
   void collide_box_box(int g1, int g2, double margin) {
@@ -875,8 +965,12 @@ struct Sim {
       if (t1 == GEOM_PLANE) {
         if (t2 == GEOM_SPHERE) collide_plane_sphere(g1, g2, margin);
         else if (t2 == GEOM_BOX) collide_plane_box(g1, g2, margin);
+        else if (t2 == GEOM_CAPSULE) collide_plane_capsule(g1, g2, margin);
         else collide_plane_convex(g1, g2, margin);
       } else if (t1 == GEOM_SPHERE && t2 == GEOM_SPHERE) collide_sphere_sphere(g1, g2, margin);
+      else if (t1 == GEOM_SPHERE && t2 == GEOM_CAPSULE) collide_sphere_capsule(g1, g2, margin);
+      else if (t1 == GEOM_CAPSULE && t2 == GEOM_CAPSULE) collide_capsule_capsule(g1, g2, margin);
+      else if (t1 == GEOM_CAPSULE && t2 == GEOM_BOX) collide_capsule_box(g1, g2, margin);
       else if (t1 == GEOM_SPHERE && t2 == GEOM_BOX) collide_sphere_box(g1, g2, margin);
       else if (t1 == GEOM_BOX && t2 == GEOM_BOX) collide_box_box(g1, g2, margin);
       else collide_convex(g1, g2, margin);

@@ -122,3 +122,82 @@ def test_many_object_kernel_settles_piles(model_many):
     assert (c["ncon_max"] > 20).all() and (c["ncon_max"] < 160).all()
     r, steps = sim.move_group(1 << 6, [[0.2]], 0.05, 300)             # the gripper still obeys its PID with the pile present
     assert (r == 0).all()
+
+
+def _isolate(model, which_type, quat, z_above_floor):
+    """State in which one object of geom type `which_type` sits alone on the pick-bin floor and every other object is parked far away
+    on the ground plane (spread out so that nothing else touches anything of interest). Returns (qpos, geom id, qpos address)."""
+    o = Oracle(model)
+    o.reset(20, 1, False)
+    q = o.get_state()["qpos"].copy()
+    gt, gb = np.asarray(model.geom_type), np.asarray(model.geom_bodyid)
+    g = int(np.where(gt == which_type)[0][0])
+    floor_top = 0.89                                                     # UR5gripper_2_finger_many_objects.xml:120 (pick_box plate)
+    adr_of = {}
+    for gi in range(model.ngeom):
+        b = int(gb[gi])
+        if model.body_jntnum[b] == 1 and model.jnt_type[model.body_jntadr[b]] == 0:
+            adr_of[gi] = int(model.jnt_qposadr[model.body_jntadr[b]])
+    for k, (gi, adr) in enumerate(sorted(adr_of.items())):
+        q[adr:adr + 7] = [3.0 + 0.4 * (k % 8), 2.0 + 0.4 * (k // 8), 0.2, 1, 0, 0, 0]
+    adr = adr_of[g]
+    r = float(model.geom_size[g][0])
+    q[adr:adr + 7] = [0.0, -0.6, floor_top + r + z_above_floor, *quat]
+    return q, g, adr
+
+
+def test_capsule_lying_on_the_bin_floor_gets_two_contacts(model_many):
+    """mjc_CapsuleBox [3P] gives a capsule lying on a face one contact under each end sphere; so do oracle and engine (own restatement),
+    which keeps it from rocking on a single MPR point. Normal forces: m g / 2 each once it has settled."""
+    s = np.sqrt(0.5)
+    q, g, adr = _isolate(model_many, 3, [s, 0, s, 0], -2e-4)              # axis along world x, 0.2 mm into the plate
+    o = Oracle(model_many)
+    o.set_state(qpos=q, qvel=np.zeros(model_many.nv))
+    o.forward()
+    mine = [c for c in o.contacts() if int(c[7]) == g or int(c[8]) == g]
+    assert len(mine) == 2
+    h = float(model_many.geom_size[g][1])
+    xs = sorted(c[1] for c in mine)
+    assert abs(xs[0] + h) < 1e-6 and abs(xs[1] - h) < 1e-6             # under the two end spheres
+    for c in mine:
+        assert abs(abs(c[6]) - 1) < 1e-9 and abs(c[0] + 2e-4) < 1e-9     # vertical normal, the prescribed penetration
+    o.step(400)
+    st = o.get_state()
+    assert np.abs(st["qvel"][adr - 8 - (adr - 8) // 7: adr - 8 - (adr - 8) // 7 + 6]).max() < 1e-3   # at rest (dof address = qpos address - #objects before it)
+    o.forward()
+    mine = [c for c in o.contacts() if int(c[7]) == g or int(c[8]) == g]
+    b = int(model_many.geom_bodyid[g])
+    mg = float(model_many.body_mass[b]) * 9.81
+    assert len(mine) == 2 and all(abs(c[10] - 0.5 * mg) < 0.02 * mg for c in mine)
+
+
+def test_capsule_primitives_engine_equals_oracle(model_many, emul_lib):
+    """A pose that exercises sphere-capsule, capsule-capsule (crossed and parallel) and capsule-box together: same contacts from both."""
+    o = Oracle(model_many)
+    o.reset(20, 1, False)
+    q = o.get_state()["qpos"].copy()
+    gt, gb = np.asarray(model_many.geom_type), np.asarray(model_many.geom_bodyid)
+    adr = lambda gi: int(model_many.jnt_qposadr[model_many.body_jntadr[int(gb[gi])]])
+    caps = [int(x) for x in np.where(gt == 3)[0][:3]]
+    sph = int(np.where(gt == 2)[0][0])
+    for k, gi in enumerate(gi for gi in range(model_many.ngeom) if model_many.body_jntnum[int(gb[gi])] == 1 and model_many.jnt_type[model_many.body_jntadr[int(gb[gi])]] == 0):
+        q[adr(gi):adr(gi) + 7] = [3.0 + 0.4 * (k % 8), 2.0 + 0.4 * (k // 8), 0.2, 1, 0, 0, 0]
+    s = np.sqrt(0.5)
+    r = [float(model_many.geom_size[c][0]) for c in caps]
+    q[adr(caps[0]):adr(caps[0]) + 7] = [0.0, -0.6, 0.89 + r[0] - 1e-4, s, 0, s, 0]                      # lying along x on the floor
+    q[adr(caps[1]):adr(caps[1]) + 7] = [0.0, -0.6, 0.89 + 2 * r[0] + r[1] - 3e-4, s, s, 0, 0]           # across it, along y
+    q[adr(caps[2]):adr(caps[2]) + 7] = [0.01, -0.6 + r[0] + r[2] - 2e-4, 0.89 + r[0] - 1e-4, s, 0, s, 0]  # beside it at axis height, parallel, shifted 1 cm
+    q[adr(sph):adr(sph) + 7] = [0.0, -0.6 - r[0] - float(model_many.geom_size[sph][0]) + 2e-4, 0.89 + r[0], 1, 0, 0, 0]   # sphere touching its side
+    o.set_state(qpos=q, qvel=np.zeros(model_many.nv))
+    o.forward()
+    sim = BatchSim(model_many, 1, lib_path=emul_lib)
+    sim.set_state(qpos=q[None], qvel=np.zeros((1, model_many.nv)))
+    d = sim.forward_debug()
+    oc = o.contacts()
+    touched = {(int(c[7]), int(c[8])) for c in oc}
+    assert {tuple(sorted((caps[0], caps[1]))), tuple(sorted((caps[0], caps[2]))), (sph, caps[0])} <= {tuple(sorted(t)) if t != (sph, caps[0]) else t for t in touched}
+    assert d["ncon"][0] == len(oc)
+    ec = d["contacts"][0][:len(oc)]
+    for c in oc:
+        best = min(ec, key=lambda e: np.abs(e[1:4] - c[1:4]).sum())
+        assert np.abs(best[1:4] - c[1:4]).max() < 1e-12 and np.abs(best[4:7] - c[4:7]).max() < 1e-12 and abs(best[0] - c[0]) < 1e-12
