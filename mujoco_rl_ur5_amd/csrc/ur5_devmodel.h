@@ -2,8 +2,9 @@
 //
 // It is the *specialised* view of a CompiledModel blob (mujoco_rl_ur5_amd/model.py): one articulated robot tree whose
 // weld groups each carry exactly one hinge ("cbody" d <-> dof d), plus up to UR5_MAXOBJ free-floating single-geom objects
-// (3 slides + ball, UR5gripper_2_finger.xml:233-279, or a free joint, objects.xml), plus static geoms. ur5_model_build()
-// (ur5sim_host.cpp) derives it and rejects scenes that do not fit, loudly.
+// (3 slides + ball, UR5gripper_2_finger.xml:233-279, or a free joint, objects.xml), plus static geoms. build_model()
+// (ur5sim_host.h) derives it and rejects scenes that do not fit, loudly. The limits below exist twice: the header is compiled once
+// per engine variant (UR5_MANY undefined / defined).
 #pragma once
 
 #define UR5_MAXRD 8                                // robot dofs == robot weld groups ("cbodies")

@@ -1,14 +1,15 @@
-// ur5_engine.h -- one-wavefront-per-env UR5 grasp-scene engine (device code shared by every kernel).
+// ur5_engine.h -- UR5 grasp-scene engine, device code shared by both kernels of libur5sim.so (ur5sim.hip: one 64-lane wavefront
+// per scene for up to 6 objects; ur5sim_many.hip: -DUR5_MANY, one 256-thread workgroup per scene for 40-object piles).
 //
 // Replaces, for a whole batch of scenes, what the reference does one scene at a time through mujoco_py [3P]:
 //   sim.step()                      gym_grasper/controller/MujocoController.py:379  -> Engine::step()
 //   PID.__call__ / ctrl writes      MujocoController.py:325-327                     -> Engine::pid_and_deltas()
-//   move_group_to_joint_target      MujocoController.py:269-393                     -> Engine::move_group()
-//   stay / open / close / grasp     MujocoController.py:408-444, 621-636            -> Engine::stay() ...
-//   move_ee / ik                    MujocoController.py:446-517                     -> Engine::move_ee(), Engine::ik()
-//   move_and_grasp                  gym_grasper/envs/GraspingEnv.py:205-386         -> Engine::grasp_attempt()
+//   move_group_to_joint_target      MujocoController.py:269-393                     -> the move loop in Engine::run()
+//   stay / open / close / grasp     MujocoController.py:408-444, 621-636            -> script opcodes in Engine::run()
+//   move_ee / ik                    MujocoController.py:446-517                     -> Engine::ik() + the move loop
+//   move_and_grasp                  gym_grasper/envs/GraspingEnv.py:205-386         -> the grasp script in Engine::run()
 //
-// Execution model: ONE 64-lane wavefront owns ONE scene. All per-scene state lives in LDS (struct Lds) for the whole
+// Execution model: ONE workgroup (a single wavefront in the small-scene build) owns ONE scene. All per-scene state lives in LDS (struct Lds) for the whole
 // launch -- thousands of 2 ms physics steps -- and is read/written from HBM once. The code is a sequence of *phases*:
 // PAR(i, n) distributes n independent items over the 64 lanes, SYNC() separates phases, WAVE_SUM/WAVE_MAX combine lane
 // partials. Statements outside PAR are wave-uniform (every lane computes the same value from LDS).
@@ -40,6 +41,8 @@
 #define UR5_PHASE_F inline
 #define UR5_PHASE_G inline
 #define UR5_PHASE_H inline
+#define UR5_STEP_ATTR inline
+#define UR5_IK_ATTR inline
 static void* ur5_emul_lds = nullptr;
 static const Ur5DevModel* ur5_emul_model = nullptr;
 #define UR5_LDS_PTR(T) (static_cast<T*>(ur5_emul_lds))
@@ -75,6 +78,12 @@ static const Ur5DevModel* ur5_emul_model = nullptr;
 #define UR5_PHASE_C UR5_BIG
 #define UR5_PHASE_D UR5_BIG
 #define UR5_PHASE_H UR5_BIG
+#endif
+#ifndef UR5_STEP_ATTR
+#define UR5_STEP_ATTR UR5_BIG
+#endif
+#ifndef UR5_IK_ATTR
+#define UR5_IK_ATTR UR5_BIG
 #endif
 #define UR5_PHASE_E UR5_BIG    // crb_and_factor, velocity_stage, integrate: they share the register-resident robot factors
 #define UR5_PHASE_F UR5_BIG
@@ -2496,7 +2505,7 @@ template <class real, int NV_> struct Engine {
     make_constraints(); PROF(PF_ROWS);
     solve_newton();
   }
-  UR5_BIG void step() {  // sim.step(), MujocoController.py:379
+  UR5_STEP_ATTR void step() {  // sim.step(), MujocoController.py:379
     Fact fr;
     forward(fr);
     PROF_T0();
@@ -2546,7 +2555,7 @@ template <class real, int NV_> struct Engine {
     *Rout = matmul(R, E);
   }
   // :467-517 -- fixed-iteration Levenberg-Marquardt from the home pose, identical to oracle Sim::ik()
-  UR5_BIG bool ik(v3 ee_position, real* out5) const {
+  UR5_IK_ATTR bool ik(v3 ee_position, real* out5) const {
     v3 tgt = ee_position + v3(0, (real)-0.005, (real)0.16);
     real q[6] = {0, (real)-1.57, (real)1.57, (real)-1.57, (real)-1.57, 0};
     const real lambda = (real)1e-4;

@@ -15,7 +15,6 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "csrc", "libur5sim.so")
 
 RES_NONE, RES_SUCCESS, RES_MAX_STEPS, RES_IK_FAIL = -1, 0, 1, 2
-DEBUG_STRIDE, REC_STRIDE, MAXB = 2048, 192, 14
 # limits of the two engine variants (csrc/ur5_devmodel.h): (max objects, debug stride, record stride, max contacts)
 _VARIANT = {0: (6, 2048, 192, 30), 1: (40, 4096, 832, 160)}
 EXPORTS = ["ur5_last_error", "ur5_create", "ur5_destroy", "ur5_num_envs", "ur5_nq", "ur5_nv", "ur5_nu", "ur5_reset",
