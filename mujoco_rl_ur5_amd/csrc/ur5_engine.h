@@ -41,8 +41,6 @@
 #define UR5_PHASE_F inline
 #define UR5_PHASE_G inline
 #define UR5_PHASE_H inline
-#define UR5_STEP_ATTR inline
-#define UR5_IK_ATTR inline
 static void* ur5_emul_lds = nullptr;
 static const Ur5DevModel* ur5_emul_model = nullptr;
 #define UR5_LDS_PTR(T) (static_cast<T*>(ur5_emul_lds))
@@ -78,12 +76,6 @@ static const Ur5DevModel* ur5_emul_model = nullptr;
 #define UR5_PHASE_C UR5_BIG
 #define UR5_PHASE_D UR5_BIG
 #define UR5_PHASE_H UR5_BIG
-#endif
-#ifndef UR5_STEP_ATTR
-#define UR5_STEP_ATTR UR5_BIG
-#endif
-#ifndef UR5_IK_ATTR
-#define UR5_IK_ATTR UR5_BIG
 #endif
 #define UR5_PHASE_E UR5_BIG    // crb_and_factor, velocity_stage, integrate: they share the register-resident robot factors
 #define UR5_PHASE_F UR5_BIG
@@ -2505,7 +2497,7 @@ template <class real, int NV_> struct Engine {
     make_constraints(); PROF(PF_ROWS);
     solve_newton();
   }
-  UR5_STEP_ATTR void step() {  // sim.step(), MujocoController.py:379
+  UR5_BIG void step() {  // sim.step(), MujocoController.py:379
     Fact fr;
     forward(fr);
     PROF_T0();
@@ -2555,7 +2547,7 @@ template <class real, int NV_> struct Engine {
     *Rout = matmul(R, E);
   }
   // :467-517 -- fixed-iteration Levenberg-Marquardt from the home pose, identical to oracle Sim::ik()
-  UR5_IK_ATTR bool ik(v3 ee_position, real* out5) const {
+  UR5_BIG bool ik(v3 ee_position, real* out5) const {
     v3 tgt = ee_position + v3(0, (real)-0.005, (real)0.16);
     real q[6] = {0, (real)-1.57, (real)1.57, (real)-1.57, (real)-1.57, 0};
     const real lambda = (real)1e-4;
