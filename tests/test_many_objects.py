@@ -201,3 +201,49 @@ def test_capsule_primitives_engine_equals_oracle(model_many, emul_lib):
     for c in oc:
         best = min(ec, key=lambda e: np.abs(e[1:4] - c[1:4]).sum())
         assert np.abs(best[1:4] - c[1:4]).max() < 1e-12 and np.abs(best[4:7] - c[4:7]).max() < 1e-12 and abs(best[0] - c[0]) < 1e-12
+
+
+def _forward_agrees(model, sim, min_robot_contacts):
+    st = sim.get_state()
+    o = Oracle(model)
+    o.set_state(qpos=st["qpos"][0], qvel=st["qvel"][0], warmstart=st["warmstart"][0], pid=st["pid"][0])
+    o.set_ctrl(sim.get_ctrl()[0])
+    o.forward()
+    d = sim.forward_debug()
+    oc = o.contacts()
+    gb = np.asarray(model.geom_bodyid)
+    robot_bodies = {b for b in range(model.nbody) if model.body_treeid[b] == 0}
+    nrobot = sum(1 for c in oc if int(gb[int(c[7])]) in robot_bodies or int(gb[int(c[8])]) in robot_bodies)
+    assert nrobot >= min_robot_contacts, nrobot
+    assert d["ncon"][0] == len(oc)
+    qacc = o.vec("qacc")
+    assert np.abs(d["qacc"][0][:model.nv] - qacc).max() < 1e-6 * max(1.0, np.abs(qacc).max())
+    return nrobot
+
+
+def test_gripper_in_the_pile_couples_robot_and_objects(model_many, emul_lib):
+    """The robot block (8 wide, last in the envelope) coupled with object blocks: push the open gripper into the settled pile and
+    compare one forward pass with the oracle's dense Newton from the same state."""
+    sim = BatchSim(model_many, 1, lib_path=emul_lib)
+    sim.reset([23], 1, 0.0)
+    sim.step(250)
+    xy = sim.body_xpos()[0, 8:]
+    k = int(np.argmin(np.hypot(xy[:, 0], xy[:, 1] + 0.6)))                # the object nearest to the bin centre
+    sim.move_ee([[xy[k, 0], xy[k, 1], 1.1]], 0.05, 400)
+    sim.move_ee([[xy[k, 0], xy[k, 1], xy[k, 2] + 0.01]], 0.01, 250)       # fingers around / onto it
+    _forward_agrees(model_many, sim, 1)
+    sim.move_group(1 << 6, [[-0.4]], 0.01, 150)                           # close on it
+    _forward_agrees(model_many, sim, 1)
+    assert sim.counters()["status"][0] == 0
+
+
+def test_closed_gripper_robot_robot_contact(model_many, emul_lib):
+    """Finger against finger: a contact between two robot bodies adds its coupling inside the robot block."""
+    sim = BatchSim(model_many, 1, lib_path=emul_lib)
+    sim.reset([20], 1, 0.0)
+    st = sim.get_state()
+    q = st["qpos"].copy()
+    q[0, 8:] = np.tile([3.0, 3.0, 5.0, 1, 0, 0, 0], 40) + np.repeat(np.arange(40) * 0.3, 7) * np.tile([1, 0, 0, 0, 0, 0, 0], 40)   # objects out of the way
+    sim.set_state(qpos=q)
+    r, steps = sim.move_group(1 << 6, [[-0.9]], 0.001, 250)               # close far beyond an object-sized gap
+    _forward_agrees(model_many, sim, 1)
