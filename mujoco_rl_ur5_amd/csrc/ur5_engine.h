@@ -274,6 +274,8 @@ template <class real, int NV_> struct Lds {
   int sr_act[UR5_MAXSR];
   real dcache[UR5_MAXOBJ + 1][44];                   // factored diagonal blocks, packed lower triangle + 1/diagonal
   short seq[UR5_MAXOBJ + 1];                         // blocks that take part in the sequential factorisation (the others are uncoupled)
+  short lvl_ptr[UR5_MAXOBJ + 3], lvl_list[UR5_MAXOBJ + 1];   // the same panels grouped by level: panels of one level belong to different
+  int nlvl;                                          // envelope groups (islands) and are processed together, one wavefront each
   real red[3 * 16];                                  // cross-wave reductions
   int redi[16];
 #endif
@@ -1953,6 +1955,25 @@ template <class real, int NV_> struct Engine {
       int ns = 0;   // panels of the sequential sweep: only blocks that some later block reaches
       for (int p2 = 0; p2 < nblk; p2++) if (S.blk_last[p2] != p2) S.seq[ns++] = (short)p2;
       S.nseq = ns;
+      // Envelope groups: maximal block ranges that no row crosses (block g starts one when nothing before it is reached from g
+      // or later). Groups share no Hessian entry, so their panels are independent; inside a group the panels form a chain.
+      // level of a panel = its position in its group's chain.
+      {
+        short lv[UR5_MAXOBJ + 1];
+        int grp_end = -1, pos = 0, nl = 0;
+        for (int p2 = 0; p2 < nblk; p2++) {
+          if (p2 > grp_end) pos = 0;
+          if (S.blk_last[p2] > grp_end) grp_end = S.blk_last[p2];
+          if (S.blk_last[p2] != p2) { lv[p2] = (short)pos; pos++; if (pos > nl) nl = pos; } else lv[p2] = -1;
+        }
+        S.nlvl = nl;
+        int o = 0;
+        for (int l = 0; l < nl; l++) {
+          S.lvl_ptr[l] = (short)o;
+          for (int p2 = 0; p2 < nblk; p2++) if (lv[p2] == l) S.lvl_list[o++] = (short)p2;
+        }
+        S.lvl_ptr[nl] = (short)o;
+      }
       S.reach_ptr[0] = 0;
       for (int p2 = 0; p2 < nblk; p2++) S.reach_ptr[p2 + 1] = (short)(S.reach_ptr[p2 + 1] + S.reach_ptr[p2]);
     }
@@ -2148,6 +2169,45 @@ template <class real, int NV_> struct Engine {
 #pragma unroll
     for (int k = 0; k < W; k++) S.panel[i][k] = out[k];
   }
+  // Work split inside a level: on the GPU wavefront w of the workgroup owns panel base + w of the pass and its 64 lanes stride over
+  // that panel's rows; the lane-emulation build walks the panels of a pass one after the other.
+#ifdef UR5_EMUL
+#define UR5_PANELS_PER_PASS 1
+#define UR5_FOR_MY_PANELS(j, base, np) for (int j = (base); j < (base) + 1 && j < (np); j++)
+#define UR5_PLANE(t, n) for (int t = 0; t < (n); t++)
+#else
+#define UR5_PANELS_PER_PASS (UR5_NT / 64)
+#define UR5_FOR_MY_PANELS(j, base, np) for (int j = (base) + (UR5_LANE >> 6), once_ = 1; once_ && j < (np); once_ = 0)
+#define UR5_PLANE(t, n) for (int t = UR5_LANE & 63; t < (n); t += 64)
+#endif
+  // A1: the panel's own rows and every reaching row compute their entries of the block column (LDS panel); H is only read
+  template <bool INLDS> UR5_FN void panel_factor_rows(int p2) {
+    const int c0 = 6 * p2, w = blk_width(p2);
+    const int nrb = S.reach_ptr[p2 + 1] - S.reach_ptr[p2], nr = reach_rows(p2, nrb);
+    UR5_PLANE(t, w + nr) {
+      const int i = t < w ? c0 + t : reach_row(p2, nrb, t - w);
+      if (p2 < M.nobj) factor_panel_row<INLDS, 6>(i, t, p2, c0); else factor_panel_row<INLDS, UR5_MAXRD>(i, t, p2, c0);
+    }
+  }
+  // A2: the finished column entries of the rows below go back to H (the block itself lives on in dcache);
+  // B: trailing update of every pair of reaching rows below the block
+  template <bool INLDS> UR5_FN void panel_trailing_update(int p2) {
+    const int c0 = 6 * p2, w = blk_width(p2);
+    const int nrb = S.reach_ptr[p2 + 1] - S.reach_ptr[p2], nr = reach_rows(p2, nrb);
+    UR5_PLANE(c, nr) {
+      const int i = reach_row(p2, nrb, c);
+      double* row = hptr<INLDS>(i, c0);
+      for (int k = 0; k < w; k++) row[k] = (double)S.panel[i][k];
+    }
+    UR5_PLANE(idx, nr * nr) {
+      const int ii = idx / nr, jj = idx - ii * nr;
+      if (jj > ii) continue;
+      const int i = reach_row(p2, nrb, ii), j = reach_row(p2, nrb, jj);
+      real sacc = 0;
+      for (int k = 0; k < w; k++) sacc += S.panel[i][k] * S.panel[j][k];
+      *hptr<INLDS>(i, j) -= (double)sacc;
+    }
+  }
   template <bool INLDS> UR5_BIG void envelope_factor() {
     // a block that reaches no earlier block gets no trailing update: its diagonal block is final after assembly, so all
     // of these (the uncoupled blocks among them) are factored at once, ahead of the sequential sweep
@@ -2157,32 +2217,15 @@ template <class real, int NV_> struct Engine {
       if (p2 < M.nobj) factor_single_row<INLDS, 6>(i, p2); else factor_single_row<INLDS, UR5_MAXRD>(i, p2);
     }
     SYNC();
-    for (int q = 0; q < S.nseq; q++) {
-      const int p2 = S.seq[q];
-      const int c0 = 6 * p2, w = blk_width(p2);
-      const int nrb = S.reach_ptr[p2 + 1] - S.reach_ptr[p2], nr = reach_rows(p2, nrb);
-      // A1: the block's own rows and every reaching row compute their entries of the block column (LDS panel); H is only read
-      PAR(t, w + nr) {
-        const int i = t < w ? c0 + t : reach_row(p2, nrb, t - w);
-        if (p2 < M.nobj) factor_panel_row<INLDS, 6>(i, t, p2, c0); else factor_panel_row<INLDS, UR5_MAXRD>(i, t, p2, c0);
+    // level by level; inside a level every wavefront takes one panel (lanes = rows / row pairs of that panel)
+    for (int l = 0; l < S.nlvl; l++) {
+      const int lp0 = S.lvl_ptr[l], np = S.lvl_ptr[l + 1] - lp0;
+      for (int base = 0; base < np; base += UR5_PANELS_PER_PASS) {
+        UR5_FOR_MY_PANELS(j, base, np) panel_factor_rows<INLDS>(S.lvl_list[lp0 + j]);
+        SYNC();
+        UR5_FOR_MY_PANELS(j, base, np) panel_trailing_update<INLDS>(S.lvl_list[lp0 + j]);
+        SYNC();
       }
-      SYNC();
-      // A2: the finished column entries of the rows below go back to H (the block itself lives on in dcache);
-      // B: trailing update of every pair of reaching rows below the block
-      PAR(c, nr) {
-        const int i = reach_row(p2, nrb, c);
-        double* row = hptr<INLDS>(i, c0);
-        for (int k = 0; k < w; k++) row[k] = (double)S.panel[i][k];
-      }
-      PAR(idx, nr * nr) {
-        const int ii = idx / nr, jj = idx - ii * nr;
-        if (jj > ii) continue;
-        const int i = reach_row(p2, nrb, ii), j = reach_row(p2, nrb, jj);
-        real sacc = 0;
-        for (int k = 0; k < w; k++) sacc += S.panel[i][k] * S.panel[j][k];
-        *hptr<INLDS>(i, j) -= (double)sacc;
-      }
-      SYNC();
     }
     PAR(i, M.nv) {   // terminal blocks: every trailing update has landed
       const int p2 = i < 6 * M.nobj ? i / 6 : M.nobj;
@@ -2256,15 +2299,20 @@ template <class real, int NV_> struct Engine {
       if (!blk_single(p2)) continue;
       if (p2 < M.nobj) solve_single_row<6>(i, p2, b); else solve_single_row<UR5_MAXRD>(i, p2, b);
     }
-    for (int q = 0; q < S.nseq; q++) {   // forward, column-oriented: y_blk = L_pp^-1 b_blk, then b_i -= L_i,blk y_blk for the rows below
-      const int p2 = S.seq[q];
-      const int c0 = 6 * p2, w = blk_width(p2);
-      const int nrb = S.reach_ptr[p2 + 1] - S.reach_ptr[p2], nr = reach_rows(p2, nrb);
-      PAR(t, w + nr) {
-        const int i = t < w ? c0 + t : reach_row(p2, nrb, t - w);
-        if (p2 < M.nobj) fwd_panel_row<INLDS, 6>(i, t, p2, c0, b, y); else fwd_panel_row<INLDS, UR5_MAXRD>(i, t, p2, c0, b, y);
+    for (int l = 0; l < S.nlvl; l++) {   // forward, column-oriented: y_blk = L_pp^-1 b_blk, then b_i -= L_i,blk y_blk for the rows below
+      const int lp0 = S.lvl_ptr[l], np = S.lvl_ptr[l + 1] - lp0;
+      for (int base = 0; base < np; base += UR5_PANELS_PER_PASS) {
+        UR5_FOR_MY_PANELS(j, base, np) {
+          const int p2 = S.lvl_list[lp0 + j];
+          const int c0 = 6 * p2, w = blk_width(p2);
+          const int nrb = S.reach_ptr[p2 + 1] - S.reach_ptr[p2], nr = reach_rows(p2, nrb);
+          UR5_PLANE(t, w + nr) {
+            const int i = t < w ? c0 + t : reach_row(p2, nrb, t - w);
+            if (p2 < M.nobj) fwd_panel_row<INLDS, 6>(i, t, p2, c0, b, y); else fwd_panel_row<INLDS, UR5_MAXRD>(i, t, p2, c0, b, y);
+          }
+        }
+        SYNC();
       }
-      SYNC();
     }
     PAR(t, M.nv) {   // terminal blocks: forward and backward substitution inside the block, then their share of y to the left
       const int p2 = t < 6 * M.nobj ? t / 6 : M.nobj;
@@ -2284,15 +2332,20 @@ template <class real, int NV_> struct Engine {
       }
     }
     SYNC();
-    for (int q = S.nseq - 1; q >= 0; q--) {   // backward, row-oriented: x_blk = L_pp^-T y_blk, then y_j -= L_blk,j^T x_blk for the columns left of it
-      const int p2 = S.seq[q];
-      const int c0 = 6 * p2, w = blk_width(p2);
-      const int f0 = S.env_first[c0];
-      PAR(jj, c0 + w - f0) {
-        const int j = f0 + jj;
-        if (p2 < M.nobj) bwd_panel_col<INLDS, 6>(j, p2, c0, y); else bwd_panel_col<INLDS, UR5_MAXRD>(j, p2, c0, y);
+    for (int l = S.nlvl - 1; l >= 0; l--) {   // backward, row-oriented: x_blk = L_pp^-T y_blk, then y_j -= L_blk,j^T x_blk for the columns left of it
+      const int lp0 = S.lvl_ptr[l], np = S.lvl_ptr[l + 1] - lp0;
+      for (int base = 0; base < np; base += UR5_PANELS_PER_PASS) {
+        UR5_FOR_MY_PANELS(j, base, np) {
+          const int p2 = S.lvl_list[lp0 + j];
+          const int c0 = 6 * p2, w = blk_width(p2);
+          const int f0 = S.env_first[c0];
+          UR5_PLANE(jj, c0 + w - f0) {
+            const int col = f0 + jj;
+            if (p2 < M.nobj) bwd_panel_col<INLDS, 6>(col, p2, c0, y); else bwd_panel_col<INLDS, UR5_MAXRD>(col, p2, c0, y);
+          }
+        }
+        SYNC();
       }
-      SYNC();
     }
     SYNC();   // S.search of the uncoupled blocks (there may be no sequential block at all)
   }
