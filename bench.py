@@ -162,12 +162,12 @@ def main():
         achieved = steps_local * bytes_per_step / k_s / 1e9
         # measured HBM bytes per env-step from the rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this same command (profiles/)
         traffic, traffic_src = None, None
-        tp = os.path.join(ROOT, "profiles", "r01_i_hbm_traffic.json")
+        tp = os.path.join(ROOT, "profiles", "r01_k_hbm_traffic.json")
         if os.path.exists(tp) and not rendered:
             with open(tp) as f:
                 tj = json.load(f)
             traffic = tj["hbm_bytes_per_env_step"] * steps_local / args.steps
-            traffic_src = "profiles/r01_i_hbm_traffic.json: (FETCH_SIZE + WRITE_SIZE) per env-step x env-steps of an average timed launch"
+            traffic_src = "profiles/r01_k_hbm_traffic.json: (FETCH_SIZE + WRITE_SIZE) per env-step x env-steps of an average timed launch"
         out = {
             "metric": f"env-steps/sec (+ grasp-attempts/sec), {n_local} parallel UR5 scenes per MI355X",
             "value": steps_all / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
