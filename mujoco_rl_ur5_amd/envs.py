@@ -102,8 +102,7 @@ class GraspEnv(object):
         rotation = a[:, 1]                                                   # :97
         depth_img = np.asarray(self.current_observation["depth"]).reshape(self.n_envs, self.IMAGE_HEIGHT, self.IMAGE_WIDTH)
         depth = depth_img[np.arange(self.n_envs), y, x]                      # :100
-        coords = np.stack([self.controller.pixel_2_world(pixel_x=x[e], pixel_y=y[e], depth=depth[e], height=self.IMAGE_HEIGHT,
-                                                         width=self.IMAGE_WIDTH) for e in range(self.n_envs)])   # :102-104
+        coords = self.controller.pixel_2_world_batch(x, y, depth, width=self.IMAGE_WIDTH, height=self.IMAGE_HEIGHT)   # :102-104
         skip = (coords[:, 2] < 0.8) | (coords[:, 1] > -0.3)                  # :124
         reward = self.move_and_grasp(coords, rotation, skip=skip)
         self.current_observation = self.get_observation(show=self.show_observations)   # :152
