@@ -7,6 +7,7 @@
  *   ur5_create            mujoco_py.load_model_from_path + MjSim + MJ_Controller.__init__/create_lists
  *                         gym_grasper/controller/MujocoController.py:29-51,136-254 ; gym_grasper/envs/GraspingEnv.py:47-51
  *   ur5_reset             GraspEnv.reset_model                      GraspingEnv.py:409-477 (IT4 variant :435-463)
+ *   ur5_reset_dev         the same for the flagged scenes only, seeds / flags in device memory (episode boundaries of a batch)
  *   ur5_set_state/get     MujocoEnv.set_state, sim.data.qpos/qvel   GraspingEnv.py:412-466 ; MujocoController.py:319
  *   ur5_set_ctrl          MJ_Controller.actuate_joint_group         MujocoController.py:256-267
  *   ur5_step              sim.step()                                MujocoController.py:379,611
@@ -53,6 +54,10 @@ int ur5_nu(const ur5_sim* h);
 
 /* seeds[n] (host). mode is informational (object joint type decides the distribution); settle_ms = 1000 in the reference. */
 int ur5_reset(ur5_sim* h, const uint64_t* seeds, int mode, double settle_ms);
+/* GraspEnv.reset_model (GraspingEnv.py:409-477) for the scenes whose flag is set, without a host round trip: seeds_dev[n] uint64 and
+   mask_dev[n] uint8 (NULL = every scene) are HIP device pointers; a scene's new state depends only on its seed (SplitMix64 stream, same
+   sampling code as ur5_reset). Unflagged scenes keep their state and sit the settle launch out. Asynchronous on the handle's stream. */
+int ur5_reset_dev(ur5_sim* h, const uint64_t* seeds_dev, const uint8_t* mask_dev, double settle_ms);
 /* host arrays, any may be NULL: qpos[n][nq] qvel[n][nv] warmstart[n][nv] pid[n][nu][4] = target, last_input, last_output, Kp */
 int ur5_set_state(ur5_sim* h, const double* qpos, const double* qvel, const double* warmstart, const double* pid);
 int ur5_get_state(ur5_sim* h, double* qpos, double* qvel, double* warmstart, double* pid);
@@ -66,8 +71,9 @@ int ur5_stay(ur5_sim* h, double ms);
 int ur5_move_ee(ur5_sim* h, const double* xyz /* [n][3] */, const double* tol, const int* max_steps, int* result, int* steps);
 /* q5[n][5] arm joint angles; result[n] = UR5_RES_SUCCESS or UR5_RES_IK_FAIL (FK(IK) further than 2 cm from the target) */
 int ur5_ik(ur5_sim* h, const double* xyz /* [n][3] */, double* q5, int* result);
-/* action[n][4] = world x, y, z, rotation index 0..5 (GraspingEnv.py:40). check_mode 0 = in-tree script, 1 = IT1. */
-int ur5_grasp_attempt(ur5_sim* h, const double* action, int check_mode, double table_height, int* reward,
+/* action[n][4] = world x, y, z, rotation index 0..5 (GraspingEnv.py:40). check_mode 0 = in-tree script, 1 = IT1.
+   skip[n] (or NULL): non-zero = GraspEnv.step's rule for targets off the table (GraspingEnv.py:124-131): the scene does not move, reward 0 */
+int ur5_grasp_attempt(ur5_sim* h, const double* action, const uint8_t* skip, int check_mode, double table_height, int* reward,
                       int* phase_steps /* [n][12] or NULL */, int* phase_result /* [n][12] or NULL */);
 /* same with HIP device pointers: action_dev [n][8] doubles (x y z rot skip - - -), reward_dev [n] int32; asynchronous.
    skip != 0: the scene sits the launch out with reward 0 -- GraspEnv.step's rule for targets off the table (GraspingEnv.py:124-131) */
@@ -75,6 +81,8 @@ int ur5_grasp_attempt_dev(ur5_sim* h, const double* action_dev, int check_mode, 
 int ur5_sync(ur5_sim* h);
 /* duration of the last launch in ms, from HIP events recorded on the handle's stream around the kernel */
 double ur5_last_launch_ms(ur5_sim* h);
+/* engine-kernel time (ms) of every launch since ur5_create whose events a ur5_sync has resolved: callers difference it around a region */
+double ur5_kernel_ms_total(ur5_sim* h);
 /* counters[n][6] host: total physics steps, last_movement_steps, status bits, Newton iterations, max contacts seen in a step,
    Newton iterations that reused the previous Cholesky factor (many-object engine; 0 otherwise).
    Status bits (sticky until ur5_reset): 1 = more contacts than slots (30 / 160), 2 = non-finite state, 4 = more equality/limit rows

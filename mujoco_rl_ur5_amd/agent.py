@@ -35,7 +35,8 @@ class BatchedGraspAgent:
         torch.manual_seed(seed)                                                        # :76-79
         np.random.seed(seed)
         self.device = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
-        self.env = env if env is not None else GraspEnv(n_envs=n_envs, show_obs=False, observation="render", **env_kwargs)
+        self.env = env if env is not None else GraspEnv(n_envs=n_envs, show_obs=False, observation="render", first_scene_id=first_scene_id,
+                                                        **env_kwargs)
         self.N, self.H, self.W = self.env.n_envs, self.env.IMAGE_HEIGHT, self.env.IMAGE_WIDTH
         self.n_actions_1, self.n_actions_2 = int(self.env.action_space.nvec[0]), int(self.env.action_space.nvec[1])   # :97-100
         self.output = self.n_actions_1 * self.n_actions_2
@@ -49,7 +50,7 @@ class BatchedGraspAgent:
         self.optimizer = torch.optim.Adam(self.policy_net.parameters(), lr=learning_rate, weight_decay=0.00002)   # :153-156
         self.eps_start, self.eps_end, self.eps_decay = eps_start, eps_end, eps_decay
         self.steps_done, self.eps_threshold = 0, eps_start
-        self.first_scene_id = first_scene_id
+        self.first_scene_id = self.env.first_scene_id if env is not None else first_scene_id   # one source of truth: the env's scene range
         self.last_loss = None
         self._gen = torch.Generator(device=self.device).manual_seed(seed)
 
@@ -59,8 +60,7 @@ class BatchedGraspAgent:
         observation = {"rgb": uint8 [N,H,W,3], "depth": float32 [N,H,W]} device tensors -> float32 [N,4,H,W]."""
         depth = observation["depth"].to(self.device).float().clamp(max=self.depth_threshold)            # :311
         if normalize:
-            if jitter_and_noise:
-                depth = depth + 0.001 * torch.randn(depth.shape, device=self.device, generator=self._gen)   # :317
+            depth = depth + 0.001 * torch.randn(depth.shape, device=self.device, generator=self._gen)       # :317 (whenever normalize=True)
             depth = -depth
             dmin = depth.amin(dim=(1, 2), keepdim=True)
             dmax = depth.amax(dim=(1, 2), keepdim=True)

@@ -11,6 +11,9 @@
 #define ur5_nv ur5m_nv
 #define ur5_nu ur5m_nu
 #define ur5_reset ur5m_reset
+#define ur5_reset_dev ur5m_reset_dev
+#define ur5_reset_kernel ur5m_reset_kernel
+#define ur5_kernel_ms_total ur5m_kernel_ms_total
 #define ur5_set_state ur5m_set_state
 #define ur5_get_state ur5m_get_state
 #define ur5_set_ctrl ur5m_set_ctrl

@@ -57,11 +57,42 @@ __global__ void __launch_bounds__(256) ur5_render_kernel(const Ur5RenderModel* _
   depth[o] = mode == 0 ? z : ur5r::gl_depth(*R, z);
 }
 
+// GraspEnv.reset_model for the flagged scenes, one thread per scene (ur5host::reset_record: the same code the host path runs);
+// max_steps[e] = number of 10-step settle chunks the following stay launch gives scene e (0: the scene sits it out).
+__global__ void __launch_bounds__(64) ur5_reset_kernel(double* __restrict__ rec, const double* __restrict__ qpos0, const uint64_t* __restrict__ seeds,
+                                                       const uint8_t* __restrict__ mask, int n, int chunks, int* __restrict__ max_steps) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const bool on = !mask || mask[e];
+  if (on) ur5host::reset_record(ur5_cmodel, qpos0, rec + (size_t)e * UR5_REC_STRIDE, seeds[e]);
+  max_steps[e] = on ? chunks : 0;
+}
+
+// Every launch is bracketed by its own pair of HIP events on the handle's stream; ur5_sync resolves the pairs recorded since
+// the previous sync (several launches may be queued: reset + settle + render + grasp attempt of one round).
 struct HipBackend {
   hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  bool timed = false;
+  std::vector<hipEvent_t> ev;      // pool: pairs [2k, 2k+1]
+  int pending = 0;                 // pairs recorded since the last sync
 };
+static void be_resolve(ur5_sim* h, HipBackend* b) {   // the stream must be idle
+  for (int k = 0; k < b->pending; k++) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, b->ev[2 * k], b->ev[2 * k + 1]) == hipSuccess) { h->last_ms = ms; h->kernel_ms_total += ms; }
+  }
+  b->pending = 0;
+}
+static int be_event_pair(ur5_sim* h, HipBackend* b, hipEvent_t* e0, hipEvent_t* e1) {
+  if (b->pending >= 64) { (void)hipStreamSynchronize(b->stream); be_resolve(h, b); }   // a caller that never syncs must not grow the pool
+  while ((int)b->ev.size() < 2 * (b->pending + 1)) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return -1;
+    b->ev.push_back(e);
+  }
+  *e0 = b->ev[2 * b->pending]; *e1 = b->ev[2 * b->pending + 1];
+  b->pending++;
+  return 0;
+}
 #define HIPCHK(call)                                                                                  \
   do {                                                                                                \
     hipError_t e_ = (call);                                                                           \
@@ -78,8 +109,6 @@ static int be_open(ur5_sim* h, int device_id) {
   HipBackend* b = new HipBackend();
   h->be = b;
   HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
-  HIPCHK(hipEventCreate(&b->ev0));
-  HIPCHK(hipEventCreate(&b->ev1));
   return 0;
 }
 static void be_close(ur5_sim* h) {
@@ -88,8 +117,7 @@ static void be_close(ur5_sim* h) {
   if (!b) return;
   (void)hipSetDevice(h->device);
   if (b->stream) (void)hipStreamSynchronize(b->stream);
-  if (b->ev0) (void)hipEventDestroy(b->ev0);
-  if (b->ev1) (void)hipEventDestroy(b->ev1);
+  for (hipEvent_t e : b->ev) (void)hipEventDestroy(e);
   if (b->stream) (void)hipStreamDestroy(b->stream);
   delete b;
   h->be = nullptr;
@@ -121,7 +149,9 @@ static int be_launch(ur5_sim* h, const Ur5Launch& P) {
   HipBackend* b = (HipBackend*)h->be;
   HIPCHK(hipSetDevice(h->device));
   { int rcm = be_upload_model(h); if (rcm) return rcm; }
-  HIPCHK(hipEventRecord(b->ev0, b->stream));
+  hipEvent_t ev0, ev1;
+  if (be_event_pair(h, b, &ev0, &ev1)) return ur5host::fail(UR5_ERR_DEVICE, "hipEventCreate failed");
+  HIPCHK(hipEventRecord(ev0, b->stream));
   dim3 grid(h->n), block(UR5_NT);
 #ifdef UR5_MANY
   {   // the scene needs more than the default 64 KB of dynamic LDS (one scene per CU)
@@ -137,8 +167,15 @@ static int be_launch(ur5_sim* h, const Ur5Launch& P) {
   else hipLaunchKernelGGL(ur5_run_kernel<UR5_MAXNV>, grid, block, sizeof(ur5::Lds<double, UR5_MAXNV>), b->stream, h->d_rec, P);
 #endif
   HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(b->ev1, b->stream));
-  b->timed = true;
+  HIPCHK(hipEventRecord(ev1, b->stream));
+  return 0;
+}
+static int be_reset_dev(ur5_sim* h, const uint64_t* seeds_dev, const uint8_t* mask_dev, int chunks, int* max_steps_dev) {
+  HipBackend* b = (HipBackend*)h->be;
+  HIPCHK(hipSetDevice(h->device));
+  { int rcm = be_upload_model(h); if (rcm) return rcm; }
+  hipLaunchKernelGGL(ur5_reset_kernel, dim3((h->n + 63) / 64), dim3(64), 0, b->stream, h->d_rec, h->d_qpos0, seeds_dev, mask_dev, h->n, chunks, max_steps_dev);
+  HIPCHK(hipGetLastError());
   return 0;
 }
 static int be_upload_model(ur5_sim* h) {
@@ -154,23 +191,19 @@ static int be_render(ur5_sim* h, int cam, int W, int Hh, int mode, uint8_t* rgb_
   HIPCHK(hipSetDevice(h->device));
   int rc = be_upload_model(h);
   if (rc) return rc;
-  HIPCHK(hipEventRecord(b->ev0, b->stream));
+  hipEvent_t ev0, ev1;
+  if (be_event_pair(h, b, &ev0, &ev1)) return ur5host::fail(UR5_ERR_DEVICE, "hipEventCreate failed");
+  HIPCHK(hipEventRecord(ev0, b->stream));
   dim3 grid(((W + 15) / 16) * ((Hh + 15) / 16), h->n), block(256);
   hipLaunchKernelGGL(ur5_render_kernel, grid, block, 0, b->stream, h->d_rm, h->d_rec, cam, W, Hh, mode, rgb_dev, depth_dev);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(b->ev1, b->stream));
-  b->timed = true;
+  HIPCHK(hipEventRecord(ev1, b->stream));
   return 0;
 }
 static int be_sync(ur5_sim* h) {
   HipBackend* b = (HipBackend*)h->be;
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipStreamSynchronize(b->stream));
-  if (b->timed) {
-    float ms = 0;
-    HIPCHK(hipEventElapsedTime(&ms, b->ev0, b->ev1));
-    h->last_ms = ms;
-    b->timed = false;
-  }
+  be_resolve(h, b);
   return 0;
 }

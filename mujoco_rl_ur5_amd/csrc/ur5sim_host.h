@@ -388,19 +388,49 @@ static int build_model(const void* data, size_t nbytes, int ee_body, Ur5DevModel
 // MujocoController.py:157-247: controller construction state (each PID called once with input 0)
 static const double PID_KP[7] = {7 * 3.0, 10 * 3.0, 5 * 3.0, 7 * 3.0, 5 * 3.0, 5 * 3.0, 2.5 * 3.0};
 static const double PID_SP[7] = {0, -1.57, 1.57, -1.57, -1.57, 0, 0};
-static const double HOME[7] = {0, -1.57, 1.57, -1.57, -1.57, 0.0, 0.3};  // GraspingEnv.py:418
 
+#if defined(__HIPCC__)
+#define UR5_HD __host__ __device__
+#else
+#define UR5_HD
+#endif
 struct SplitMix {
   uint64_t s;
-  uint64_t next() {
+  UR5_HD uint64_t next() {
     uint64_t z = (s += 0x9E3779B97F4A7C15ull);
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return z ^ (z >> 31);
   }
-  double uniform() { return (double)(next() >> 11) * (1.0 / 9007199254740992.0); }
-  double uniform(double lo, double hi) { return lo + (hi - lo) * uniform(); }
+  UR5_HD double uniform() { return (double)(next() >> 11) * (1.0 / 9007199254740992.0); }
+  UR5_HD double uniform(double lo, double hi) { return lo + (hi - lo) * uniform(); }
 };
+
+// GraspEnv.reset_model (GraspingEnv.py:409-477) for ONE scene record: MujocoEnv.reset() -> sim.reset() [3P] (qpos0, zero velocity /
+// warm start / ctrl / time; the controller's PID state persists), arm teleported to the home pose (:418), objects re-sampled from
+// the scene's own SplitMix64 stream (:420-430 free-joint piles; :435-463 the IT4 slide+ball objects). Shared by the host path
+// (ur5_reset) and the device path (ur5_reset_dev) so that both produce the same record.
+UR5_HD inline void reset_record(const Ur5DevModel& M, const double* qpos0, double* r, uint64_t seed) {
+  const double home[7] = {0, -1.57, 1.57, -1.57, -1.57, 0.0, 0.3};   // GraspingEnv.py:418
+  for (int i = 0; i < M.nq; i++) r[UR5_REC_QPOS + i] = qpos0[i];
+  for (int i = 0; i < M.nv; i++) { r[UR5_REC_QVEL + i] = 0; r[UR5_REC_WARM + i] = 0; }
+  for (int a = 0; a < M.nu; a++) { r[UR5_REC_CTRL + a] = 0; r[UR5_REC_QPOS + M.act_dof[a]] = home[a]; r[UR5_REC_TARGET + a] = home[a]; }
+  r[UR5_REC_MISC + 2] = 0; r[UR5_REC_MISC + 3] = 0;
+  SplitMix rng{seed};
+  const double two_pi = 6.283185307179586476925286766559;
+  for (int k = 0; k < M.nobj; k++) {
+    double* q = r + UR5_REC_QPOS + M.nrd + 7 * k;
+    if (M.obj_kind[k] == 1) {  // GraspingEnv.py:420-430
+      q[0] = rng.uniform(-0.25, 0.25); q[1] = rng.uniform(-0.77, -0.43); q[2] = rng.uniform(1.0, 1.5);
+      double r1 = rng.uniform(), r2 = rng.uniform(), r3 = rng.uniform();
+      q[3] = sqrt(1.0 - r1) * sin(two_pi * r2); q[4] = sqrt(1.0 - r1) * cos(two_pi * r2);
+      q[5] = sqrt(r1) * sin(two_pi * r3); q[6] = sqrt(r1) * cos(two_pi * r3);
+    } else {                   // GraspingEnv.py:435-463 (IT4)
+      q[0] = rng.uniform(-0.25, 0.25); q[1] = rng.uniform(-0.17, 0.17); q[2] = 0.0;
+      q[3] = 1; q[4] = q[5] = q[6] = 0;
+    }
+  }
+}
 
 }  // namespace ur5host
 
@@ -420,7 +450,8 @@ struct ur5_sim {
   float* d_depth = nullptr;
   size_t img_cap = 0;
   unsigned* d_mask = nullptr;
-  double *d_target = nullptr, *d_tol = nullptr, *d_debug = nullptr, *d_hess = nullptr;
+  double *d_target = nullptr, *d_tol = nullptr, *d_debug = nullptr, *d_hess = nullptr, *d_qpos0 = nullptr;
+  double kernel_ms_total = 0;   // engine-kernel time of every launch since ur5_create (HIP events on the handle's stream)
   int *d_max = nullptr, *d_result = nullptr, *d_steps = nullptr, *d_ps = nullptr, *d_pr = nullptr;
   std::vector<double> h_rec;
   double last_ms = 0;
@@ -437,6 +468,7 @@ static int be_d2h(ur5_sim* h, void* dst, const void* src, size_t bytes);
 static int be_launch(ur5_sim* h, const Ur5Launch& P);
 static int be_sync(ur5_sim* h);
 static int be_render(ur5_sim* h, int cam, int W, int Hh, int mode, uint8_t* rgb_dev, float* depth_dev);
+static int be_reset_dev(ur5_sim* h, const uint64_t* seeds_dev, const uint8_t* mask_dev, int chunks, int* max_steps_dev);
 
 namespace ur5host {
 static int pull(ur5_sim* h) { h->h_rec.resize((size_t)h->n * UR5_REC_STRIDE); return be_d2h(h, h->h_rec.data(), h->d_rec, h->h_rec.size() * 8); }
@@ -473,11 +505,12 @@ int ur5m_set_state(ur5_sim* h, const double* qpos, const double* qvel, const dou
 int ur5m_get_state(ur5_sim* h, double* qpos, double* qvel, double* warm, double* pid);
 int ur5m_set_ctrl(ur5_sim* h, const double* ctrl); int ur5m_get_ctrl(ur5_sim* h, double* ctrl);
 int ur5m_get_counters(ur5_sim* h, int64_t* c);
-int ur5m_stay(ur5_sim* h, double ms); int ur5m_reset(ur5_sim* h, const uint64_t* seeds, int mode, double settle_ms); int ur5m_step(ur5_sim* h, int nsteps);
+int ur5m_stay(ur5_sim* h, double ms); int ur5m_reset(ur5_sim* h, const uint64_t* seeds, int mode, double settle_ms);
+int ur5m_reset_dev(ur5_sim* h, const uint64_t* seeds_dev, const uint8_t* mask_dev, double settle_ms); double ur5m_kernel_ms_total(ur5_sim* h); int ur5m_step(ur5_sim* h, int nsteps);
 int ur5m_move_group(ur5_sim* h, const uint32_t* mask, const double* target, const double* tol, const int* max_steps, int* result, int* steps);
 int ur5m_move_ee(ur5_sim* h, const double* xyz, const double* tol, const int* max_steps, int* result, int* steps);
 int ur5m_grasp_attempt_dev(ur5_sim* h, const double* action_dev, int check_mode, double table_height, int* reward_dev);
-int ur5m_grasp_attempt(ur5_sim* h, const double* action, int check_mode, double table_height, int* reward, int* phase_steps, int* phase_result);
+int ur5m_grasp_attempt(ur5_sim* h, const double* action, const uint8_t* skip, int check_mode, double table_height, int* reward, int* phase_steps, int* phase_result);
 int ur5m_ik(ur5_sim* h, const double* xyz, double* q5, int* result);
 int ur5m_render_dev(ur5_sim* h, int camera_id, int width, int height, int depth_mode, uint8_t* rgb_dev, float* depth_dev);
 int ur5m_render(ur5_sim* h, int camera_id, int width, int height, int depth_mode, uint8_t* rgb, float* depth);
@@ -552,7 +585,7 @@ int ur5_create(const void* blob, size_t nbytes, int n_env, int device_id, const 
 void ur5_destroy(ur5_sim* h) {
   UR5_FWD_VOID(destroy, (h));
   if (!h) return;
-  void* ptrs[] = {h->dm, h->d_rec, h->d_mask, h->d_target, h->d_tol, h->d_max, h->d_result, h->d_steps, h->d_ps, h->d_pr, h->d_debug, h->d_rm, h->d_rgb, h->d_depth, h->d_hess};
+  void* ptrs[] = {h->dm, h->d_rec, h->d_mask, h->d_target, h->d_tol, h->d_max, h->d_result, h->d_steps, h->d_ps, h->d_pr, h->d_debug, h->d_rm, h->d_rgb, h->d_depth, h->d_hess, h->d_qpos0};
   for (void* p : ptrs) if (p) be_free(h, p);
   be_close(h);
   delete h;
@@ -650,31 +683,28 @@ int ur5_reset(ur5_sim* h, const uint64_t* seeds, int mode, double settle_ms) {
   if (!seeds) return fail(UR5_ERR_ARG, "ur5_reset: seeds is NULL");
   int rc = pull(h);
   if (rc) return rc;
-  const Ur5DevModel& M = h->hm;
-  for (int e = 0; e < h->n; e++) {
-    double* r = h->h_rec.data() + (size_t)e * UR5_REC_STRIDE;
-    // MujocoEnv.reset() -> sim.reset() [3P]: qpos0, zero velocity / warm start / ctrl / time; controller state persists
-    for (int i = 0; i < M.nq; i++) r[UR5_REC_QPOS + i] = h->qpos0[i];
-    for (int i = 0; i < M.nv; i++) { r[UR5_REC_QVEL + i] = 0; r[UR5_REC_WARM + i] = 0; }
-    for (int a = 0; a < M.nu; a++) { r[UR5_REC_CTRL + a] = 0; r[UR5_REC_QPOS + M.act_dof[a]] = HOME[a]; r[UR5_REC_TARGET + a] = HOME[a]; }
-    r[UR5_REC_MISC + 2] = 0; r[UR5_REC_MISC + 3] = 0;
-    SplitMix rng{seeds[e]};
-    for (int k = 0; k < M.nobj; k++) {
-      double* q = r + UR5_REC_QPOS + M.nrd + 7 * k;
-      if (M.obj_kind[k] == 1) {  // GraspingEnv.py:420-430
-        q[0] = rng.uniform(-0.25, 0.25); q[1] = rng.uniform(-0.77, -0.43); q[2] = rng.uniform(1.0, 1.5);
-        double r1 = rng.uniform(), r2 = rng.uniform(), r3 = rng.uniform();
-        q[3] = std::sqrt(1.0 - r1) * std::sin(2 * M_PI * r2); q[4] = std::sqrt(1.0 - r1) * std::cos(2 * M_PI * r2);
-        q[5] = std::sqrt(r1) * std::sin(2 * M_PI * r3); q[6] = std::sqrt(r1) * std::cos(2 * M_PI * r3);
-      } else {                   // GraspingEnv.py:435-463 (IT4)
-        q[0] = rng.uniform(-0.25, 0.25); q[1] = rng.uniform(-0.17, 0.17); q[2] = 0.0;
-        q[3] = 1; q[4] = q[5] = q[6] = 0;
-      }
-    }
-  }
+  for (int e = 0; e < h->n; e++) reset_record(h->hm, h->qpos0.data(), h->h_rec.data() + (size_t)e * UR5_REC_STRIDE, seeds[e]);
   rc = push(h);
   if (rc) return rc;
   return settle_ms > 0 ? ur5_stay(h, settle_ms) : 0;  // GraspingEnv.py:473
+}
+
+int ur5_reset_dev(ur5_sim* h, const uint64_t* seeds_dev, const uint8_t* mask_dev, double settle_ms) {
+  UR5_FWD(reset_dev, (h, seeds_dev, mask_dev, settle_ms));
+  using namespace ur5host;
+  if (!seeds_dev) return fail(UR5_ERR_ARG, "ur5_reset_dev: seeds_dev is NULL");
+  if (!h->d_qpos0) {
+    h->d_qpos0 = (double*)be_alloc(h, h->qpos0.size() * 8);
+    if (!h->d_qpos0) return fail(UR5_ERR_DEVICE, "device allocation failed (qpos0)");
+    int rc0 = be_h2d(h, h->d_qpos0, h->qpos0.data(), h->qpos0.size() * 8);
+    if (rc0) return rc0;
+  }
+  const int chunks = settle_ms > 0 ? (int)std::ceil(settle_ms / 1000.0 / h->hm.timestep / 10.0 - 1e-9) : 0;
+  int rc = be_reset_dev(h, seeds_dev, mask_dev, chunks, h->d_max);   // samples the flagged records, d_max[e] = flagged ? chunks : 0
+  if (rc || chunks == 0) return rc;
+  Ur5Launch P = base_launch(h, UR5_OP_STAY);
+  P.max_steps = h->d_max;
+  return be_launch(h, P);
 }
 
 int ur5_step(ur5_sim* h, int nsteps) {
@@ -736,12 +766,12 @@ int ur5_grasp_attempt_dev(ur5_sim* h, const double* action_dev, int check_mode, 
   P.result = reward_dev; P.steps = h->d_steps; P.phase_steps = h->d_ps; P.phase_result = h->d_pr;
   return be_launch(h, P);
 }
-int ur5_grasp_attempt(ur5_sim* h, const double* action, int check_mode, double table_height, int* reward, int* phase_steps, int* phase_result) {
-  UR5_FWD(grasp_attempt, (h, action, check_mode, table_height, reward, phase_steps, phase_result));
+int ur5_grasp_attempt(ur5_sim* h, const double* action, const uint8_t* skip, int check_mode, double table_height, int* reward, int* phase_steps, int* phase_result) {
+  UR5_FWD(grasp_attempt, (h, action, skip, check_mode, table_height, reward, phase_steps, phase_result));
   using namespace ur5host;
   if (!action || !reward) return fail(UR5_ERR_ARG, "ur5_grasp_attempt: action/reward are required");
   std::vector<double> t((size_t)h->n * 8, 0.0);
-  for (int e = 0; e < h->n; e++) for (int k = 0; k < 4; k++) t[8 * e + k] = action[4 * e + k];
+  for (int e = 0; e < h->n; e++) { for (int k = 0; k < 4; k++) t[8 * e + k] = action[4 * e + k]; t[8 * e + 4] = (skip && skip[e]) ? 1.0 : 0.0; }
   int rc = upload(h, h->d_target, t.data(), t.size());
   if (rc) return rc;
   rc = ur5_grasp_attempt_dev(h, h->d_target, check_mode, table_height, h->d_result);
@@ -796,6 +826,8 @@ int ur5_sync(ur5_sim* h) {
   UR5_FWD(sync, (h)); return be_sync(h); }
 double ur5_last_launch_ms(ur5_sim* h) {
   UR5_FWD(last_launch_ms, (h)); return h->last_ms; }
+double ur5_kernel_ms_total(ur5_sim* h) {
+  UR5_FWD(kernel_ms_total, (h)); return h->kernel_ms_total; }
 void* ur5_state_device_ptr(ur5_sim* h) {
   UR5_FWD(state_device_ptr, (h)); return h->d_rec; }
 

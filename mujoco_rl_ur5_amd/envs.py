@@ -44,7 +44,8 @@ class GraspEnv(object):
     metadata = {"render.modes": ["human", "rgb_array"], "video.frames_per_second": 500}
 
     def __init__(self, file="/UR5+gripper/UR5gripper_2_finger_many_objects.xml", image_width=200, image_height=200, show_obs=True,
-                 demo=False, render=False, n_envs=1, device_id=0, observation="render", check_mode=0, base_seed=20, _lib_path=None):
+                 demo=False, render=False, n_envs=1, device_id=0, observation="render", check_mode=0, base_seed=20, first_scene_id=0, n_total=None,
+                 _lib_path=None):
         self.initialized = False
         self.IMAGE_WIDTH = image_width
         self.IMAGE_HEIGHT = image_height
@@ -69,6 +70,11 @@ class GraspEnv(object):
         self.observation_mode = observation
         self.check_mode = check_mode                                         # 0 = in-tree script, 1 = IT1 (README.md:20)
         self.base_seed = base_seed                                           # Grasping_Agent_multidiscrete.py:64
+        # multi-rank runs: this handle simulates scenes [first_scene_id, first_scene_id + n_envs) of n_total; seeds are keyed by the
+        # GLOBAL scene id (sharding.global_seeds), so a scene's trajectory does not depend on how the batch is sharded
+        self.first_scene_id = int(first_scene_id)
+        self.n_total = int(n_total) if n_total is not None else self.first_scene_id + self.n_envs
+        self.device_id = int(device_id)
         self._episode = 0
         self.last_phase_steps = None
         self.last_phase_result = None
@@ -115,17 +121,8 @@ class GraspEnv(object):
         """GraspingEnv.py:205-386 for every scene at once; scenes flagged in ``skip`` (:124-131) sit the launch out."""
         coords = np.atleast_2d(np.asarray(coordinates, dtype=np.float64))
         rot = np.broadcast_to(np.asarray(rotation, dtype=np.int64), (self.n_envs,))
-        if skip is not None and np.any(skip):
-            # a skipped scene must not move: park it by saving / restoring its record around the launch
-            saved = self.sim.get_state()
-        rew, ps, pr = self.sim.grasp_attempt(coords, rot, check_mode=self.check_mode, table_height=self.TABLE_HEIGHT)
-        if skip is not None and np.any(skip):
-            now = self.sim.get_state()
-            for k in now:
-                now[k][skip] = saved[k][skip]
-            self.sim.set_state(qpos=now["qpos"], qvel=now["qvel"], warmstart=now["warmstart"], pid=now["pid"])
-            rew = np.where(skip, 0, rew)
-            ps = np.where(skip[:, None], 0, ps)
+        # a skipped scene takes the kernel's early-out (script case 0), exactly as in step_device: nothing of its state changes
+        rew, ps, pr = self.sim.grasp_attempt(coords, rot, check_mode=self.check_mode, table_height=self.TABLE_HEIGHT, skip=skip)
         self.last_phase_steps, self.last_phase_result = ps, pr
         self.controller.last_movement_steps = self._one(ps[:, 11])
         return rew.astype(np.int64)
@@ -135,7 +132,8 @@ class GraspEnv(object):
         return self.reset_model()
 
     def reset_model(self, show_obs=True):                                    # :409-477
-        seeds = np.uint64(self.base_seed) + np.arange(self.n_envs, dtype=np.uint64) + np.uint64(self._episode * self.n_envs)
+        seeds = (np.uint64(self.base_seed) + np.arange(self.first_scene_id, self.first_scene_id + self.n_envs, dtype=np.uint64)
+                 + np.uint64(self._episode * self.n_total))                   # == sharding.global_seeds for this rank's range
         self._episode += 1
         self.sim.reset(seeds, mode=1, settle_ms=1000.0 + (5000.0 if self.demo_mode else 0.0))   # :473-475
         self.current_observation = self.get_observation(show=self.show_observations)
@@ -158,8 +156,19 @@ class GraspEnv(object):
     # The agent loop of Grasping_Agent_multidiscrete.py needs, per step, the RGB-D observation as a network input and the depth under
     # the chosen pixel. With thousands of scenes the 280 KB observation per scene must not cross PCIe: these two methods keep
     # observations, actions and rewards in torch tensors on the simulating GPU (host tensors for the CPU lane-emulation build).
+    def _torch_device(self, device):
+        """None -> the GPU this handle simulates on. The engine dereferences raw data_ptr()s, so a CUDA tensor on another device is an error."""
+        import torch
+        d = torch.device(f"cuda:{self.device_id}" if device is None else device)
+        if d.type == "cuda" and d.index is None:
+            d = torch.device("cuda", torch.cuda.current_device())
+        if d.type == "cuda" and d.index != self.device_id:
+            raise ValueError(f"tensors on {d} but the engine handle runs on cuda:{self.device_id}")
+        return d
+
     def _torch_setup(self, device):
         import torch
+        device = self._torch_device(device)
         if getattr(self, "_tdev", None) == str(device):
             return torch
         self._tdev = str(device)
@@ -176,7 +185,7 @@ class GraspEnv(object):
         self._t_t = torch.from_numpy(Rinv @ self.controller.cam_pos).to(device)
         return torch
 
-    def observation_device(self, device="cuda"):
+    def observation_device(self, device=None):
         """get_observation (:390-406) without leaving the device: {"rgb": uint8 [N,H,W,3], "depth": float32 [N,H,W] metres}."""
         torch = self._torch_setup(device)
         cam = self.model.camera_name2id("top_down")
@@ -188,12 +197,12 @@ class GraspEnv(object):
         near, far = self.model.opt["znear"] * ext, self.model.opt["zfar"] * ext
         return {"rgb": self._t_rgb, "depth": near / (1 - self._t_gl * (1 - near / far))}          # depth_2_meters (:729-740)
 
-    def pixel_world_device(self, depth, device="cuda"):
+    def pixel_world_device(self, depth, device=None):
         """World coordinates [N,H,W,3] (float64) of every pixel given the metric depth image: pixel_2_world for all pixels at once."""
         self._torch_setup(device)
         return self._t_t - depth.double().unsqueeze(-1) * self._t_rays
 
-    def step_device(self, action, depth, device="cuda"):
+    def step_device(self, action, depth, device=None):
         """GraspEnv.step (:62-156) with ``action`` long [N,2] = [pixel, rotation] and the current metric ``depth`` [N,H,W] on the device.
         Returns (reward int32 [N], skipped bool [N]) as device tensors; the caller asks for the next observation when it needs one."""
         torch = self._torch_setup(device)

@@ -17,7 +17,7 @@ DEFAULT_LIB = os.path.join(_HERE, "csrc", "libur5sim.so")
 RES_NONE, RES_SUCCESS, RES_MAX_STEPS, RES_IK_FAIL = -1, 0, 1, 2
 # limits of the two engine variants (csrc/ur5_devmodel.h): (max objects, debug stride, record stride, max contacts)
 _VARIANT = {0: (6, 2048, 192, 30), 1: (40, 4096, 832, 160)}
-EXPORTS = ["ur5_last_error", "ur5_create", "ur5_destroy", "ur5_num_envs", "ur5_nq", "ur5_nv", "ur5_nu", "ur5_reset",
+EXPORTS = ["ur5_last_error", "ur5_create", "ur5_destroy", "ur5_num_envs", "ur5_nq", "ur5_nv", "ur5_nu", "ur5_reset", "ur5_reset_dev", "ur5_kernel_ms_total",
            "ur5_set_state", "ur5_get_state", "ur5_set_ctrl", "ur5_get_ctrl", "ur5_step", "ur5_move_group", "ur5_stay",
            "ur5_move_ee", "ur5_ik", "ur5_grasp_attempt", "ur5_grasp_attempt_dev", "ur5_sync", "ur5_last_launch_ms",
            "ur5_get_counters", "ur5_body_xpos", "ur5_render", "ur5_render_dev", "ur5_state_device_ptr", "ur5_forward_debug"]
@@ -46,6 +46,9 @@ def load(path=None):
     for f in ("ur5_num_envs", "ur5_nq", "ur5_nv", "ur5_nu", "ur5_sync"):
         getattr(L, f).argtypes = [vp]
     L.ur5_reset.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int, C.c_double]
+    L.ur5_reset_dev.argtypes = [vp, vp, vp, C.c_double]
+    L.ur5_kernel_ms_total.argtypes = [vp]
+    L.ur5_kernel_ms_total.restype = C.c_double
     L.ur5_set_state.argtypes = [vp, dp, dp, dp, dp]
     L.ur5_get_state.argtypes = [vp, dp, dp, dp, dp]
     L.ur5_set_ctrl.argtypes = [vp, dp]
@@ -55,7 +58,7 @@ def load(path=None):
     L.ur5_stay.argtypes = [vp, C.c_double]
     L.ur5_move_ee.argtypes = [vp, dp, dp, ip, ip, ip]
     L.ur5_ik.argtypes = [vp, dp, dp, ip]
-    L.ur5_grasp_attempt.argtypes = [vp, dp, C.c_int, C.c_double, ip, ip, ip]
+    L.ur5_grasp_attempt.argtypes = [vp, dp, C.POINTER(C.c_uint8), C.c_int, C.c_double, ip, ip, ip]
     L.ur5_grasp_attempt_dev.argtypes = [vp, vp, C.c_int, C.c_double, vp]
     L.ur5_last_launch_ms.argtypes = [vp]
     L.ur5_last_launch_ms.restype = C.c_double
@@ -119,6 +122,11 @@ class BatchSim:
     def reset(self, seeds, mode=1, settle_ms=1000.0):
         s = np.ascontiguousarray(np.broadcast_to(np.asarray(seeds, dtype=np.uint64), (self.n,)).copy())
         self._check(self.lib.ur5_reset(self._h, s.ctypes.data_as(C.POINTER(C.c_uint64)), mode, float(settle_ms)), "ur5_reset")
+
+    def reset_dev(self, seeds_ptr, mask_ptr=None, settle_ms=1000.0):
+        """Asynchronous reset of the flagged scenes: seeds_ptr -> [n] uint64, mask_ptr -> [n] uint8 or None, HIP device pointers."""
+        self._check(self.lib.ur5_reset_dev(self._h, C.c_void_p(seeds_ptr), C.c_void_p(mask_ptr) if mask_ptr else None, float(settle_ms)),
+                    "ur5_reset_dev")
 
     def get_state(self):
         qpos, qvel, warm = np.zeros((self.n, self.nq)), np.zeros((self.n, self.nv)), np.zeros((self.n, self.nv))
@@ -186,14 +194,15 @@ class BatchSim:
         self._check(self.lib.ur5_ik(self._h, _dp(x), _dp(q5), _ip(res)), "ur5_ik")
         return q5, res
 
-    def grasp_attempt(self, xyz, rot=0, check_mode=0, table_height=0.91):
+    def grasp_attempt(self, xyz, rot=0, check_mode=0, table_height=0.91, skip=None):
         a = np.zeros((self.n, 4))
         a[:, :3] = np.broadcast_to(np.asarray(xyz, dtype=np.float64), (self.n, 3))
         a[:, 3] = np.broadcast_to(np.asarray(rot, dtype=np.float64), (self.n,))
         rew = np.zeros(self.n, dtype=np.int32)
         ps, pr = np.zeros((self.n, 12), dtype=np.int32), np.zeros((self.n, 12), dtype=np.int32)
-        self._check(self.lib.ur5_grasp_attempt(self._h, _dp(a), int(check_mode), float(table_height), _ip(rew), _ip(ps), _ip(pr)),
-                    "ur5_grasp_attempt")
+        sk = None if skip is None else np.ascontiguousarray(np.broadcast_to(np.asarray(skip), (self.n,)).astype(np.uint8))
+        self._check(self.lib.ur5_grasp_attempt(self._h, _dp(a), None if sk is None else sk.ctypes.data_as(C.POINTER(C.c_uint8)), int(check_mode),
+                                               float(table_height), _ip(rew), _ip(ps), _ip(pr)), "ur5_grasp_attempt")
         return rew, ps, pr
 
     def grasp_attempt_dev(self, action_ptr, reward_ptr, check_mode=0, table_height=0.91):
@@ -207,8 +216,25 @@ class BatchSim:
     def last_launch_ms(self):
         return float(self.lib.ur5_last_launch_ms(self._h))
 
+    def kernel_ms_total(self):
+        return float(self.lib.ur5_kernel_ms_total(self._h))
+
     def state_device_ptr(self):
         return self.lib.ur5_state_device_ptr(self._h)
+
+    def state_tensor(self, device):
+        """The [n, stride] float64 state records (csrc/ur5_devmodel.h layout) as a torch tensor ALIASING the engine's device memory
+        (host memory for the test-only emulation build): lets callers read object poses / write nothing without a PCIe round trip."""
+        import torch
+        stride = _VARIANT[self.variant][2]
+        ptr = self.state_device_ptr()
+        if torch.device(device).type == "cpu":
+            buf = (C.c_double * (self.n * stride)).from_address(ptr)
+            return torch.frombuffer(buf, dtype=torch.float64).view(self.n, stride)
+
+        class _Alias:   # __cuda_array_interface__ v2: torch wraps the pointer without copying
+            __cuda_array_interface__ = {"shape": (self.n, stride), "typestr": "<f8", "data": (int(ptr), False), "version": 2, "strides": None}
+        return torch.as_tensor(_Alias(), device=device)
 
     def body_xpos(self):
         out = np.zeros((self.n, 8 + _VARIANT[self.variant][0], 3))

@@ -114,8 +114,8 @@ class ReplayBuffer:
     b-1 transitions drawn without replacement plus the most recent one (:46-49), python ``random`` seeded with 20 (:33).
 
     Batched use: ``push`` takes N transitions at once (one per scene of the rank) and stores them in scene order, which is what N
-    consecutive pushes of the reference would do. States are kept as uint8 RGB + float16 normalised depth (5 bytes per pixel instead of
-    the reference's 16) and expanded to the 4-channel float tensor on ``sample``."""
+    consecutive pushes of the reference would do. States are kept as uint8 RGB + float32 normalised depth (7 bytes per pixel instead of
+    the reference's 16; the 1e-3 depth noise of transform_observation survives, which float16's 5e-4 steps would not guarantee) and expanded to the 4-channel float tensor on ``sample``."""
 
     def __init__(self, size, height=200, width=200, device="cpu", simple=True, seed=20):
         if not simple:
@@ -123,7 +123,7 @@ class ReplayBuffer:
         self.size, self.position, self.count = int(size), 0, 0
         self.device = torch.device(device)
         self.rgb = torch.zeros((self.size, 3, height, width), dtype=torch.uint8, device=self.device)
-        self.depth = torch.zeros((self.size, 1, height, width), dtype=torch.float16, device=self.device)
+        self.depth = torch.zeros((self.size, 1, height, width), dtype=torch.float32, device=self.device)
         self.action = torch.zeros((self.size, 1), dtype=torch.long, device=self.device)
         self.reward = torch.zeros((self.size, 1), dtype=torch.float32, device=self.device)
         self._rng = random.Random(seed)
@@ -134,9 +134,14 @@ class ReplayBuffer:
     def push(self, state, action, reward):
         """state [N,4,H,W] float in [0,1] (rgb/255, normalised depth), action [N] or [N,1] long, reward [N] or [N,1]."""
         n = state.shape[0]
+        if n > self.size:   # N consecutive pushes into a ring of `size` keep the last `size`: drop the rest up front (no duplicate indices)
+            drop = n - self.size
+            state, action, reward = state[drop:], action.reshape(n, -1)[drop:], reward.reshape(n, -1)[drop:]
+            self.position = (self.position + drop) % self.size
+            n = self.size
         idx = (self.position + torch.arange(n, device=self.device)) % self.size
         self.rgb[idx] = (state[:, :3].to(self.device) * 255.0).round().clamp(0, 255).to(torch.uint8)
-        self.depth[idx] = state[:, 3:4].to(self.device).to(torch.float16)
+        self.depth[idx] = state[:, 3:4].to(self.device).float()
         self.action[idx] = action.reshape(n, 1).to(self.device).long()
         self.reward[idx] = reward.reshape(n, 1).to(self.device).float()
         self.position = (self.position + n) % self.size

@@ -16,6 +16,22 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """`gpu` tests need the MI355X and the built HIP library: skip (not fail) them on a box without either."""
+    import torch
+    lib = os.path.join(ROOT, "mujoco_rl_ur5_amd", "csrc", "libur5sim.so")
+    why = None
+    if not torch.cuda.is_available():
+        why = "no GPU visible"
+    elif not os.path.exists(lib):
+        why = "mujoco_rl_ur5_amd/csrc/libur5sim.so is not built"
+    if why:
+        skip = pytest.mark.skip(reason=why)
+        for it in items:
+            if "gpu" in it.keywords:
+                it.add_marker(skip)
+
+
 def build_emul(flags=(), name="libur5sim_emul.so"):
     """Test-only lane-emulation build of the engine source (see tests/emul/ur5sim_emul.cpp)."""
     lib = os.path.join(os.path.dirname(EMUL_LIB), name)

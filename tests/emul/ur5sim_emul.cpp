@@ -15,6 +15,14 @@ static void be_free(ur5_sim*, void* p) { free(p); }
 static int be_h2d(ur5_sim*, void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); return 0; }
 static int be_d2h(ur5_sim*, void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); return 0; }
 static int be_sync(ur5_sim*) { return 0; }
+static int be_reset_dev(ur5_sim* h, const uint64_t* seeds, const uint8_t* mask, int chunks, int* max_steps) {
+  for (int e = 0; e < h->n; e++) {
+    const bool on = !mask || mask[e];
+    if (on) ur5host::reset_record(*h->dm, h->d_qpos0, h->d_rec + (size_t)e * UR5_REC_STRIDE, seeds[e]);
+    max_steps[e] = on ? chunks : 0;
+  }
+  return 0;
+}
 
 template <int NV> static void run_all(ur5_sim* h, const Ur5Launch& P) {
   typedef ur5::Lds<double, NV> L;

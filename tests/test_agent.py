@@ -43,7 +43,9 @@ def test_agent_rounds_on_cpu(model_it1, emul_lib):
     assert state.shape == (2, 4, 24, 24) and float(state.min()) >= 0 and float(state.max()) <= 1
     d = obs["depth"].clamp(max=agent.depth_threshold)                       # transform_observation of the reference, one image
     ref = (-d[0] - (-d[0]).min()) / ((-d[0]).max() - (-d[0]).min())
-    assert torch.allclose(state[0, 3], ref, atol=1e-6) and torch.allclose(state[0, :3], obs["rgb"][0].permute(2, 0, 1).float() / 255)
+    # the reference adds N(0, 1e-3) depth noise whenever normalize=True (Grasping_Agent_multidiscrete.py:317): 5 sigma over the ~0.1-0.2 m range
+    span = float((-d[0]).max() - (-d[0]).min())                           # a view of the bare table has no depth range: the noise is all there is
+    assert (span < 0.02 or torch.allclose(state[0, 3], ref, atol=0.006 / span)) and torch.allclose(state[0, :3], obs["rgb"][0].permute(2, 0, 1).float() / 255)
     action, greedy = agent.epsilon_greedy(state, obs)                       # epsilon = 1 at the start: every action is a random table pixel
     assert not greedy.any() and agent.steps_done == 2
     pa = agent.transform_action(action)

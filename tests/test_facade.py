@@ -85,3 +85,38 @@ def test_default_env_is_the_many_object_scene(emul_lib):
     assert c["status"][0] == 0 and 5 < c["ncon_max"][0] < 160
     r = e.controller.move_group_to_joint_target(group="Gripper", target=[0.2], tolerance=0.05, max_steps=200, quiet=True)
     assert r == "success"
+
+
+def test_reset_dev_matches_host_reset_and_leaves_unflagged_scenes_alone(model_it1, emul_lib):
+    """ur5_reset_dev (device-side GraspEnv.reset_model for flagged scenes) == ur5_reset scene by scene; unflagged scenes untouched."""
+    import ctypes as C
+    import numpy as np
+    from mujoco_rl_ur5_amd.native import BatchSim
+    n = 4
+    a, b = BatchSim(model_it1, n, lib_path=emul_lib), BatchSim(model_it1, n, lib_path=emul_lib)
+    seeds = (20 + np.arange(n)).astype(np.uint64)
+    a.reset(seeds + np.uint64(100), 1, 40.0)                      # the controller's PID state persists across resets: same history
+    a.reset(seeds, 1, 40.0)
+    b.reset(seeds + np.uint64(100), 1, 40.0)
+    before = b.get_state()
+    mask = np.array([1, 0, 1, 1], dtype=np.uint8)
+    b.reset_dev(seeds.ctypes.data, mask.ctypes.data, 40.0)        # emulation build: "device" pointers are host pointers
+    b.sync()
+    sa, sb = a.get_state(), b.get_state()
+    for k in ("qpos", "qvel", "warmstart"):
+        assert np.array_equal(sa[k][mask == 1], sb[k][mask == 1]), k
+        assert np.array_equal(before[k][1], sb[k][1]), k
+
+
+def test_host_step_skip_uses_the_kernel_early_out(model_it1, emul_lib):
+    """GraspingEnv.py:124-131: a skipped scene keeps its whole record (ctrl and counters included), reward 0."""
+    import numpy as np
+    from mujoco_rl_ur5_amd.native import BatchSim
+    sim = BatchSim(model_it1, 2, lib_path=emul_lib)
+    sim.reset((20 + np.arange(2)).astype(np.uint64), 1, 40.0)
+    st0, c0, u0 = sim.get_state(), sim.counters(), sim.get_ctrl()
+    rew, ps, _ = sim.grasp_attempt(np.array([[0.0, -0.6, 0.95], [0.0, -0.6, 0.95]]), rot=0, check_mode=1, skip=np.array([1, 0]))
+    st1, c1, u1 = sim.get_state(), sim.counters(), sim.get_ctrl()
+    assert rew[0] == 0 and ps[0].sum() == 0 and c1["total_steps"][0] == c0["total_steps"][0] and np.array_equal(u0[0], u1[0])
+    assert all(np.array_equal(st0[k][0], st1[k][0]) for k in st0)
+    assert c1["total_steps"][1] > c0["total_steps"][1]
