@@ -1,19 +1,32 @@
 #!/usr/bin/env python3
-"""Headline benchmark (BASELINE.json config 2): 4096 batched IT1 scenes per MI355X, physics only, fixed-z grasp attempts
-with the 500-step closing check (README.md:20 of the reference). A "step" is one grasp-attempt round over the whole batch
-= one launch of the hot path (GraspEnv.step -> move_and_grasp, GraspingEnv.py:62-156,205-386) on every scene.
+"""Headline benchmark (BASELINE.json config 2): 4096 batched IT1 scenes, physics only, fixed-z grasp attempts with the 500-step
+closing check (README.md:20 of the reference). A "step" is one grasp-attempt round over the whole batch = the hot path
+(GraspEnv.step -> move_and_grasp, GraspingEnv.py:62-156,205-386, plus GraspEnv.reset_model at episode boundaries, :409-477).
 
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0. value = env-steps/s of the whole job (2 ms physics steps actually executed, summed over all
-scenes and ranks, / max-over-ranks wall time of the K timed rounds); grasp-attempts/s is reported next to it.
-Inputs (actions) are resident in HBM before the timed region; rewards stay on the device. N > 1: scenes shard over ranks
-(4096 per GPU, weak scaling, seeds keyed by global scene id) and every round ends with ONE RCCL all_gather of the 16-byte
-outcome records (mujoco_rl_ur5_amd/sharding.py), inside the timed region.
+Workload (stationary by construction, stated in the JSON line as config.rule):
+  * every scene lives through episodes of EP = 4 rounds: reset_model (objects re-sampled from the scene's SplitMix64 stream, arm to
+    home, 1000 ms settle) and then one grasp attempt per round. Scene g starts its episodes at rounds r with (r + g) % 4 == 0, so in
+    every round exactly a quarter of the batch resets: the mix of settling / full-bin / nearly-empty-bin scenes is the same in every
+    round, warm-up or timed.
+  * rule "aimed" (headline): in round j of its episode scene g aims at the CURRENT position of the first of boxes (g + j + i) % 4,
+    i = 0.., that still lies on the pick plate (read from the engine's state records on the device), z = 0.91, rotation cycling;
+    an empty plate gets an attempt at its centre.
+  * rule "uniform" (second figure, SURVEY.md section 8d's own rule): a uniformly drawn pixel of the 200x200 top-down image whose
+    back-projection lies on the table (the agent's rejection rule, Grasping_Agent_multidiscrete.py:266-280), rotation 0, z = 0.91.
+Everything a round needs (seeds, flags, action records) is produced on the device on the SAME HIP stream as the engine's kernels
+(ur5_set_stream): no host synchronisation inside a round except the outcome all_gather's own.
+
+Prints ONE JSON line on rank 0. value = env-steps/s of the whole job (2 ms physics steps actually executed, summed over all scenes
+and ranks, / max-over-ranks wall time of the K timed rounds); grasp-attempts/s next to it. N > 1: scenes shard over ranks
+(--scaling weak: 4096 per GPU; strong: 4096 in total), seeds keyed by global scene id, and every round ends
+with ONE RCCL all_gather of the 16-byte outcome records (mujoco_rl_ur5_amd/sharding.py), inside the timed region.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -22,63 +35,166 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+EP = 4          # rounds per episode
+BASE_SEED = 20  # Grasping_Agent_multidiscrete.py:64
 
 
-def aimed_actions(qpos, first_id, round_idx, nobj=4):
-    """Synthetic input: scene g aims at the settled position of object (g + round) % nobj, z = 0.91."""
-    n = qpos.shape[0]
-    a = np.zeros((n, 8))
-    for e in range(n):
-        objs = qpos[e][8:].reshape(-1, 7)
-        k = (first_id + e + round_idx) % nobj
-        a[e, :3] = [objs[k, 0], -0.6 + objs[k, 1], 0.91]
-        a[e, 3] = ((first_id + e) // nobj + round_idx) % 6
-    return a
+class It1Rounds:
+    """Device-side driver of the stationary IT1 workload for one rank: flags / seeds of the scenes that reset, action records."""
+
+    def __init__(self, torch, model, sim, dev, lo, n_local, n_total, rule):
+        from mujoco_rl_ur5_amd.controller import MJ_Controller
+        self.torch, self.sim, self.rule, self.n, self.n_total = torch, sim, rule, n_local, n_total
+        self.gid = torch.arange(lo, lo + n_local, dtype=torch.int64, device=dev)
+        self.state = sim.state_tensor(dev)                                        # [n, 192] f64, aliases the engine's records
+        # objects: 3 slides + ball each (UR5gripper_2_finger.xml:233-239): world position = body_pos + slide offsets
+        self.nobj = (model.nq - 8) // 7
+        obj_bodies = [int(model.jnt_bodyid[list(model.jnt_qposadr).index(8 + 7 * k)]) for k in range(self.nobj)]
+        self.pos0 = torch.from_numpy(np.asarray(model.body_pos)[obj_bodies].copy()).to(dev)   # [nobj, 3]
+        # pinhole of the top-down camera at table height (MujocoController.py:742-806): world (x, y) <-> pixel is affine at fixed z
+        ctl = MJ_Controller(model, sim, None)
+        z_t = 0.91
+        cam_z = float(model.cam_pos0[model.camera_name2id("top_down")][2])
+        p00 = ctl.pixel_2_world(0, 0, cam_z - z_t, 200, 200)
+        p10 = ctl.pixel_2_world(1, 0, cam_z - z_t, 200, 200)
+        p01 = ctl.pixel_2_world(0, 1, cam_z - z_t, 200, 200)
+        self.px0 = (float(p00[0]), float(p00[1]))
+        self.dxdpx, self.dydpy = float(p10[0] - p00[0]), float(p01[1] - p00[1])
+        assert abs(p10[1] - p00[1]) < 1e-9 and abs(p01[0] - p00[0]) < 1e-9, "top-down camera: pixel axes are world axes"
+        if rule == "uniform":                                                    # pixels whose back-projection lies on the plate
+            px = np.arange(200)
+            X = self.px0[0] + self.dxdpx * px
+            Y = self.px0[1] + self.dydpy * px
+            ok = (np.abs(X)[None, :] <= 0.27) & (np.abs(Y + 0.6)[:, None] <= 0.19)
+            self.table_pixels = torch.from_numpy(np.flatnonzero(ok.ravel())).to(dev)       # flat index = y * 200 + x
+            self.gen = torch.Generator(device=dev).manual_seed(BASE_SEED)
+
+    def reset_flags(self, r):
+        """(flags uint8 [n], seeds int64 [n]) for round r: scene g starts an episode when (r + g) % EP == 0 (not at r = 0: the
+        untimed reset before the first round already is episode 0)."""
+        torch = self.torch
+        k = self.gid + r
+        flags = ((k % EP) == 0) & torch.tensor(r > 0, device=k.device)
+        seeds = BASE_SEED + self.gid + self.n_total * (k // EP)                  # == sharding.global_seeds(20, n_total, ..., episode)
+        return flags.to(torch.uint8), seeds
+
+    def actions(self, r):
+        """[n, 8] f64 action records (x y z rot skip - - -) and the aimed pixel index [n] int32, from the CURRENT state on the device."""
+        torch = self.torch
+        a = torch.zeros((self.n, 8), dtype=torch.float64, device=self.gid.device)
+        a[:, 2] = 0.91
+        if self.rule == "aimed":
+            q = self.state[:, 8:8 + 7 * self.nobj].view(self.n, self.nobj, 7)[:, :, :3] + self.pos0      # [n, nobj, 3] world
+            on = (q[:, :, 0].abs() <= 0.27) & ((q[:, :, 1] + 0.6).abs() <= 0.19) & (q[:, :, 2] >= 0.905) & (q[:, :, 2] <= 1.0)
+            j = (self.gid + r) % EP
+            order = (self.gid[:, None] + j[:, None] + torch.arange(self.nobj, device=on.device)[None, :]) % self.nobj
+            on_o = torch.gather(on, 1, order)
+            first = torch.argmax(on_o.to(torch.int8), dim=1)                     # first candidate that is on the plate
+            pick = torch.gather(order, 1, first[:, None])[:, 0]
+            any_on = on_o.any(dim=1)
+            xy = q[torch.arange(self.n, device=on.device), pick, :2]
+            centre = torch.tensor([0.0, -0.6], dtype=torch.float64, device=on.device)
+            a[:, :2] = torch.where(any_on[:, None], xy, centre)
+            a[:, 3] = ((self.gid // EP + r) % 6).double()
+        else:
+            idx = self.table_pixels[torch.randint(len(self.table_pixels), (self.n,), device=self.gid.device, generator=self.gen)]
+            a[:, 0] = self.px0[0] + self.dxdpx * (idx % 200).double()
+            a[:, 1] = self.px0[1] + self.dydpy * (idx // 200).double()
+        px = ((a[:, 0] - self.px0[0]) / self.dxdpx).round().clamp(0, 199)
+        py = ((a[:, 1] - self.px0[1]) / self.dydpy).round().clamp(0, 199)
+        return a, (py * 200 + px).to(torch.int32)
 
 
-def aimed_actions_rendered(xpos, first_id, round_idx):
-    """--workload many / it4 (configs[3] / configs[2] shape): scene g aims at one of the objects lying in the pick bin, 2 cm above its
-    centre (what the depth image gives for these object sizes), rotation index cycling through the 6 wrist angles (GraspingEnv.py:40).
-    xpos: world positions of the objects [n, nobj, 3]."""
-    n = xpos.shape[0]
-    a = np.zeros((n, 8))
-    for e in range(n):
-        objs = xpos[e]
-        inbin = np.where((np.abs(objs[:, 0]) < 0.2) & (np.abs(objs[:, 1] + 0.6) < 0.13) & (objs[:, 2] > 0.85))[0]
-        k = inbin[(first_id + e + round_idx) % len(inbin)] if len(inbin) else 0
-        a[e, :3] = [objs[k, 0], objs[k, 1], objs[k, 2] + 0.02]
-        a[e, 3] = (first_id + e + round_idx) % 6
-    return a
-
-
-def cpu_baseline(model, budget_s=10.0, many=False):
-    """The fp64 oracle (a port: the reference's own MuJoCo binary cannot exist here) on the host cores, same scenes/actions:
-    one scene per native thread on every core (SURVEY.md section 8d ii; oracle/ur5_oracle.cpp ur5o_batch), plus the single-core rate.
-    IT1: reset settling + one aimed grasp attempt per scene (= aimed_actions() above); many: the first 100 steps of the drop."""
+def cpu_baseline(model, budget_s=12.0, many=False):
+    """The fp64 oracle (a port: the reference's own MuJoCo binary cannot exist here) on the host cores, SAME workload as the timed GPU
+    rounds: whole episodes of reset + 1000 ms settle + EP aimed grasp attempts (oracle/ur5_oracle.cpp ur5o_batch mode 2, bench_aim),
+    one scene per native thread on every core (SURVEY.md section 8d ii), plus the single-core rate."""
     from oracle import oracle as O
     cores = os.cpu_count() or 1
-    s1, a1, t1 = O.batch(model, 1, 0.3 * budget_s, 1 if many else 0, 100)
-    sn, an, tn = O.batch(model, cores, 0.7 * budget_s, 1 if many else 0, 100)
-    what = ("the first 100 steps of the 40-object drop of scenes 0..%d" % (an - 1)) if many else \
-           ("IT1 reset settling + one aimed grasp attempt of scenes 0..%d" % (an - 1))
-    out = dict(value=sn / tn, unit="env-steps/s", cores=cores, kind="port",
-               sample=f"{what} ({sn} physics steps), oracle/ur5_oracle.cpp, one scene per thread on {cores} threads for {tn:.1f} s wall",
-               single_core={"value": s1 / t1, "sample": f"{a1} scenes ({s1} steps), {t1:.1f} s on one core"})
-    if not many:
-        out["grasp_attempts_per_s"] = an / tn
+    if many:
+        s1, a1, t1, _, _ = O.batch(model, 1, 0.3 * budget_s, 1, 100)
+        sn, an, tn, _, _ = O.batch(model, cores, 0.7 * budget_s, 1, 100)
+        return dict(value=sn / tn, unit="env-steps/s", cores=cores, kind="port",
+                    sample=f"the first 100 steps of the 40-object drop of scenes 0..{an - 1} ({sn} physics steps), oracle/ur5_oracle.cpp, "
+                           f"one scene per thread on {cores} threads for {tn:.1f} s wall",
+                    single_core={"value": s1 / t1, "sample": f"{a1} scenes ({s1} steps), {t1:.1f} s on one core"})
+    s1, e1, t1, att1, _ = O.batch(model, 1, 0.3 * budget_s, 2, EP)
+    sn, en, tn, attn, sucn = O.batch(model, cores, 0.7 * budget_s, 2, EP)
+    return dict(value=sn / tn, unit="env-steps/s", cores=cores, kind="port",
+                sample=f"{en} whole episodes (scenes 0..{en - 1}: reset + 1000 ms settle + {EP} aimed attempts, the timed GPU rule; {sn} physics "
+                       f"steps, {attn} attempts), oracle/ur5_oracle.cpp, one scene per thread on {cores} threads for {tn:.1f} s wall",
+                grasp_attempts_per_s=attn / tn, grasp_success_rate=sucn / max(1, attn), env_steps_per_attempt=sn / max(1, attn),
+                single_core={"value": s1 / t1, "grasp_attempts_per_s": att1 / t1,
+                             "sample": f"{e1} episodes ({s1} steps, {att1} attempts), {t1:.1f} s on one core"})
+
+
+def rendered_sub_result(torch, dev, local_rank, workload, n, rounds, warmup):
+    """Short N=1 measurement of the render + grasp-round shape of BASELINE.json configs[2] (it4) / configs[3] (many) so that the driver's
+    one line also times them: `rounds` timed rounds after `warmup`, actions aimed (from the reset state) at distinct objects per round."""
+    from mujoco_rl_ur5_amd.model import load_model
+    from mujoco_rl_ur5_amd.native import BatchSim
+    many = workload == "many"
+    model = load_model("/UR5+gripper/UR5gripper_2_finger_many_objects.xml" if many else "/UR5+gripper/UR5gripper_2_finger.xml")
+    sim = BatchSim(model, n, device_id=local_rank)
+    sim.reset(BASE_SEED + np.arange(n, dtype=np.uint64), 1, 1000.0)
+    nobj = (model.nv - 8) // 6
+    xpos = sim.body_xpos()[:, 8:8 + nobj]
+    acts = np.zeros((warmup + rounds, n, 8))
+    for r in range(warmup + rounds):
+        for e in range(n):
+            objs = xpos[e]
+            inbin = np.where((np.abs(objs[:, 0]) < 0.2) & (np.abs(objs[:, 1] + 0.6) < 0.13) & (objs[:, 2] > 0.85))[0]
+            k = inbin[(e + r) % len(inbin)] if len(inbin) else 0
+            acts[r, e, :3] = [objs[k, 0], objs[k, 1], objs[k, 2] + 0.02]       # 2 cm above the centre: what the depth image gives
+            acts[r, e, 3] = (e + r) % 6
+    actions = torch.from_numpy(acts).to(dev)
+    img = torch.zeros((n, 200, 200, 3), dtype=torch.uint8, device=dev)
+    dep = torch.zeros((n, 200, 200), dtype=torch.float32, device=dev)
+    reward = torch.zeros((warmup + rounds, n), dtype=torch.int32, device=dev)
+    cam = model.camera_name2id("top_down")
+    sim.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def one(r):
+        sim.render_dev(img.data_ptr(), dep.data_ptr(), cam, 200, 200, 1)            # get_observation (GraspingEnv.py:390-406)
+        sim.grasp_attempt_dev(actions[r].data_ptr(), reward[r].data_ptr(), check_mode=0, table_height=0.91)
+    for r in range(warmup):
+        one(r)
+    sim.sync()
+    c0, k0 = sim.counters(), sim.kernel_ms_total()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for r in range(warmup, warmup + rounds):
+        one(r)
+    sim.sync()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    c1, k1 = sim.counters(), sim.kernel_ms_total()
+    steps = int((c1["total_steps"] - c0["total_steps"]).sum())
+    words = model.nq + 2 * model.nv + 5 * model.nu + 8
+    out = {"workload": "configs[3] shape: 40-object piles (UR5gripper_2_finger_many_objects.xml, condim 6), 200x200 RGB-D render + grasp script per round" if many
+           else "configs[2] shape: IT4 (in-tree UR5gripper_2_finger.xml, 3 boxes + 3 spheres), 200x200 RGB-D render + grasp script per round",
+           "scenes": n, "rounds": rounds, "warmup": warmup, "env_steps_per_s": steps / dt, "grasp_attempts_per_s": rounds * n / dt,
+           "grasp_success_rate": float(reward[warmup:].sum().item()) / (rounds * n), "env_steps_per_attempt": steps / (rounds * n),
+           "newton_iters_per_step": float((c1["solver_iters"] - c0["solver_iters"]).sum()) / max(1, steps),
+           "status_bits": int(np.bitwise_or.reduce(c1["status"])), "kernel_ms_per_round": (k1 - k0) / rounds,
+           "roofline_frac": steps * 2 * words * 8 / ((k1 - k0) * 1e-3) / 8e12,
+           "kernel": "ur5m_run_kernel<248>" if many else "ur5_run_kernel<44>"}
+    sim.close()
     return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--envs", type=int, default=None, help="scenes per GPU (default 4096; 2048 for --workload many)")
-    ap.add_argument("--workload", choices=("it1", "it4", "many"), default="it1",
-                    help="it1 = BASELINE.json configs[1] (the headline metric); it4 = configs[2] shape: in-tree 6-object scene, render + in-tree "
-                         "grasp script; many = configs[3] shape: 40-object piles, render + grasp round")
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--envs", type=int, default=None, help="scenes per GPU (default 4096 for --scaling weak, 4096 / gpus for strong)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: 4096 scenes per GPU; strong: 4096 scenes in total, 4096 / N per GPU (SURVEY.md section 8e)")
+    ap.add_argument("--rule", choices=("aimed", "uniform"), default="aimed", help="action rule of the timed rounds (see the module docstring)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the uniform-rule figure and the it4 / many sub-results (N = 1 only)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for 2 ranks on one device)")
     args = ap.parse_args()
 
     import torch
@@ -92,58 +208,56 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_id = local_rank % max(1, ndev)                                            # >1 rank per device only in the single-GPU shard-invariance check
+    torch.cuda.set_device(dev_id)
+    dev = torch.device("cuda", dev_id)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group(args.backend, **({"device_id": dev} if args.backend == "nccl" else {}))
 
-    many, rendered = args.workload == "many", args.workload in ("many", "it4")
-    model = load_model({"many": "/UR5+gripper/UR5gripper_2_finger_many_objects.xml", "it4": "/UR5+gripper/UR5gripper_2_finger.xml",
-                        "it1": "it1_4box"}[args.workload])
-    n_local = args.envs if args.envs else (2048 if many else 4096)
+    model = load_model("it1_4box")
+    n_local = args.envs if args.envs else (4096 if args.scaling == "weak" else 4096 // world)
     n_total = n_local * world
     lo, hi = sharding.shard_range(n_total, rank, world)
-    sim = BatchSim(model, n_local, device_id=local_rank)
-    sim.reset(sharding.global_seeds(20, n_total, rank, world), 1, 1000.0)          # GraspingEnv.py:409-477, untimed
-    settled = sim.get_state()["qpos"]
+    sim = BatchSim(model, n_local, device_id=dev_id)
+    sim.reset(sharding.global_seeds(BASE_SEED, n_total, rank, world), 1, 1000.0)    # episode 0 of every scene (GraspingEnv.py:409-477), untimed
+    sim.set_stream(torch.cuda.current_stream().cuda_stream)
     rounds = args.warmup + args.steps
-    if rendered:
-        xpos = sim.body_xpos()[:, 8:8 + (model.nv - 8) // 6]
-        actions = torch.from_numpy(np.stack([aimed_actions_rendered(xpos, lo, r) for r in range(rounds)])).to(dev)
-    else:
-        actions = torch.from_numpy(np.stack([aimed_actions(settled, lo, r) for r in range(rounds)])).to(dev)   # [rounds, n, 8] f64 in HBM
-    if rendered:                                                                  # the observation of every round stays on the device
-        img = torch.zeros((n_local, 200, 200, 3), dtype=torch.uint8, device=dev)
-        dep = torch.zeros((n_local, 200, 200), dtype=torch.float32, device=dev)
-        cam = model.camera_name2id("top_down")
     reward = torch.zeros((rounds, n_local), dtype=torch.int32, device=dev)
     ids = torch.arange(lo, hi, dtype=torch.int32, device=dev)
 
-    def one_round(r):
-        if rendered:
-            sim.render_dev(img.data_ptr(), dep.data_ptr(), cam, 200, 200, 1)       # get_observation (GraspingEnv.py:390-406), same stream
-        sim.grasp_attempt_dev(actions[r].data_ptr(), reward[r].data_ptr(), check_mode=0 if rendered else 1, table_height=0.91)
-        sim.sync()                                                             # handle stream -> host; rewards now valid
-        rec = torch.stack([ids, torch.zeros_like(ids), actions[r, :, 3].to(torch.int32), reward[r]], dim=1)
-        return sharding.gather_outcomes(rec), sim.last_launch_ms()
+    def run_rounds(wl, r0, r1, reward):
+        for r in range(r0, r1):
+            flags, seeds = wl.reset_flags(r)
+            sim.reset_dev(seeds.data_ptr(), flags.data_ptr(), 1000.0)              # reset_model of the scenes starting an episode, then their settle
+            act, pixel = wl.actions(r)                                             # stream-ordered after the settle launch
+            sim.grasp_attempt_dev(act.data_ptr(), reward[r].data_ptr(), check_mode=1, table_height=0.91)
+            rec = torch.stack([ids, pixel, act[:, 3].to(torch.int32), reward[r]], dim=1)
+            gathered = sharding.gather_outcomes(rec)                               # the path's only collective: 16 B per scene per round
+        return gathered
 
-    for r in range(args.warmup):
-        one_round(r)
-    c0 = sim.counters()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    kernel_ms = []
-    for r in range(args.warmup, rounds):
-        _, ms = one_round(r)
-        kernel_ms.append(ms)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    c1 = sim.counters()
+    def timed(wl, r0, r1, reward):
+        sim.sync()
+        c0, k0 = sim.counters(), sim.kernel_ms_total()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        g = run_rounds(wl, r0, r1, reward)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        sim.sync()                                                                 # resolves the HIP event pairs of the region's launches
+        c1, k1 = sim.counters(), sim.kernel_ms_total()
+        return elapsed, c0, c1, k1 - k0, g
+
+    wl = It1Rounds(torch, model, sim, dev, lo, n_local, n_total, args.rule)
+    run_rounds(wl, 0, args.warmup, reward)
+    elapsed, c0, c1, kernel_ms, gathered = timed(wl, args.warmup, rounds, reward)
+    assert gathered.shape == (n_total, 4)
     steps_local = int((c1["total_steps"] - c0["total_steps"]).sum())
+    per_round = reward[args.warmup:].double().mean(dim=1)
     stats = torch.tensor([elapsed, float(steps_local), float(reward[args.warmup:].sum().item())], dtype=torch.float64, device=dev)
     if world > 1:
         tmax = stats[:1].clone()
@@ -158,42 +272,60 @@ def main():
         # algorithmic HBM bytes per env-step: (nq + 2 nv + 5 nu + 8) words, read + written, fp64
         words = model.nq + 2 * model.nv + 5 * model.nu + 8
         bytes_per_step = 2 * words * 8
-        k_s = sum(kernel_ms) * 1e-3
-        achieved = steps_local * bytes_per_step / k_s / 1e9
-        # measured HBM bytes per env-step from the rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this same command (profiles/)
-        traffic, traffic_src = None, None
-        tp = os.path.join(ROOT, "profiles", "r01_k_hbm_traffic.json")
-        if os.path.exists(tp) and not rendered:
+        achieved = steps_local * bytes_per_step / (kernel_ms * 1e-3) / 1e9
+        traffic, traffic_src = None, "not measured in this run (PMC passes are separate rocprofv3 runs)"
+        tp = os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")
+        if os.path.exists(tp):
             with open(tp) as f:
                 tj = json.load(f)
             traffic = tj["hbm_bytes_per_env_step"] * steps_local / args.steps
-            traffic_src = "profiles/r01_k_hbm_traffic.json: (FETCH_SIZE + WRITE_SIZE) per env-step x env-steps of an average timed launch"
+            traffic_src = (f"from profiles/ ({tj.get('source', 'hbm_traffic_latest.json')}), NOT measured in this run: (FETCH_SIZE + WRITE_SIZE) per "
+                           "env-step of the rocprofv3 PMC passes of this command x env-steps of an average timed round")
         out = {
-            "metric": f"env-steps/sec (+ grasp-attempts/sec), {n_local} parallel UR5 scenes per MI355X",
+            "metric": f"env-steps/sec (+ grasp-attempts/sec), {n_total} parallel UR5 scenes on {world} MI355X",
             "value": steps_all / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "grasp_attempts_per_s": attempts / elapsed, "grasp_success_rate": succ_all / attempts,
+            "grasp_success_rate_per_round_rank0": [round(float(x), 4) for x in per_round.tolist()],
             "env_steps_per_attempt": steps_all / attempts,
             "newton_iters_per_step": float((c1["solver_iters"] - c0["solver_iters"]).sum()) / max(1, steps_local),
             "status_bits": int(np.bitwise_or.reduce(c1["status"])),
-            "config": {"workload": ("BASELINE.json configs[3] shape: IT5 many-object piles (UR5gripper_2_finger_many_objects.xml, 40 objects, "
-                                    "condim 6), 200x200 RGB-D render + multi-discrete rotation action + in-tree grasp script per step") if many else
-                                   ("BASELINE.json configs[2] shape: IT4 (in-tree UR5gripper_2_finger.xml, 3 boxes + 3 spheres), 200x200 RGB-D render + "
-                                    "grasp height from the object top + in-tree grasp script (closing check at the drop position) per step") if rendered else
-                                   ("BASELINE.json configs[1]: IT1 (UR5gripper_2_finger.xml robot + bins, 4 equal 4 cm boxes), physics only, "
-                                    "fixed z = 0.91, lift + 500-step closing check, one grasp-attempt round per step"),
-                       "scenes_per_gpu": n_local, "scenes_total": n_total, "solver": "Newton (MuJoCo default), tol 1e-10",
-                       "timestep_s": model.opt["timestep"], "parallelism": f"scenes sharded x{world}, 1 all_gather of 16 B outcome records per round"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "ur5m_run_kernel<248>" if many else ("ur5_run_kernel<44>" if rendered else "ur5_run_kernel<32>"), "bytes_per_env_step": bytes_per_step,
-                         "avg_launch_ms": float(np.mean(kernel_ms)), "env_steps_per_launch": steps_local / args.steps,
-                         "note": "algorithmic state bytes x env-steps / HIP-event kernel time on the handle's stream (rank 0). The kernel keeps a "
-                                 "scene in LDS for a whole grasp attempt, so real HBM traffic is far below the algorithmic figure; the step is "
-                                 "latency/VALU bound (DESIGN.md)"},
+            "config": {"workload": "BASELINE.json configs[1]: IT1 (UR5gripper_2_finger.xml robot + bins, 4 equal 4 cm boxes), physics only, fixed "
+                                   "z = 0.91, lift + 500-step closing check; one grasp-attempt round per step, episodes of 4 rounds with reset_model "
+                                   "(+ 1000 ms settle) for the quarter of the batch that starts an episode in the round",
+                       "rule": ("aimed: current position of a box still on the pick plate, read from the state records on the device" if args.rule == "aimed"
+                                else "uniform: uniformly drawn table pixel, rotation 0 (SURVEY.md 8d / Grasping_Agent_multidiscrete.py:266-280)"),
+                       "scenes_per_gpu": n_local, "scenes_total": n_total, "solver": "Newton (MuJoCo default; north_star says PGS, see DESIGN.md D1), "
+                       f"tolerance 1e-10, iteration cap {model.opt['iterations']}", "timestep_s": model.opt["timestep"],
+                       "parallelism": f"scenes sharded x{world}, 1 all_gather of 16 B outcome records per round"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
+                         "traffic_source": traffic_src, "kernel": "ur5_run_kernel<32>", "bytes_per_env_step": bytes_per_step,
+                         "kernel_ms_per_round": kernel_ms / args.steps, "env_steps_per_round": steps_local / args.steps,
+                         "note": "algorithmic state bytes x env-steps / summed HIP-event time of the engine kernels of the timed rounds (settle + "
+                                 "grasp launches, rank 0). A scene stays in LDS for a whole launch, so the algorithmic figure is an accounting "
+                                 "unit, not the traffic: the step is latency / VALU-issue bound (DESIGN.md section 3)"},
         }
+        if world == 1 and not args.no_extras:
+            # second figure: SURVEY.md 8d's own action rule, same episode structure, a few rounds continuing from the current state
+            wl_u = It1Rounds(torch, model, sim, dev, lo, n_local, n_total, "uniform")
+            ur = max(2, min(4, args.steps))
+            rew_u = torch.zeros((rounds + 1 + ur, n_local), dtype=torch.int32, device=dev)
+            run_rounds(wl_u, rounds, rounds + 1, rew_u)
+            e_u, cu0, cu1, k_u, _ = timed(wl_u, rounds + 1, rounds + 1 + ur, rew_u)
+            st_u = int((cu1["total_steps"] - cu0["total_steps"]).sum())
+            out["uniform_rule"] = {"rounds": ur, "env_steps_per_s": st_u / e_u, "grasp_attempts_per_s": ur * n_local / e_u,
+                                   "grasp_success_rate": float(rew_u[rounds + 1:].sum().item()) / (ur * n_local),
+                                   "env_steps_per_attempt": st_u / (ur * n_local),
+                                   "rule": "uniformly drawn table pixel, rotation 0, z = 0.91 (SURVEY.md section 8d config 2)"}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(model, many=many)
+            out["cpu_baseline"] = cpu_baseline(model)
+    sim.close()
+    if rank == 0 and world == 1 and not args.no_extras:
+        torch.cuda.synchronize()
+        out["it4"] = rendered_sub_result(torch, dev, dev_id, "it4", 4096, 2, 1)
+        out["many"] = rendered_sub_result(torch, dev, dev_id, "many", 512, 2, 1)
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

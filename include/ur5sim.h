@@ -79,6 +79,10 @@ int ur5_grasp_attempt(ur5_sim* h, const double* action, const uint8_t* skip, int
    skip != 0: the scene sits the launch out with reward 0 -- GraspEnv.step's rule for targets off the table (GraspingEnv.py:124-131) */
 int ur5_grasp_attempt_dev(ur5_sim* h, const double* action_dev, int check_mode, double table_height, int* reward_dev);
 int ur5_sync(ur5_sim* h);
+/* Queue the handle's launches on a caller-owned HIP stream (hipStream_t, e.g. torch.cuda.current_stream().cuda_stream) so that the
+   caller's own device work (action tensors, the CNN) is ordered with them without host synchronisation. external = 1: use hip_stream
+   as given (NULL is the device's default stream -- which is what torch's default stream is); external = 0: back to the private stream. */
+int ur5_set_stream(ur5_sim* h, void* hip_stream, int external);
 /* duration of the last launch in ms, from HIP events recorded on the handle's stream around the kernel */
 double ur5_last_launch_ms(ur5_sim* h);
 /* engine-kernel time (ms) of every launch since ur5_create whose events a ur5_sync has resolved: callers difference it around a region */

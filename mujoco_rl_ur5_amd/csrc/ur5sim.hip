@@ -71,7 +71,8 @@ __global__ void __launch_bounds__(64) ur5_reset_kernel(double* __restrict__ rec,
 // Every launch is bracketed by its own pair of HIP events on the handle's stream; ur5_sync resolves the pairs recorded since
 // the previous sync (several launches may be queued: reset + settle + render + grasp attempt of one round).
 struct HipBackend {
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;    // the stream launches go to: `own` or a caller-owned one (ur5_set_stream)
+  hipStream_t own = nullptr;
   std::vector<hipEvent_t> ev;      // pool: pairs [2k, 2k+1]
   int pending = 0;                 // pairs recorded since the last sync
 };
@@ -108,7 +109,8 @@ static int be_open(ur5_sim* h, int device_id) {
   HIPCHK(hipSetDevice(device_id));
   HipBackend* b = new HipBackend();
   h->be = b;
-  HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&b->own, hipStreamNonBlocking));
+  b->stream = b->own;
   return 0;
 }
 static void be_close(ur5_sim* h) {
@@ -118,9 +120,17 @@ static void be_close(ur5_sim* h) {
   (void)hipSetDevice(h->device);
   if (b->stream) (void)hipStreamSynchronize(b->stream);
   for (hipEvent_t e : b->ev) (void)hipEventDestroy(e);
-  if (b->stream) (void)hipStreamDestroy(b->stream);
+  if (b->own) (void)hipStreamDestroy(b->own);
   delete b;
   h->be = nullptr;
+}
+static int be_set_stream(ur5_sim* h, void* stream, int external) {
+  HipBackend* b = (HipBackend*)h->be;
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(b->stream));   // nothing of ours may still be queued on the stream we leave
+  be_resolve(h, b);
+  b->stream = external ? (hipStream_t)stream : b->own;   // external NULL = the device's default stream (torch's default)
+  return 0;
 }
 static void* be_alloc(ur5_sim* h, size_t bytes) {
   void* p = nullptr;

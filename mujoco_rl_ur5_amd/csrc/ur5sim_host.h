@@ -467,6 +467,7 @@ static int be_h2d(ur5_sim* h, void* dst, const void* src, size_t bytes);
 static int be_d2h(ur5_sim* h, void* dst, const void* src, size_t bytes);
 static int be_launch(ur5_sim* h, const Ur5Launch& P);
 static int be_sync(ur5_sim* h);
+static int be_set_stream(ur5_sim* h, void* stream, int external);
 static int be_render(ur5_sim* h, int cam, int W, int Hh, int mode, uint8_t* rgb_dev, float* depth_dev);
 static int be_reset_dev(ur5_sim* h, const uint64_t* seeds_dev, const uint8_t* mask_dev, int chunks, int* max_steps_dev);
 
@@ -514,7 +515,7 @@ int ur5m_grasp_attempt(ur5_sim* h, const double* action, const uint8_t* skip, in
 int ur5m_ik(ur5_sim* h, const double* xyz, double* q5, int* result);
 int ur5m_render_dev(ur5_sim* h, int camera_id, int width, int height, int depth_mode, uint8_t* rgb_dev, float* depth_dev);
 int ur5m_render(ur5_sim* h, int camera_id, int width, int height, int depth_mode, uint8_t* rgb, float* depth);
-int ur5m_sync(ur5_sim* h); double ur5m_last_launch_ms(ur5_sim* h); void* ur5m_state_device_ptr(ur5_sim* h);
+int ur5m_sync(ur5_sim* h); int ur5m_set_stream(ur5_sim* h, void* s, int external); double ur5m_last_launch_ms(ur5_sim* h); void* ur5m_state_device_ptr(ur5_sim* h);
 int ur5m_forward_debug(ur5_sim* h, double* out); int ur5m_body_xpos(ur5_sim* h, double* out); int ur5m_profile_read(ur5_sim* h, double* out);
 }
 #endif
@@ -824,6 +825,8 @@ int ur5_render(ur5_sim* h, int camera_id, int width, int height, int depth_mode,
 }
 int ur5_sync(ur5_sim* h) {
   UR5_FWD(sync, (h)); return be_sync(h); }
+int ur5_set_stream(ur5_sim* h, void* hip_stream, int external) {
+  UR5_FWD(set_stream, (h, hip_stream, external)); return be_set_stream(h, hip_stream, external); }
 double ur5_last_launch_ms(ur5_sim* h) {
   UR5_FWD(last_launch_ms, (h)); return h->last_ms; }
 double ur5_kernel_ms_total(ur5_sim* h) {

@@ -19,7 +19,7 @@ RES_NONE, RES_SUCCESS, RES_MAX_STEPS, RES_IK_FAIL = -1, 0, 1, 2
 _VARIANT = {0: (6, 2048, 192, 30), 1: (40, 4096, 832, 160)}
 EXPORTS = ["ur5_last_error", "ur5_create", "ur5_destroy", "ur5_num_envs", "ur5_nq", "ur5_nv", "ur5_nu", "ur5_reset", "ur5_reset_dev", "ur5_kernel_ms_total",
            "ur5_set_state", "ur5_get_state", "ur5_set_ctrl", "ur5_get_ctrl", "ur5_step", "ur5_move_group", "ur5_stay",
-           "ur5_move_ee", "ur5_ik", "ur5_grasp_attempt", "ur5_grasp_attempt_dev", "ur5_sync", "ur5_last_launch_ms",
+           "ur5_move_ee", "ur5_ik", "ur5_grasp_attempt", "ur5_grasp_attempt_dev", "ur5_sync", "ur5_set_stream", "ur5_last_launch_ms",
            "ur5_get_counters", "ur5_body_xpos", "ur5_render", "ur5_render_dev", "ur5_state_device_ptr", "ur5_forward_debug"]
 
 
@@ -31,7 +31,8 @@ _libs = {}
 
 
 def load(path=None):
-    path = path or DEFAULT_LIB
+    # UR5SIM_LIB: A/B builds of the SAME HIP engine (tools/, kernel experiments); never a CPU build -- ur5_create still needs the GPU
+    path = path or os.environ.get("UR5SIM_LIB") or DEFAULT_LIB
     if path in _libs:
         return _libs[path]
     if not os.path.exists(path):
@@ -46,6 +47,7 @@ def load(path=None):
     for f in ("ur5_num_envs", "ur5_nq", "ur5_nv", "ur5_nu", "ur5_sync"):
         getattr(L, f).argtypes = [vp]
     L.ur5_reset.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int, C.c_double]
+    L.ur5_set_stream.argtypes = [vp, vp, C.c_int]
     L.ur5_reset_dev.argtypes = [vp, vp, vp, C.c_double]
     L.ur5_kernel_ms_total.argtypes = [vp]
     L.ur5_kernel_ms_total.restype = C.c_double
@@ -212,6 +214,14 @@ class BatchSim:
 
     def sync(self):
         self._check(self.lib.ur5_sync(self._h), "ur5_sync")
+
+    def set_stream(self, hip_stream):
+        """Run on a caller-owned HIP stream given as an int handle, e.g. torch.cuda.current_stream().cuda_stream (0 = the default
+        stream, which is torch's default); None = back to the handle's private stream."""
+        if hip_stream is None:
+            self._check(self.lib.ur5_set_stream(self._h, None, 0), "ur5_set_stream")
+        else:
+            self._check(self.lib.ur5_set_stream(self._h, C.c_void_p(int(hip_stream)) if hip_stream else None, 1), "ur5_set_stream")
 
     def last_launch_ms(self):
         return float(self.lib.ur5_last_launch_ms(self._h))

@@ -41,6 +41,10 @@ def gather_outcomes(records, device=None):
         t = t.to(device)
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return t.clone()
+    if dist.get_backend() != "nccl" and t.is_cuda:   # gloo (CPU tests, several ranks on one GPU): gather through host memory
+        parts = [torch.empty(t.shape, dtype=t.dtype) for _ in range(dist.get_world_size())]
+        dist.all_gather(parts, t.cpu().contiguous())
+        return torch.cat(parts).to(t.device)
     out = torch.empty((dist.get_world_size() * t.shape[0], t.shape[1]), dtype=t.dtype, device=t.device)
     dist.all_gather_into_tensor(out, t.contiguous())
     return out

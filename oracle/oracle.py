@@ -68,20 +68,22 @@ def lib():
         L.ur5o_get_rows.argtypes = [vp, dp]
         L.ur5o_render.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_ubyte), C.POINTER(C.c_float)]
         L.ur5o_batch.restype = C.c_long
-        L.ur5o_batch.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_long), C.POINTER(C.c_double)]
+        L.ur5o_batch.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_long), C.POINTER(C.c_double),
+                                 C.POINTER(C.c_long), C.POINTER(C.c_long)]
         _LIB = L
     return _LIB
 
 
 def batch(model, nthreads, budget_s, mode=0, nsteps=100):
     """bench.py's CPU baseline: `nthreads` native threads, one scene each at a time, for `budget_s` seconds of wall time
-    (mode 0 = IT1 reset + aimed grasp attempt per scene, mode 1 = the first `nsteps` steps of the many-object drop).
-    Returns (physics steps, scenes completed, wall seconds)."""
+    (mode 0 = IT1 reset + one aimed grasp attempt per scene, mode 1 = the first `nsteps` steps of the many-object drop,
+    mode 2 = bench.py's stationary IT1 workload: episodes of reset + settle + `nsteps` aimed attempts).
+    Returns (physics steps, scenes completed, wall seconds, grasp attempts, successes)."""
     blob = model.to_blob()
-    scenes, wall = C.c_long(0), C.c_double(0)
+    scenes, wall, att, suc = C.c_long(0), C.c_double(0), C.c_long(0), C.c_long(0)
     steps = lib().ur5o_batch(blob, len(blob), model.body_name2id("ee_link"), model.body_name2id("base_link"), int(nthreads), float(budget_s),
-                             int(mode), int(nsteps), C.byref(scenes), C.byref(wall))
-    return int(steps), int(scenes.value), float(wall.value)
+                             int(mode), int(nsteps), C.byref(scenes), C.byref(wall), C.byref(att), C.byref(suc))
+    return int(steps), int(scenes.value), float(wall.value), int(att.value), int(suc.value)
 
 
 def _dp(a):

@@ -1763,9 +1763,24 @@ int ur5o_close_gripper(void* h, int max_steps) { return ((Sim*)h)->close_gripper
 // mode 0: IT1 round of scene g = reset(seed 20 + g, settle) + one grasp attempt aimed at object g % 4 (z = 0.91, check_mode 1),
 // i.e. exactly bench.py's aimed_actions(); mode 1: the first `nsteps` steps of the many-object drop of scene g. Returns the
 // physics steps executed by all threads; *scenes_out = scenes completed; *wall_out = seconds.
+// bench.py's "aimed" workload rule (bench.py aim_targets does the same on the device): scene g, round j of its episode aims at the first of
+// boxes (g + j + i) % nobj, i = 0.., that still lies on the pick plate, z = 0.91; an empty plate gets an attempt at its centre.
+static void bench_aim(const Sim& s, int g, int j, double* xyz) {
+  int objs[16], nobj = 0;
+  for (int b = 1; b < s.M.nbody && nobj < 16; b++)
+    if (s.M.body_parentid[b] == 0 && s.M.body_jntnum[b] == 4 && s.M.jnt_type[s.M.body_jntadr[b]] == JNT_SLIDE) objs[nobj++] = b;
+  xyz[0] = 0; xyz[1] = -0.6; xyz[2] = 0.91;
+  for (int i = 0; i < nobj; i++) {
+    const int b = objs[(g + j + i) % nobj], qa = s.M.jnt_qposadr[s.M.body_jntadr[b]];
+    const double x = s.M.body_pos[3 * b] + s.qpos[qa], y = s.M.body_pos[3 * b + 1] + s.qpos[qa + 1], z = s.M.body_pos[3 * b + 2] + s.qpos[qa + 2];
+    if (std::fabs(x) <= 0.27 && std::fabs(y + 0.6) <= 0.19 && z >= 0.905 && z <= 1.0) { xyz[0] = x; xyz[1] = y; return; }
+  }
+}
+// mode 0: reset + settle + ONE aimed attempt per scene (round-1 sample, kept for comparison); mode 1: reset + nsteps raw steps (many-object drop);
+// mode 2: bench.py's stationary IT1 workload -- whole episodes of reset + settle + `nsteps` aimed attempts (bench_aim) per scene.
 long ur5o_batch(const void* blob, size_t nbytes, int ee_body, int base_body, int nthreads, double budget_s, int mode, int nsteps,
-                long* scenes_out, double* wall_out) {
-  std::atomic<long> steps{0}, scenes{0};
+                long* scenes_out, double* wall_out, long* attempts_out, long* success_out) {
+  std::atomic<long> steps{0}, scenes{0}, attempts{0}, success{0};
   std::atomic<int> next{0};
   auto t0 = std::chrono::steady_clock::now();
   auto elapsed = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
@@ -1781,7 +1796,17 @@ long ur5o_batch(const void* blob, size_t nbytes, int ee_body, int base_body, int
         int nobj = (s.nq - 8) / 7, k = g % (nobj < 4 ? nobj : 4);
         double xyz[3] = {s.qpos[8 + 7 * k], -0.6 + s.qpos[8 + 7 * k + 1], 0.91};
         int ps[12], pr[12];
-        s.grasp_attempt(xyz, (g / 4) % 6, 1, 0.91, ps, pr);
+        success += s.grasp_attempt(xyz, (g / 4) % 6, 1, 0.91, ps, pr);
+        attempts++;
+      } else if (mode == 2) {
+        s.reset(20 + (uint64_t)g, 1, 1);
+        for (int j = 0; j < nsteps; j++) {
+          double xyz[3];
+          bench_aim(s, g, j, xyz);
+          int ps[12], pr[12];
+          success += s.grasp_attempt(xyz, (g / 4 + j) % 6, 1, 0.91, ps, pr);
+          attempts++;
+        }
       } else {
         s.reset(20 + (uint64_t)g, 1, 0);
         for (int i = 0; i < nsteps; i++) s.step();
@@ -1795,6 +1820,8 @@ long ur5o_batch(const void* blob, size_t nbytes, int ee_body, int base_body, int
   for (auto& t : th) t.join();
   if (scenes_out) *scenes_out = scenes.load();
   if (wall_out) *wall_out = elapsed();
+  if (attempts_out) *attempts_out = attempts.load();
+  if (success_out) *success_out = success.load();
   return steps.load();
 }
 int ur5o_grasp_attempt(void* h, const double* xyz, int rot, int check_mode, double table_height, int* phase_steps, int* phase_result) {

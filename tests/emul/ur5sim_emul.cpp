@@ -15,6 +15,7 @@ static void be_free(ur5_sim*, void* p) { free(p); }
 static int be_h2d(ur5_sim*, void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); return 0; }
 static int be_d2h(ur5_sim*, void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); return 0; }
 static int be_sync(ur5_sim*) { return 0; }
+static int be_set_stream(ur5_sim*, void*, int) { return 0; }
 static int be_reset_dev(ur5_sim* h, const uint64_t* seeds, const uint8_t* mask, int chunks, int* max_steps) {
   for (int e = 0; e < h->n; e++) {
     const bool on = !mask || mask[e];
