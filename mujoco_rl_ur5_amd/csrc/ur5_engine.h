@@ -50,6 +50,7 @@ static const Ur5DevModel* ur5_emul_model = nullptr;
 #define WAVE_SUM(v) (v)
 #define WAVE_MAX(v) (v)
 #define UR5_LANE 0
+#define UR5_GBASE 0
 #else
 #include <hip/hip_runtime.h>
 #define UR5_FN __device__ __forceinline__
@@ -64,19 +65,13 @@ static const Ur5DevModel* ur5_emul_model = nullptr;
 // hungry ones are real functions: each then gets its own register allocation instead of sharing one 50 k-instruction
 // function body with every other phase, which cuts the spill traffic (+30 % env-steps/s measured, same-box A/B of the
 // inline/noinline combinations); the rest stay inlined. The many-object kernel has 512 registers per lane and inlines all.
-#ifndef UR5_MANY
-#define UR5_PHASE_A UR5_CALL   // collision
-#define UR5_PHASE_B UR5_CALL   // make_constraints
-#define UR5_PHASE_C UR5_CALL   // solve_newton
-#define UR5_PHASE_D UR5_CALL   // kinematics
-#define UR5_PHASE_H UR5_CALL   // newton_direction
-#else
-#define UR5_PHASE_A UR5_BIG
-#define UR5_PHASE_B UR5_BIG
-#define UR5_PHASE_C UR5_BIG
-#define UR5_PHASE_D UR5_BIG
-#define UR5_PHASE_H UR5_BIG
-#endif
+// (Engine::FLAT decides per instantiation: the bodies below are always inlinable, each has a real-function wrapper next to it.) The kernels
+// that own all 512 registers of a lane -- two scenes per wavefront, and the many-object kernel -- inline everything.
+#define UR5_PHASE_A UR5_BIG   // collision
+#define UR5_PHASE_B UR5_BIG   // make_constraints
+#define UR5_PHASE_C UR5_BIG   // solve_newton
+#define UR5_PHASE_D UR5_BIG   // kinematics
+#define UR5_PHASE_H UR5_BIG   // newton_direction
 #define UR5_PHASE_E UR5_BIG    // crb_and_factor, velocity_stage, integrate: they share the register-resident robot factors
 #define UR5_PHASE_F UR5_BIG
 #define UR5_PHASE_G UR5_BIG
@@ -90,11 +85,17 @@ static const Ur5DevModel* ur5_emul_model = nullptr;
 // every (non-inlined) phase routine addresses them with ds_* / s_load instead of flat instructions.
 extern __shared__ __attribute__((aligned(16))) double ur5_smem[];
 __constant__ Ur5DevModel ur5_cmodel;
-#define UR5_LDS_PTR(T) (reinterpret_cast<T*>(ur5_smem))
+// A scene is owned by a GROUP of GS lanes (Engine<real, NV, GS>): GS = 64 is one wavefront per scene, GS = 32 packs two scenes into a
+// wavefront (64 / GS scenes per 64-thread workgroup, each with its own Lds image), GS = UR5_NT = 256 is the many-object variant.
+// UR5_LANE is the lane's index inside its group, UR5_GBASE the workgroup thread index of the group's first lane. Everything that is
+// "wave-uniform" in the one-scene-per-wave layout is group-uniform here; the compiler masks the lanes of a scene whose control flow
+// differs from its wave neighbour's (scenes never exchange data, so the only cost of divergence is the idle half-wave).
+#define UR5_LDS_PTR(T) (reinterpret_cast<T*>(ur5_smem) + (GS == UR5_NT ? 0 : (int)threadIdx.x / GS))
 #define UR5_MODEL ur5_cmodel
-#define PAR(i, n) for (int i = (int)threadIdx.x; i < (n); i += UR5_NT)
+#define PAR(i, n) for (int i = UR5_LANE; i < (n); i += GS)
 #define SYNC() __syncthreads()
-#define UR5_LANE ((int)threadIdx.x)
+#define UR5_LANE ((int)threadIdx.x & (GS - 1))
+#define UR5_GBASE ((int)threadIdx.x & ~(GS - 1))
 // Wave-wide sum / max with DPP (data-parallel primitives: the adder reads a neighbour lane's register directly) instead of
 // __shfl_xor, which goes through the LDS crossbar (ds_bpermute) six times per value: quad swaps, row mirrors, then the two
 // row broadcasts of GFX9 leave the total in lane 63, which v_readlane hands to every lane.
@@ -118,33 +119,58 @@ template <class T> __device__ __forceinline__ T ur5_wave_sum(T v0) {
   v += ur5_dpp<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3: lane 63 = total
   return (T)ur5_lane63(v);
 }
-template <class T> __device__ __forceinline__ T ur5_wave_max(T v) {
+// the same for a 32-lane group (two scenes per wavefront): the four in-row steps, then v_permlane16_swap (gfx950) exchanges row 1 of one
+// copy with row 0 of the other (rows 3 / 2 likewise), so copy + copy = the sum of the group's two rows in each of its lanes
+template <class T> __device__ __forceinline__ T ur5_half_sum(T v0) {
+  double v = (double)v0;
+  v += ur5_dpp<0xb1, 0xf>(v);
+  v += ur5_dpp<0x4e, 0xf>(v);
+  v += ur5_dpp<0x141, 0xf>(v);
+  v += ur5_dpp<0x140, 0xf>(v);
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return (T)(__hiloint2double(rh[0], rl[0]) + __hiloint2double(rh[1], rl[1]));
+}
+template <int W, class T> __device__ __forceinline__ T ur5_wave_max(T v) {   // max over aligned groups of W lanes
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { T w = __shfl_xor(v, o, 64); v = w > v ? w : v; }
+  for (int o = W / 2; o > 0; o >>= 1) { T w = __shfl_xor(v, o, 64); v = w > v ? w : v; }
   return v;
 }
-#if UR5_NT == 64
-#define WAVE_SUM(v) ur5_wave_sum(v)
-#define WAVE_MAX(v) ur5_wave_max(v)
-#else   // several wavefronts per scene: Engine::block_sum / block_max combine the wave results through LDS in a fixed order
-#define WAVE_SUM(v) block_sum(v)
-#define WAVE_MAX(v) block_max(v)
-#endif
+// sums / maxima over the lanes of a scene: one wavefront (GS = 64), half of one (GS = 32) or several (Engine::block_sum / block_max
+// combine the per-wave results through LDS in a fixed order)
+#define WAVE_SUM(v) group_sum(v)
+#define WAVE_MAX(v) group_max(v)
 #endif
 
 // optional per-phase cycle accounting (-DUR5_PROFILE builds libur5sim_prof.so; never defined for the product library)
 #if defined(UR5_PROFILE) && !defined(UR5_EMUL)
 #define PROF_T0() unsigned long long prof_t_ = __builtin_readcyclecounter()
 #define PROF_RE() prof_t_ = __builtin_readcyclecounter()
-#define PROF(id) do { unsigned long long n_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) S.prof[id] += (double)(n_ - prof_t_); prof_t_ = n_; } while (0)
+#define PROF(id) do { unsigned long long n_ = __builtin_readcyclecounter(); if (UR5_LANE == 0) S.prof[id] += (double)(n_ - prof_t_); prof_t_ = n_; } while (0)
 #else
 #define PROF_T0() ((void)0)
 #define PROF_RE() ((void)0)
 #define PROF(id) ((void)0)
 #endif
 enum { PF_KIN = 0, PF_CRB, PF_VEL, PF_BROAD, PF_NARROW, PF_ROWS, PF_NEWTON_INIT, PF_IMAGES, PF_LINESEARCH, PF_GRADG, PF_HASM, PF_CHOL, PF_SOLVE,
-       PF_INTEGRATE, PF_PID, PF_IK, PF_COUNT };
+       PF_INTEGRATE, PF_PID, PF_IK, PF_CORECLK, PF_REALCLK, PF_COUNT };   // the last two: start / end of the scene's wave in 100 MHz ticks (s_memrealtime)
 
+#ifndef UR5_INL_POW
+#define UR5_INL_POW 1
+#endif
+#ifndef UR5_INL_IMAGES
+#define UR5_INL_IMAGES 1
+#endif
+#ifndef UR5_INL_MATVEC
+#define UR5_INL_MATVEC 1
+#endif
+#ifndef UR5_INL_COST
+#define UR5_INL_COST 1
+#endif
+#ifndef UR5_INL_DUMP
+#define UR5_INL_DUMP 0   // the introspection dump (FORWARD op only) stays a real function: inlined into the flat kernel it made the kernel fault (gfx950, ROCm 7.2)
+#endif
 namespace ur5 {
 
 enum { RES_NONE = -1, RES_SUCCESS = 0, RES_MAX_STEPS = 1, RES_IK_FAIL = 2 };
@@ -307,7 +333,16 @@ template <class real, int NV_> struct Lds {
 };
 
 // ---------------------------------------------------------------------------------------------- the engine
-template <class real, int NV_> struct Engine {
+template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
+  static constexpr int GS = GS_;   // lanes that own one scene
+  // The register-hungry phases (kinematics, collision, constraint rows, Newton solve / direction) are real functions in the one-scene-per-
+  // wavefront kernel (256-register cap, 2 waves per SIMD): each then gets its own register allocation instead of sharing one 50 k-instruction
+  // body (+30 % measured in round 1). FLAT kernels have the whole register file and inline them.
+#ifdef UR5_EMUL
+  static constexpr bool FLAT = true;
+#else
+  static constexpr bool FLAT = GS_ != 64;
+#endif
   typedef Lds<real, NV_> L;
   typedef V3<real> v3;
   typedef M3<real> m3;
@@ -328,7 +363,13 @@ template <class real, int NV_> struct Engine {
   UR5_FN int nslot() const { return M.nrg + M.nobj; }
   UR5_FN int slot_of(int b) const { return b < M.nrd ? M.rd_gslot[b] : M.nrg + (b - M.nrd); }
   UR5_FN int body_of_slot(int sl) const { return sl < M.nrg ? M.rg_body[sl] : M.nrd + (sl - M.nrg); }
-#if !defined(UR5_EMUL) && UR5_NT > 64
+#if !defined(UR5_EMUL)
+  UR5_FN real group_sum(real v) {
+    if constexpr (GS == 64) return ur5_wave_sum(v); else if constexpr (GS == 32) return ur5_half_sum(v); else return block_sum(v);
+  }
+  UR5_FN real group_max(real v) {
+    if constexpr (GS == 64) return ur5_wave_max<64>(v); else if constexpr (GS == 32) return ur5_wave_max<32>(v); else return block_max(v);
+  }
   // sums / maxima over all wavefronts of the scene: wave shuffle, then the per-wave results through LDS in wave order
   UR5_FN real block_sum(real v) {
     v = ur5_wave_sum(v);
@@ -351,7 +392,7 @@ template <class real, int NV_> struct Engine {
     a = ta; b = tb; c = tc;
   }
   UR5_FN real block_max(real v) {
-    v = ur5_wave_max(v);
+    v = ur5_wave_max<64>(v);
     SYNC();
     if ((UR5_LANE & 63) == 0) S.red[UR5_LANE >> 6] = v;
     SYNC();
@@ -370,7 +411,7 @@ template <class real, int NV_> struct Engine {
     if (UR5_LANE == 0) { S.nskip = 0; S.act_changed = 1; }
 #endif
 #if defined(UR5_PROFILE) && !defined(UR5_EMUL)
-    if (UR5_LANE == 0) for (int i = 0; i < PF_COUNT; i++) S.prof[i] = 0;
+    if (UR5_LANE == 0) { for (int i = 0; i < PF_COUNT; i++) S.prof[i] = 0; S.prof[PF_CORECLK] = (double)wall_clock64(); }
 #endif
     SYNC();
     S.status = (int)S.rec[UR5_REC_MISC + 3];
@@ -401,7 +442,9 @@ template <class real, int NV_> struct Engine {
   }
 
   // ------------------------------------------------------------------ kinematics (mj_kinematics + mj_comPos [3P])
-  UR5_PHASE_D void kinematics() {
+  UR5_CALL void kinematics_fn() { kinematics_body(); }
+  UR5_FN void kinematics() { if constexpr (FLAT) kinematics_body(); else kinematics_fn(); }
+  UR5_PHASE_D void kinematics_body() {
     // ping-pong buffers of the pointer-jumping pass: ce / cde (contact images, dead until this step's constraint rows are
     // built) hold the frames, cand (broad-phase list, rebuilt later) the ancestor links
     static_assert(UR5_MAXCON * NB >= 12 * UR5_MAXRD && UR5_MAXCAND * sizeof(short) >= 2 * UR5_MAXRD * sizeof(int), "scratch aliasing");
@@ -575,15 +618,16 @@ template <class real, int NV_> struct Engine {
   // ---- block-parallel register linear algebra: every lane owns one row of one diagonal block (<= 8 columns, held in
   // registers r[0..7] by block-local column). All blocks are factored / solved simultaneously; the pivot row of each block
   // is fetched with a lane shuffle (ds_bpermute), so 8 column steps serve the robot block and every object block at once.
-  struct Blk { int base, loc, size; };   // first lane of my block, my row inside it, its order (0 = lane idle)
+  struct Blk { int base, loc, size; };   // first lane of my block (index inside the scene's lane group), my row inside it, its order (0 = lane idle)
   static __device__ __forceinline__ real shfl_d(real v, int src) { return (real)__shfl((double)v, src, 64); }
   // in-place Cholesky (lower, row-wise); returns 1 / (own diagonal entry)
   static __device__ __forceinline__ real blk_cholesky(real (&r)[UR5_MAXRD], const Blk& b) {
     real myinv = 1;
+    const int gb = UR5_GBASE;
 #pragma unroll
     for (int j = 0; j < UR5_MAXRD; j++) {
       const bool act = j < b.size;
-      const int src = act ? b.base + j : (int)threadIdx.x;
+      const int src = act ? gb + b.base + j : (int)threadIdx.x;
       real sacc = r[j];
 #pragma unroll
       for (int k = 0; k < j; k++) sacc -= r[k] * shfl_d(r[k], src);
@@ -599,12 +643,12 @@ template <class real, int NV_> struct Engine {
     return myinv;
   }
   // x <- (L L^T)^-1 x for every block; lt = LDS scratch of 64 x 8 reals used to transpose the factors
-  static __device__ __forceinline__ real blk_solve(const real (&r)[UR5_MAXRD], real myinv, const Blk& b, real x, real* lt, int nl = 64) {
-    const int lane = threadIdx.x;
+  static __device__ __forceinline__ real blk_solve(const real (&r)[UR5_MAXRD], real myinv, const Blk& b, real x, real* lt, int nl = GS) {
+    const int lane = UR5_LANE, gb = UR5_GBASE, self = (int)threadIdx.x;
 #pragma unroll
     for (int j = 0; j < UR5_MAXRD; j++) {
       const bool act = j < b.size;
-      real yj = shfl_d(x * myinv, act ? b.base + j : lane);
+      real yj = shfl_d(x * myinv, act ? gb + b.base + j : self);
       if (act) x = b.loc == j ? yj : (b.loc > j ? x - r[j] * yj : x);
     }
     if (lane < nl) {
@@ -619,7 +663,7 @@ template <class real, int NV_> struct Engine {
 #pragma unroll
     for (int k = UR5_MAXRD - 1; k >= 0; k--) {
       const bool act = k < b.size;
-      real xk = shfl_d(x * myinv, act ? b.base + k : lane);
+      real xk = shfl_d(x * myinv, act ? gb + b.base + k : self);
       if (act) x = b.loc == k ? xk : (b.loc < k ? x - t[k] * xk : x);
     }
     return x;
@@ -755,7 +799,10 @@ template <class real, int NV_> struct Engine {
     s.margin = margin;
     return s;
   }
-  UR5_BIG v3 support(const Shape& s, v3 dir) const {
+  // W = 1: the calling lane scans the hull's vertices itself. W = 8 (GPU narrow phase): the 8 lanes of an aligned sub-group work on the same
+  // pair with identical arguments; lane `sl` of the sub-group takes vertices sl, sl + 8, ... and a 3-step lane exchange picks the winner --
+  // larger dot product, smaller index on ties, which is exactly the vertex the serial scan (strict >) returns.
+  template <int W = 1> UR5_BIG v3 support(const Shape& s, v3 dir, int sl = 0) const {
     v3 d = mulT(s.mat, dir), l;
     if (s.type == UR5_GEOM_SPHERE) l = d * s.size.x;
     else if (s.type == UR5_GEOM_BOX) l = v3(d.x >= 0 ? s.size.x : -s.size.x, d.y >= 0 ? s.size.y : -s.size.y, d.z >= 0 ? s.size.z : -s.size.z);
@@ -767,30 +814,45 @@ template <class real, int NV_> struct Engine {
     } else if (s.type == UR5_GEOM_MESH) {
       real best = -1e300;
       int bi = 0;
-      for (int i = 0; i < s.vnum; i++) {
+      for (int i = (W > 1 ? sl : 0); i < s.vnum; i += W) {
         const double* p = M.hullvert[s.vadr + i];
         real v = (real)p[0] * d.x + (real)p[1] * d.y + (real)p[2] * d.z;
         if (v > best) { best = v; bi = i; }
       }
+#ifndef UR5_EMUL
+      if constexpr (W == 8) {
+        support_exchange<0xb1>(best, bi);    // quad_perm [1,0,3,2]: lane ^ 1
+        support_exchange<0x4e>(best, bi);    // quad_perm [2,3,0,1]: lane ^ 2
+        support_exchange<0x141>(best, bi);   // row_half_mirror: lane -> 7 - lane, the other quad of the sub-group
+      }
+#endif
       l = v3(M.hullvert[s.vadr + bi]);
     }
     return s.pos + mul(s.mat, l) + dir * ((real)0.5 * s.margin);
   }
+#ifndef UR5_EMUL
+  template <int CTRL> static __device__ __forceinline__ void support_exchange(real& best, int& bi) {
+    const real ob = (real)ur5_dpp<CTRL, 0xf>((double)best);
+    const int oi = __builtin_amdgcn_update_dpp(0, bi, CTRL, 0xf, 0xf, false);
+    const bool take = ob > best || (ob == best && oi < bi);
+    best = take ? ob : best; bi = take ? oi : bi;
+  }
+#endif
   struct MV { v3 v, a, b; };
-  UR5_FN MV msupport(const Shape& A, const Shape& B, v3 dir) const {
+  template <int W = 1> UR5_FN MV msupport(const Shape& A, const Shape& B, v3 dir, int sl = 0) const {
     MV r;
-    r.a = support(A, dir); r.b = support(B, -dir); r.v = r.a - r.b;
+    r.a = support<W>(A, dir, sl); r.b = support<W>(B, -dir, sl); r.v = r.a - r.b;
     return r;
   }
   // Minkowski portal refinement; same scheme, tolerances and result definition as oracle mpr_penetration()
-  UR5_MPR_ATTR bool mpr(const Shape& A, const Shape& B, real* depth, v3* dir_out, v3* pos_out) const {
+  template <int W = 1> UR5_MPR_ATTR bool mpr(const Shape& A, const Shape& B, real* depth, v3* dir_out, v3* pos_out, int sl = 0) const {
     const real tol = (real)1e-6;
     const int maxit = 50;
     MV v0, v1, v2, v3_, v4;
     v0.a = A.center; v0.b = B.center; v0.v = v0.a - v0.b;
     if (norm(v0.v) < (real)1e-12) v0.v = v3((real)1e-5, 0, 0);
     v3 dir = normalized(-v0.v);
-    v1 = msupport(A, B, dir);
+    v1 = msupport<W>(A, B, dir, sl);
     if (dot(v1.v, dir) <= 0) return false;
     dir = cross(v0.v, v1.v);
     if (norm(dir) < (real)1e-12 * maxv((real)1, norm(v0.v) * norm(v1.v))) {
@@ -799,13 +861,13 @@ template <class real, int NV_> struct Engine {
       return true;
     }
     dir = normalized(dir);
-    v2 = msupport(A, B, dir);
+    v2 = msupport<W>(A, B, dir, sl);
     if (dot(v2.v, dir) <= 0) return false;
     dir = normalized(cross(v1.v - v0.v, v2.v - v0.v));
     if (dot(dir, v0.v) > 0) { MV t = v1; v1 = v2; v2 = t; dir = -dir; }
     for (int it = 0;; it++) {
       if (it > maxit) return false;
-      v3_ = msupport(A, B, dir);
+      v3_ = msupport<W>(A, B, dir, sl);
       if (dot(v3_.v, dir) <= 0) return false;
       bool cont = false;
       if (dot(cross(v1.v, v3_.v), v0.v) < 0) { v2 = v3_; cont = true; }
@@ -819,7 +881,7 @@ template <class real, int NV_> struct Engine {
       if (dot(dir, v0.v) > 0) dir = -dir;
       real d1 = dot(v1.v, dir);
       if (d1 >= 0) hit = true;
-      v4 = msupport(A, B, dir);
+      v4 = msupport<W>(A, B, dir, sl);
       real d4 = dot(v4.v, dir);
       if (!hit && d4 < 0) return false;
       if (d4 - d1 <= tol || it >= maxit) {
@@ -1025,7 +1087,7 @@ template <class real, int NV_> struct Engine {
     if (do_emit) emit(out, c + e * ((real)0.5 * (best - r)), -e, -best - r);
     return -best - r;
   }
-  UR5_BIG void narrow(int g1, int g2, real margin, Sink& out, Single& keep) const {
+  UR5_BIG void narrow(int g1, int g2, real margin, Sink& out, Single& keep, int pair = -1) {
     int t1 = M.g_type[g1], t2 = M.g_type[g2];
     GeomPose A = geom_pose(g1), B = geom_pose(g2);
     if (t1 == UR5_GEOM_PLANE) {
@@ -1133,6 +1195,13 @@ template <class real, int NV_> struct Engine {
       box_box(A, v3(M.g_size[g1]), B, v3(M.g_size[g2]), margin, out, sat);
       keep.sat_code = sat.code; keep.sat_flip = sat.flip; keep.sat_best = sat.best;
     } else {
+#if !defined(UR5_EMUL) && !defined(UR5_MANY)
+      {   // general convex pair: queued for the cooperative MPR pass of collision_body (8 lanes per pair)
+        const int q = __hip_atomic_fetch_add(&S.ncouple, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (q < UR5_MAXCON) S.couple[q] = pair; else S.status |= UR5_ST_CAND_OVERFLOW;   // more such pairs than list slots: flagged, never silently dropped
+        (void)keep;
+      }
+#else
       if (out.mode == 0) {
         Shape sa = make_shape(g1, margin), sb = make_shape(g2, margin);
         real depth;
@@ -1141,6 +1210,7 @@ template <class real, int NV_> struct Engine {
         if (keep.hit && !(keep.dist < margin)) keep.hit = false;
       }
       if (keep.hit) emit(out, keep.pos, keep.normal, keep.dist);
+#endif
     }
   }
   UR5_BIG bool cull(int g1, int g2, real margin) const {  // true = cannot touch
@@ -1171,16 +1241,18 @@ template <class real, int NV_> struct Engine {
     return k == UR5_KIND_STATIC ? -1 : (k == UR5_KIND_ROBOT ? M.g_owner[g] : M.nrd + M.g_owner[g]);
   }
 
-  UR5_PHASE_A void collision() {
-    if (UR5_LANE == 0) { S.ncon = 0; S.ncand = 0; }
+  UR5_CALL void collision_fn() { collision_body(); }
+  UR5_FN void collision() { if constexpr (FLAT) collision_body(); else collision_fn(); }
+  UR5_PHASE_A void collision_body() {
+    if (UR5_LANE == 0) { S.ncon = 0; S.ncand = 0; S.ncouple = 0; }
     SYNC();
     if (!S.contacts_enabled) return;
     PROF_T0();
     // broad phase: ordered compaction of the surviving pairs
     int ncand = 0;
-    for (int p0 = 0; p0 < M.npair; p0 += UR5_NT) {
+    for (int p0 = 0; p0 < M.npair; p0 += GS) {
 #ifdef UR5_EMUL
-      for (int p = p0; p < p0 + UR5_NT && p < M.npair; p++) {
+      for (int p = p0; p < p0 + GS && p < M.npair; p++) {
         int g1 = M.pair_g1[p], g2 = M.pair_g2[p];
         real margin = maxv((real)M.g_margin[g1], (real)M.g_margin[g2]);
         if (!cull(g1, g2, margin)) { if (ncand < UR5_MAXCAND) S.cand[ncand] = (short)p; ncand++; }
@@ -1195,6 +1267,7 @@ template <class real, int NV_> struct Engine {
       }
       unsigned long long mask = __ballot(keep);
 #if UR5_NT == 64
+      if constexpr (GS < 64) mask = (mask >> UR5_GBASE) & ((1ull << (GS & 63)) - 1ull);   // the votes of this scene's lanes
       int slot = ncand + __popcll(mask & ((1ull << UR5_LANE) - 1ull));
       if (keep && slot < UR5_MAXCAND) S.cand[slot] = (short)p;
       ncand += __popcll(mask);
@@ -1219,7 +1292,7 @@ template <class real, int NV_> struct Engine {
 #ifdef UR5_EMUL
     for (int ci = 0; ci < ncand; ci++) {
 #else
-    for (int ci = UR5_LANE; ci < ncand; ci += UR5_NT) {
+    for (int ci = UR5_LANE; ci < ncand; ci += GS) {
 #endif
       if (ci < ncand) {
         Sink sink;
@@ -1229,10 +1302,35 @@ template <class real, int NV_> struct Engine {
         int p = S.cand[ci];
         sink.g1 = M.pair_g1[p]; sink.g2 = M.pair_g2[p];
         real margin = maxv((real)M.g_margin[sink.g1], (real)M.g_margin[sink.g2]);
-        narrow(sink.g1, sink.g2, margin, sink, keep);
+        narrow(sink.g1, sink.g2, margin, sink, keep, p);
       }
     }
     SYNC();
+#if !defined(UR5_EMUL) && !defined(UR5_MANY)
+    {   // general convex pairs (hull against hull / box / ...): Minkowski portal refinement with 8 lanes per pair. The lanes of a sub-group
+        // run the same MPR on the same pair (sub-group-uniform control flow) and share the hull scans of its support calls; GS / 8
+        // pairs are in flight at once. S.couple / S.ncouple are free until make_constraints rebuilds them.
+      const int nm = S.ncouple < UR5_MAXCON ? S.ncouple : UR5_MAXCON;
+      const int sub = UR5_LANE >> 3, sl = UR5_LANE & 7;
+      for (int base = 0; base < nm; base += GS / 8) {
+        const int idx = base + sub;
+        if (idx < nm) {
+          const int p = S.couple[idx];
+          Sink sink;
+          sink.mode = 0; sink.slot = 0; sink.n = 0;
+          sink.g1 = M.pair_g1[p]; sink.g2 = M.pair_g2[p];
+          const real margin = maxv((real)M.g_margin[sink.g1], (real)M.g_margin[sink.g2]);
+          Shape sa = make_shape(sink.g1, margin), sb = make_shape(sink.g2, margin);
+          real depth;
+          v3 nrm, pos;
+          const bool hit = mpr<8>(sa, sb, &depth, &nrm, &pos, sl);
+          const real dist = margin - depth;
+          if (hit && dist < margin && sl == 0) emit(sink, pos, nrm, dist);
+        }
+      }
+      SYNC();
+    }
+#endif
     if (UR5_LANE == 0) {
       int n = S.ncon;
       if (n > UR5_MAXCON) { n = UR5_MAXCON; S.status |= UR5_ST_CONTACT_OVERFLOW; }
@@ -1247,7 +1345,7 @@ template <class real, int NV_> struct Engine {
   // x^p of the impedance sigmoid: p = 2 (MuJoCo's default solimp) is a product; the general pow() is large, so it is kept
   // out of line instead of being expanded at each of the eight places an impedance is evaluated
   UR5_CALL static real pow_any(real x, real p) { return pow(x, p); }
-  UR5_FN static real powr(real x, real p) { return p == (real)2 ? x * x : pow_any(x, p); }
+  UR5_FN static real powr(real x, real p) { if constexpr (FLAT && UR5_INL_POW) return p == (real)2 ? x * x : pow(x, p); else return p == (real)2 ? x * x : pow_any(x, p); }
   UR5_FN static real impedance(const double* solimp, real x_abs) {
     real dmin = clampv((real)solimp[0], (real)0.0001, (real)0.9999), dmax = clampv((real)solimp[1], (real)0.0001, (real)0.9999);
     real width = (real)solimp[2], mid = (real)solimp[3], power = (real)solimp[4];
@@ -1279,13 +1377,17 @@ template <class real, int NV_> struct Engine {
     e[0] = dot(n, u); e[1] = dot(t1, u); e[2] = dot(t2, u); e[3] = dot(n, w);
     if constexpr (NB > 4) { e[NB - 2] = dot(t1, w); e[NB - 1] = dot(t2, w); }
   }
-  UR5_PHASE_B void make_constraints() {
+  UR5_CALL void make_constraints_fn() { make_constraints_body(); }
+  UR5_FN void make_constraints() { if constexpr (FLAT) make_constraints_body(); else make_constraints_fn(); }
+  UR5_PHASE_B void make_constraints_body() {
 #if !defined(UR5_EMUL) && UR5_NT == 64
     // special rows (joint equality, violated joint / slide limits): one candidate per lane -- [0, neq) equalities, then 2 sides of
     // every robot joint, then 2 sides of every object slide -- compacted in candidate order (= the serial order below) with a ballot
+    // (candidates are taken GS at a time when there are more of them than lanes in the scene's group)
     const int ncand_rows = M.neq + 2 * M.nrd + 6 * M.nobj;
-    if (ncand_rows <= 64) {
-      const int t = UR5_LANE;
+    int nrows = 0;
+    for (int t0 = 0; t0 < ncand_rows; t0 += GS) {
+      const int t = t0 + UR5_LANE;
       bool on = false;
       int d1 = 0, d2 = -1, uni = 1;
       real c1 = 0, c2 = 0, Dr = 0, aref = 0;
@@ -1325,15 +1427,17 @@ template <class real, int NV_> struct Engine {
           }
         }
       }
-      const unsigned long long mask = __ballot(on);
-      const int slot = __popcll(mask & ((1ull << t) - 1ull));
+      unsigned long long mask = __ballot(on);
+      if constexpr (GS < 64) mask = (mask >> UR5_GBASE) & ((1ull << (GS & 63)) - 1ull);   // the votes of this scene's lanes
+      const int slot = nrows + __popcll(mask & ((1ull << UR5_LANE) - 1ull));
       if (on && slot < UR5_MAXSR) {
         S.sr_d1[slot] = d1; S.sr_d2[slot] = d2; S.sr_c1[slot] = c1; S.sr_c2[slot] = c2; S.sr_uni[slot] = uni; S.sr_D[slot] = Dr; S.sr_aref[slot] = aref;
       }
-      if (t == 0) { const int n = __popcll(mask); S.nsr = n < UR5_MAXSR ? n : UR5_MAXSR; if (n > UR5_MAXSR) S.status |= UR5_ST_ROW_OVERFLOW; }
-    } else
-#endif
-    // ... or lane 0 builds them one after the other (lane emulation, scenes with more candidates than lanes)
+      nrows += __popcll(mask);
+    }
+    if (UR5_LANE == 0) { S.nsr = nrows < UR5_MAXSR ? nrows : UR5_MAXSR; if (nrows > UR5_MAXSR) S.status |= UR5_ST_ROW_OVERFLOW; }
+#else
+    // ... or lane 0 builds them one after the other (lane emulation, the many-object variant)
     if (UR5_LANE == 0) {
       int ns = 0;
       for (int e = 0; e < M.neq; e++) {
@@ -1388,6 +1492,7 @@ template <class real, int NV_> struct Engine {
       }
       S.nsr = ns;
     }
+#endif
     PAR(c, S.ncon) {
       int g1 = S.cg1[c], g2 = S.cg2[c];
       make_frame(v3(S.cframe[c]), S.cframe[c]);
@@ -1436,7 +1541,9 @@ template <class real, int NV_> struct Engine {
   // ------------------------------------------------------------------ Newton solver pieces
   UR5_FN real row_mu(int c, int k) const { return k <= 2 ? S.cfri[c][0] : (k == 3 ? S.cfri[c][1] : S.cfri[c][NB > 4 ? 2 : 1]); }
   // twists of every body for a dof-space vector, then base images (with or without the aref offsets)
-  UR5_CALL void images(const real* vec, bool offset, real (*out)[NB], real* srout) {
+  UR5_CALL void images_fn(const real* vec, bool offset, real (*out)[NB], real* srout) { images_body(vec, offset, out, srout); }
+  UR5_FN void images(const real* vec, bool offset, real (*out)[NB], real* srout) { if constexpr (FLAT && UR5_INL_IMAGES) images_body(vec, offset, out, srout); else images_fn(vec, offset, out, srout); }
+  UR5_FN void images_body(const real* vec, bool offset, real (*out)[NB], real* srout) {
     PAR(sl, nslot()) {
       const int b = body_of_slot(sl);
       if (b < M.nrd) {
@@ -1465,7 +1572,9 @@ template <class real, int NV_> struct Engine {
     }
     SYNC();
   }
-  UR5_CALL void mat_vec_M(const real* vec, real* out) {
+  UR5_CALL void mat_vec_M_fn(const real* vec, real* out) { mat_vec_M_body(vec, out); }
+  UR5_FN void mat_vec_M(const real* vec, real* out) { if constexpr (FLAT && UR5_INL_MATVEC) mat_vec_M_body(vec, out); else mat_vec_M_fn(vec, out); }
+  UR5_FN void mat_vec_M_body(const real* vec, real* out) {
     PAR(i, M.nv) {
       if (i < M.nrd) { real s = 0; for (int e = 0; e < M.nrd; e++) s += S.Mr[i][e] * vec[e]; out[i] = s; }
       else out[i] = S.Mobj[i - M.nrd] * vec[i];
@@ -1474,7 +1583,9 @@ template <class real, int NV_> struct Engine {
   }
   // constraint cost of the current images (ce, sr_jar) shifted by alpha along (cde, sr_jv); also first/second derivative
   struct Cost3 { real c, d1, d2; };
-  UR5_CALL Cost3 constraint_cost(real alpha) {
+  UR5_CALL Cost3 constraint_cost_fn(real alpha) { return constraint_cost_body(alpha); }
+  UR5_FN Cost3 constraint_cost(real alpha) { if constexpr (FLAT && UR5_INL_COST) return constraint_cost_body(alpha); else return constraint_cost_fn(alpha); }
+  UR5_FN Cost3 constraint_cost_body(real alpha) {
     real c0 = 0, g1 = 0, g2 = 0;
     PAR(c, S.ncon) {
       real D = S.cD[c];
@@ -1595,7 +1706,11 @@ template <class real, int NV_> struct Engine {
   }
   // gradient at S.x (images in S.ce / S.sr_jar must be current) and, unless `check` finds it below the tolerance (returns true:
   // converged, nothing else computed), the Newton direction S.search = -H^-1 grad
-  UR5_PHASE_H bool newton_direction(const bool check, const real scale, const real tolerance) {
+  UR5_CALL bool newton_direction_fn(const bool check, const real scale, const real tolerance) { return newton_direction_body(check, scale, tolerance); }
+  UR5_FN bool newton_direction(const bool check, const real scale, const real tolerance) {
+    if constexpr (FLAT) return newton_direction_body(check, scale, tolerance); else return newton_direction_fn(check, scale, tolerance);
+  }
+  UR5_PHASE_H bool newton_direction_body(const bool check, const real scale, const real tolerance) {
     PROF_T0();
     const int nbod = nb();
     // per-body wrench (gradient) and 6x6 twist-space Hessian accumulators: every contact lane scatters its two sides with
@@ -1746,7 +1861,7 @@ template <class real, int NV_> struct Engine {
     SYNC();
 #else
     (void)LD;
-    factor_solve_rows<false>();
+    if constexpr (FLAT) factor_solve_rows_body<false>(); else factor_solve_rows<false>();
     PROF(PF_SOLVE);
 #endif
 #endif   // UR5_MANY
@@ -1824,8 +1939,10 @@ template <class real, int NV_> struct Engine {
 #endif
 
 #if !defined(UR5_EMUL) && !defined(UR5_MANY)
-  // broadcast lane `src` (wave-uniform) of a double through two v_readlane
+  // broadcast lane `src` (group-uniform index inside the scene's lane group) of a double: two v_readlane when the group is the whole
+  // wavefront, a lane shuffle (ds_bpermute) when two scenes share it -- both scenes are at the same column, sources src and 32 + src
   static __device__ __forceinline__ real bcast(real v, int src) {
+    if constexpr (GS != 64) return shfl_d(v, UR5_GBASE + src);
     double d = (double)v;
     int lo = __double2loint(d), hi = __double2hiint(d);
     lo = __builtin_amdgcn_readlane(lo, src);
@@ -1835,9 +1952,11 @@ template <class real, int NV_> struct Engine {
   // H (lower triangle in LDS) -> S.search = -H^-1 grad. Row i of the factor lives in the registers of lane i; the pivot row
   // is broadcast with v_readlane, so the whole factorisation runs without touching LDS. BLOCKDIAG: no contact couples two
   // movable bodies, H = diag(robot 8x8, object 6x6 ...) and every column only looks back to the start of its own block.
-  template <bool BLOCKDIAG> __device__ __noinline__ void factor_solve_rows() {
+  template <bool BLOCKDIAG> __device__ __noinline__ void factor_solve_rows() { factor_solve_rows_body<BLOCKDIAG>(); }
+  template <bool BLOCKDIAG> __device__ __forceinline__ void factor_solve_rows_body() {
     constexpr int N = NV_;
-    const int lane = threadIdx.x, nv = M.nv;
+    static_assert(NV_ <= GS, "one Hessian row per lane of the scene's group");
+    const int lane = UR5_LANE, nv = M.nv;
     real Lrow[N];
 #pragma unroll
     for (int j = 0; j < N; j++) Lrow[j] = (lane < nv && j <= lane) ? S.H[UR5_HIDX(lane, j)] : (j == lane ? (real)1 : (real)0);
@@ -2351,7 +2470,9 @@ template <class real, int NV_> struct Engine {
   }
 #endif
 
-  UR5_PHASE_C void solve_newton() {
+  UR5_CALL void solve_newton_fn() { solve_newton_body(); }
+  UR5_FN void solve_newton() { if constexpr (FLAT) solve_newton_body(); else solve_newton_fn(); }
+  UR5_PHASE_C void solve_newton_body() {
     const int nv = M.nv;
     if (S.ncon == 0 && S.nsr == 0) {
       PAR(i, nv) S.x[i] = S.as[i];
@@ -2652,7 +2773,8 @@ template <class real, int NV_> struct Engine {
   UR5_FN void write_kp0(real v) { SYNC(); if (UR5_LANE == 0) kp()[0] = v; SYNC(); }
   UR5_FN int stay_chunks_for(real ms) const { return (int)ceil(ms / (real)1000 / (real)M.timestep / (real)10 - (real)1e-9); }  // :621-636, H2
 
-  UR5_FN void run(const Ur5Launch& P, int env) {
+  // One scene per wavefront (GS = 64): the script as nested loops -- its registers are wave-uniform (SGPRs) and are not live across step().
+  UR5_FN void run_nested(const Ur5Launch& P, int env) {
     const int op = P.op;
     int pc = 0, result = RES_NONE, last_res = RES_NONE, last_n = 0;
     // grasp-script registers (GraspingEnv.py:205-386; mirrors oracle Sim::grasp_attempt)
@@ -2823,8 +2945,210 @@ template <class real, int NV_> struct Engine {
     }
   }
 
+  // One loop for the whole launch. Each trip (a) advances the scene's script until it needs a physics step -- consuming the result of the
+  // finished primitive, choosing the next one, running its IK, evaluating the PIDs and the termination tests of the move loop
+  // (MujocoController.py:318-382) -- and (b) takes that one step. Scenes that share a wavefront (GS < 64) are at different points of their
+  // scripts; with this shape they still execute every physics step together, and only the short control code of (a) diverges.
+  UR5_FN void run(const Ur5Launch& P, int env, bool live = true) {
+    if constexpr (FLAT) run_flat(P, env, live); else { if (live) run_nested(P, env); }
+  }
+  UR5_FN void run_flat(const Ur5Launch& P, int env, bool live) {
+    const int op = P.op;
+    int pc = 0, result = RES_NONE, last_res = RES_NONE, last_n = 0;
+    // grasp-script registers (GraspingEnv.py:205-386; mirrors oracle Sim::grasp_attempt)
+    v3 coord;
+    int rotation = 0, result1 = RES_NONE, result_final = RES_NONE;
+    bool result_grasp = false, grasped = false;
+    if (live && (op == UR5_OP_GRASP || op == UR5_OP_MOVE_EE || op == UR5_OP_IK)) coord = v3((real)P.target[8 * env], (real)P.target[8 * env + 1], (real)P.target[8 * env + 2]);
+    if (live && op == UR5_OP_GRASP) {
+      rotation = (int)P.target[8 * env + 3];
+      if (UR5_LANE == 0) for (int i = 0; i < 12; i++) { if (P.phase_steps) P.phase_steps[12 * env + i] = 0; if (P.phase_result) P.phase_result[12 * env + i] = -1; }
+    }
+    auto record = [&](int slot, int res, int n) {
+      if (UR5_LANE == 0) { if (P.phase_steps) P.phase_steps[12 * env + slot] = n; if (P.phase_result) P.phase_result[12 * env + slot] = res; }
+    };
+    // the primitive in flight
+    Prim pr;
+    pr.done = false; pr.need_ik = false; pr.repeat = 1; pr.mask = 0; pr.tol = 0; pr.max_steps = 0;
+    int slot = -1;       // phase slot the primitive reports into (grasp script)
+    int res = RES_NONE, steps = 0, rep = 0, reps = 0;
+    bool reached = false, raw = false, need_new = true, done = !live;
+    // the primitive is over: publish its step count, hand its result to the script
+    auto finish = [&]() {
+      SYNC();
+      if (UR5_LANE == 0) S.last_steps = steps;
+      SYNC();
+      last_res = res; last_n = steps;
+      if (slot >= 0) record(slot, res, steps);
+      need_new = true;
+    };
+    // one repetition of the move loop ended (converged, or out of steps): start the next one (stay: chunks of 10 steps) or finish
+    auto end_rep = [&]() {
+      rep++;
+      if (rep < reps) { steps = 1; res = RES_NONE; reached = false; }
+      else { if (raw) { steps = pr.max_steps; res = RES_SUCCESS; } finish(); }
+    };
+    while (!done) {
+      bool want_step = false;
+      while (!want_step && !done) {
+        if (need_new) {
+          pr.done = false; pr.need_ik = false; pr.repeat = 1; pr.mask = 0; pr.tol = 0; pr.max_steps = 0;
+          slot = -1;
+          // ---------------- script logic: consume the previous result, choose the next primitive
+          if (op == UR5_OP_MOVE) {
+            if (pc == 0) {
+              pr.mask = P.group_mask[env];
+              SYNC();
+              if (UR5_LANE == 0 && P.target) {
+                int k = 0;
+                for (int a = 0; a < M.nu; a++) if (pr.mask >> a & 1u) { double t = P.target[8 * env + k++]; if (t == t) target()[a] = (real)t; }
+              }
+              SYNC();
+              pr.tol = (real)P.tol[env]; pr.max_steps = P.max_steps[env];
+            } else { result = last_res; pr.done = true; }
+          } else if (op == UR5_OP_STAY) {
+            if (pc == 0) { pr.mask = mask_all(); pr.tol = (real)1e-7; pr.max_steps = 10; pr.repeat = P.max_steps[env]; }
+            else { result = RES_SUCCESS; pr.done = true; }
+          } else if (op == UR5_OP_MOVE_EE) {
+            if (pc == 0) { pr.need_ik = true; pr.xyz = coord; pr.mask = 0x1fu; pr.tol = (real)P.tol[env]; pr.max_steps = P.max_steps[env]; }
+            else { result = last_res; pr.done = true; }
+          } else if (op == UR5_OP_GRASP) {
+            const real table_height = (real)P.table_height;
+            bool chosen = false;
+            while (!chosen) {
+              chosen = true;
+              switch (pc) {
+                case 0:   // GraspEnv.step's skip rule (GraspingEnv.py:124-131): the caller flags targets it must not act on
+                  if (P.target[8 * env + 4] != 0) { result = 0; pr.done = true; break; }
+                  // :212 move above the target
+                  pr.need_ik = true; pr.xyz = v3(coord.x, coord.y, (real)1.1); pr.mask = 0x1fu; pr.tol = (real)0.05; pr.max_steps = 1000; slot = 0; break;
+                case 1:   // :227-239 centre fallback when the IK failed
+                  result1 = last_res;
+                  if (result1 == RES_IK_FAIL) { pr.need_ik = true; pr.xyz = v3(0, (real)-0.6, (real)1.1); pr.mask = 0x1fu; pr.tol = (real)0.05; pr.max_steps = 1000; slot = 0; }
+                  else { pc = 3; chosen = false; }
+                  break;
+                case 2: result1 = last_res; pc = 3; chosen = false; break;
+                case 3:   // :242 stuck -> skip the grasp; else :252 rotate the wrist
+                  if (result1 == RES_MAX_STEPS) { pc = 9; chosen = false; break; }
+                  {
+                    const real rot_deg[6] = {0, 30, 60, 90, -30, -60};
+                    real deg = rotation == 0 ? rot_deg[0] : rotation == 1 ? rot_deg[1] : rotation == 2 ? rot_deg[2] : rotation == 3 ? rot_deg[3] : rotation == 4 ? rot_deg[4] : rot_deg[5];
+                    write_target(5, deg * (real)3.14159265358979323846 / (real)180);
+                  }
+                  pr.mask = mask_all(); pr.tol = (real)0.05; pr.max_steps = 500; slot = 1; break;
+                case 4:   // :255 open_gripper(half=True)
+                  write_target(6, (real)0); pr.mask = 1u << 6; pr.tol = (real)0.05; pr.max_steps = 1000; slot = 2; break;
+                case 5:   // :258-269 descend
+                  pr.need_ik = true; pr.xyz = v3(coord.x, coord.y, maxv(table_height, coord.z - (real)0.01)); pr.mask = 0x1fu; pr.tol = (real)0.01; pr.max_steps = 300; slot = 3; break;
+                case 6:   // :272-277 could not reach -> no grasp; else stay(100)
+                  if (last_res == RES_MAX_STEPS) { pc = 9; chosen = false; break; }
+                  pr.mask = mask_all(); pr.tol = (real)1e-7; pr.max_steps = 10; pr.repeat = stay_chunks_for(100); break;
+                case 7:   // :278 grasp() = close_gripper(max_steps=300)
+                  write_target(6, (real)-0.4); pr.mask = 1u << 6; pr.tol = (real)0.01; pr.max_steps = 300; break;
+                case 8:
+                  result_grasp = last_res != RES_SUCCESS;
+                  record(5, result_grasp ? RES_MAX_STEPS : RES_SUCCESS, last_n);
+                  pc = 9; chosen = false; break;
+                case 9:   // :282
+                  write_kp0(10);
+                  if (P.check_mode == 1) { pr.need_ik = true; pr.xyz = v3(coord.x, coord.y, (real)1.1); pr.mask = 0x1fu; pr.tol = (real)0.05; pr.max_steps = 1000; slot = 6; }
+                  else { pc = 12; chosen = false; }
+                  break;
+                case 10:  // IT1 (README.md:20): 500-step closing check right after lifting
+                  if (result_grasp) { write_target(6, (real)-0.4); pr.mask = 1u << 6; pr.tol = (real)0.01; pr.max_steps = 500; slot = 9; }
+                  else { pc = 12; chosen = false; }
+                  break;
+                case 11: result_final = last_res; pc = 12; chosen = false; break;
+                case 12:  // :285 back above the table centre
+                  pr.need_ik = true; pr.xyz = v3(0, (real)-0.6, (real)1.1); pr.mask = 0x1fu; pr.tol = (real)0.05; pr.max_steps = 1000; slot = 7; break;
+                case 13:  // :297 to the drop position
+                  pr.need_ik = true; pr.xyz = v3((real)0.6, 0, (real)1.15); pr.mask = 0x1fu; pr.tol = (real)0.01; pr.max_steps = 1200; slot = 8; break;
+                case 14:  // :312-321 closing check at the drop position
+                  if (P.check_mode == 0 && result_grasp) { write_target(6, (real)-0.4); pr.mask = 1u << 6; pr.tol = (real)0.01; pr.max_steps = 1000; slot = 9; }
+                  else { pc = 16; chosen = false; }
+                  break;
+                case 15: result_final = last_res; pc = 16; chosen = false; break;
+                case 16:  // :327, :338 open the gripper
+                  grasped = (result_final == RES_MAX_STEPS) && result_grasp;
+                  write_target(6, (real)0.4); pr.mask = 1u << 6; pr.tol = (real)0.05; pr.max_steps = 1000; slot = 10; break;
+                case 17:  // :341-342
+                  if (grasped) { pr.mask = mask_all(); pr.tol = (real)1e-7; pr.max_steps = 10; pr.repeat = stay_chunks_for(200); }
+                  else { pc = 18; chosen = false; }
+                  break;
+                case 18:  // :345 rotate back
+                  write_target(5, (real)0); pr.mask = mask_all(); pr.tol = (real)0.05; pr.max_steps = 500; slot = 11; break;
+                default:  // :347
+                  write_kp0(20);
+                  result = grasped ? 1 : 0;
+                  pr.done = true; break;
+              }
+            }
+          } else if (op == UR5_OP_STEP) {
+            if (pc == 0) { pr.mask = 0; pr.tol = (real)-1; pr.max_steps = P.max_steps[env]; pr.repeat = -1; }   // repeat < 0: raw sim.step() x max_steps
+            else { result = RES_SUCCESS; pr.done = true; }
+          } else if (op == UR5_OP_IK) {
+            if (pc == 0) { pr.need_ik = true; pr.xyz = coord; pr.repeat = 0; }
+            else { result = last_res; pr.done = true; }
+          } else {  // UR5_OP_FORWARD
+            if (pc == 0) pr.repeat = -2; else { result = RES_SUCCESS; pr.done = true; }
+          }
+          if (pr.done) { done = true; break; }
+          pc++;
+          // ---------------- the primitive
+          res = RES_NONE; steps = 0;
+          bool ikfail = false;
+          if (pr.need_ik) {   // :446-465 move_ee = ik + move_group("Arm")
+            PROF_T0();
+            real q5[5];
+            bool ok = ik(pr.xyz, q5);
+            SYNC();
+            if (ok && op != UR5_OP_IK) { if (UR5_LANE == 0) for (int j = 0; j < 5; j++) target()[j] = q5[j]; }
+            if (op == UR5_OP_IK && UR5_LANE == 0 && P.out) for (int j = 0; j < 5; j++) P.out[8 * env + j] = (double)q5[j];
+            SYNC();
+            ikfail = !ok;
+            res = ok ? RES_SUCCESS : RES_IK_FAIL;
+            PROF(PF_IK);
+          }
+          if (pr.repeat == -2) {
+            Fact fr0;
+            forward(fr0);
+            if (P.debug) dump(P.debug + (size_t)UR5_DEBUG_STRIDE * env);
+            finish();
+          } else if (!ikfail && pr.repeat != 0) {   // enter the move loop
+            raw = pr.repeat < 0;
+            reps = raw ? 1 : pr.repeat;
+            rep = 0; steps = 1; res = RES_NONE; reached = false;
+            need_new = false;
+          } else finish();
+        } else {   // one trip of MujocoController.py:318-382 up to (not including) its sim.step()
+          if (!raw) {
+            real md = pid_and_deltas(pr.mask);
+            if (md < pr.tol) { res = RES_SUCCESS; reached = true; }   // no break: one more sim.step() follows (:351-363)
+          }
+          if (steps > pr.max_steps) { res = RES_MAX_STEPS; end_rep(); }
+          else want_step = true;
+        }
+      }
+      if (want_step) {
+        step();
+        steps++;
+        if (reached) end_rep();
+      }
+    }
+    if (live && UR5_LANE == 0) {
+      if (P.result) P.result[env] = result;
+      if (P.steps) P.steps[env] = S.last_steps;
+#if defined(UR5_PROFILE) && !defined(UR5_EMUL)
+      S.prof[PF_REALCLK] = (double)wall_clock64();   // [PF_CORECLK] = start, [PF_REALCLK] = end of the scene's wave, 100 MHz ticks
+      if (P.debug && P.op != UR5_OP_FORWARD) for (int i = 0; i < PF_COUNT; i++) P.debug[(size_t)UR5_DEBUG_STRIDE * env + i] = S.prof[i];
+#endif
+    }
+  }
+
   // introspection for the parity tests: [0] ncon, [1] nsr, [2..] fixed sections (see tests/test_parity_forward.py)
-  UR5_CALL void dump(double* out) {
+  UR5_CALL void dump_fn(double* out) { dump_body(out); }
+  UR5_FN void dump(double* out) { if constexpr (FLAT && UR5_INL_DUMP) dump_body(out); else dump_fn(out); }
+  UR5_FN void dump_body(double* out) {
     SYNC();
     if (UR5_LANE != 0) return;
     int o = 0;

@@ -7,29 +7,36 @@
 #include "ur5_engine.h"
 #include "ur5sim_host.h"
 
-// Register budget: with no hint the compiler takes all 512 registers of a SIMD lane for this one-wave workgroup (occupancy 1).
-// The scene's LDS footprint allows 8 scenes per CU = 2 waves per SIMD, and two resident waves hide each other's LDS / scalar
-// latency: 256 registers + some spill is 22 % faster than 512 registers (measured, profiles/); 3 waves (168) is slower.
+// Lanes per scene (GS) and register budget of the small-scene kernels. Measured on one MI355X, bench.py workload (profiles/r02_*):
+//  * GS = 64 (default): one scene per wavefront, two waves per SIMD at 256 registers (8 scenes per CU, the LDS limit). The two resident
+//    waves hide each other's latencies almost perfectly (a wave alone takes 68 us per settled step, 8 per CU 90 us each).
+//  * GS = 32 (-DUR5_SMALL_GS=32, NV = 32 kernel only): TWO scenes per wavefront, one wave per SIMD with the whole 512-entry register file.
+//    One instruction stream serves two scenes (a lone wave: 88 us per step for both), but the LDS footprint still caps a CU at 8 scenes,
+//    i.e. ONE such wave per SIMD with nothing to overlap it: 5.5 M env-steps/s against 7.7 M for GS = 64 on the same box. It would need
+//    <= 10 KB of LDS per scene (two such waves per SIMD) to win. Kept as a build option; tests/ pass in both layouts.
+#ifndef UR5_SMALL_GS
+#define UR5_SMALL_GS 64
+#endif
 #ifndef UR5_WAVES_PER_EU
 #define UR5_WAVES_PER_EU 2
 #endif
 #ifdef UR5_MANY
-#define UR5_KERNEL_ATTR __launch_bounds__(UR5_NT)
+#define UR5_KERNEL_ATTR(GS) __launch_bounds__(UR5_NT)
 #else
-#define UR5_KERNEL_ATTR __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(UR5_WAVES_PER_EU)))
+#define UR5_KERNEL_ATTR(GS) __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((GS) < 64 ? 1 : UR5_WAVES_PER_EU)))
 #endif
-template <int NV>
-__global__ void UR5_KERNEL_ATTR ur5_run_kernel(double* __restrict__ rec, Ur5Launch P) {
-  const int env = blockIdx.x;
-  if (env >= P.n_env) return;
-  ur5::Engine<double, NV> eng;
-  double* r = rec + (size_t)env * UR5_REC_STRIDE;
-  eng.load(r, P.pid_dt, P.contacts_enabled);
+template <int NV, int GS>
+__global__ void UR5_KERNEL_ATTR(GS) ur5_run_kernel(double* __restrict__ rec, Ur5Launch P) {
+  const int env = blockIdx.x * (UR5_NT / GS) + (int)threadIdx.x / GS;
+  const bool live = env < P.n_env;                 // a half-filled last workgroup: the lanes of the missing scene idle
+  ur5::Engine<double, NV, GS> eng;
+  double* r = rec + (size_t)(live ? env : 0) * UR5_REC_STRIDE;
+  if (live) eng.load(r, P.pid_dt, P.contacts_enabled);
 #ifdef UR5_MANY
   eng.set_hess(P.hess + (size_t)env * UR5_HESS_STRIDE);
 #endif
-  eng.run(P, env);
-  eng.save(r);
+  eng.run(P, env, live);
+  if (live) eng.save(r);
 }
 
 // the model sits in __constant__ memory (one copy per device); a handle re-uploads it only when another handle used the device last
@@ -162,19 +169,22 @@ static int be_launch(ur5_sim* h, const Ur5Launch& P) {
   hipEvent_t ev0, ev1;
   if (be_event_pair(h, b, &ev0, &ev1)) return ur5host::fail(UR5_ERR_DEVICE, "hipEventCreate failed");
   HIPCHK(hipEventRecord(ev0, b->stream));
-  dim3 grid(h->n), block(UR5_NT);
+  dim3 block(UR5_NT);
 #ifdef UR5_MANY
+  dim3 grid(h->n);
   {   // the scene needs more than the default 64 KB of dynamic LDS (one scene per CU)
     static bool attr_set[64] = {false};
     if (!attr_set[h->device & 63]) {
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ur5_run_kernel<UR5_MAXNV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ur5::Lds<double, UR5_MAXNV>)));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ur5_run_kernel<UR5_MAXNV, UR5_NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ur5::Lds<double, UR5_MAXNV>)));
       attr_set[h->device & 63] = true;
     }
   }
-  hipLaunchKernelGGL(ur5_run_kernel<UR5_MAXNV>, grid, block, sizeof(ur5::Lds<double, UR5_MAXNV>), b->stream, h->d_rec, P);
+  hipLaunchKernelGGL((ur5_run_kernel<UR5_MAXNV, UR5_NT>), grid, block, sizeof(ur5::Lds<double, UR5_MAXNV>), b->stream, h->d_rec, P);
 #else
-  if (h->nvt == 32) hipLaunchKernelGGL(ur5_run_kernel<32>, grid, block, sizeof(ur5::Lds<double, 32>), b->stream, h->d_rec, P);
-  else hipLaunchKernelGGL(ur5_run_kernel<UR5_MAXNV>, grid, block, sizeof(ur5::Lds<double, UR5_MAXNV>), b->stream, h->d_rec, P);
+  if (h->nvt == 32) {
+    constexpr int SPW = UR5_NT / UR5_SMALL_GS;   // scenes per workgroup
+    hipLaunchKernelGGL((ur5_run_kernel<32, UR5_SMALL_GS>), dim3((h->n + SPW - 1) / SPW), block, SPW * sizeof(ur5::Lds<double, 32>), b->stream, h->d_rec, P);
+  } else hipLaunchKernelGGL((ur5_run_kernel<UR5_MAXNV, 64>), dim3(h->n), block, sizeof(ur5::Lds<double, UR5_MAXNV>), b->stream, h->d_rec, P);
 #endif
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(ev1, b->stream));

@@ -847,13 +847,13 @@ int ur5_forward_debug(ur5_sim* h, double* out) {
   return rc;
 }
 #ifdef UR5_PROFILE
-// profile build only: per-env, per-phase cycle totals of the last launch ([n][16] host)
+// profile build only: per-env, per-phase cycle totals of the last launch ([n][18] host: 16 phases, shader cycles and 100 MHz ticks of the launch)
 int ur5_profile_read(ur5_sim* h, double* out) {
   UR5_FWD(profile_read, (h, out));
   std::vector<double> dbg((size_t)h->n * UR5_DEBUG_STRIDE);
   int rc = be_d2h(h, dbg.data(), h->d_debug, dbg.size() * 8);
   if (rc) return rc;
-  for (int e = 0; e < h->n; e++) memcpy(out + (size_t)e * 16, dbg.data() + (size_t)e * UR5_DEBUG_STRIDE, 16 * 8);
+  for (int e = 0; e < h->n; e++) memcpy(out + (size_t)e * 18, dbg.data() + (size_t)e * UR5_DEBUG_STRIDE, 18 * 8);
   return 0;
 }
 #endif
