@@ -309,6 +309,7 @@ template <class real, int NV_> struct Lds {
   real fs[NV_], as[NV_], x[NV_], Ma[NV_], grad[NV_], search[NV_], Mv[NV_], tmpv[NV_ + 4];
   // contacts
   int ncon, nsr, ncand, ncouple;
+  unsigned cplmask;              // bit k: object k takes part in a contact between two movable bodies; bit 31: one of them has a robot side
   unsigned long long bodymask;   // cbodies that carry at least one contact
   int cA[UR5_MAXCON], cB[UR5_MAXCON], cdim[UR5_MAXCON], cg1[UR5_MAXCON], cg2[UR5_MAXCON];
   short cand[UR5_MAXCAND];
@@ -1521,6 +1522,34 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       S.ceoff[c][0] += ckr;
     }
     SYNC();
+#if !defined(UR5_EMUL) && !defined(UR5_MANY)
+    {   // contacts between two movable bodies, compacted in contact order with a ballot; body / coupling masks with LDS atomics
+      static_assert(UR5_MAXCON <= 32, "one contact per lane of the smallest lane group");
+      if (UR5_LANE == 0) { S.bodymask = 0; S.cplmask = 0; }
+      SYNC();
+      const int c = UR5_LANE;
+      bool cp = false;
+      if (c < S.ncon) {
+        const int A = S.cA[c], B = S.cB[c];
+        cp = A >= 0 && B >= 0;
+        unsigned long long bm = 0;
+        if (A >= 0) bm |= 1ull << A;
+        if (B >= 0) bm |= 1ull << B;
+        if (bm) __hip_atomic_fetch_or(&S.bodymask, bm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (cp) {
+          unsigned cm = 0;
+          if (A >= M.nrd) cm |= 1u << (A - M.nrd);
+          if (B >= M.nrd) cm |= 1u << (B - M.nrd);
+          if ((A < M.nrd) != (B < M.nrd)) cm |= 1u << 31;
+          if (cm) __hip_atomic_fetch_or(&S.cplmask, cm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+      unsigned long long mask = __ballot(cp);
+      if constexpr (GS < 64) mask = (mask >> UR5_GBASE) & ((1ull << (GS & 63)) - 1ull);
+      if (cp) S.couple[__popcll(mask & ((1ull << UR5_LANE) - 1ull))] = c;
+      if (UR5_LANE == 0) S.ncouple = __popcll(mask);
+    }
+#else
     if (UR5_LANE == 0) {
       int nc = 0;
       unsigned long long bm = 0;
@@ -1532,6 +1561,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       S.ncouple = nc;
       S.bodymask = bm;
     }
+#endif
     SYNC();
 #ifdef UR5_MANY
     envelope_structure();
@@ -1961,12 +1991,31 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
 #pragma unroll
     for (int j = 0; j < N; j++) Lrow[j] = (lane < nv && j <= lane) ? S.H[UR5_HIDX(lane, j)] : (j == lane ? (real)1 : (real)0);
     real myinv = 1;
+    // Structure of H (dof order: robot 0-7, then 6 per object): an object that shares no contact with another movable body only has its
+    // own diagonal block; the others ("coupled": S.cplmask) may reach the robot columns (if any contact joins the robot and an object)
+    // and the blocks of earlier coupled objects (direct coupling or fill-in). Every skipped product has an exactly zero factor, so the
+    // result is the dense factorisation's, bit for bit; a box in the gripper needs ~140 of the 496 column products.
+    const unsigned cpl = S.cplmask;
 #pragma unroll
     for (int j = 0; j < N; j++) {
-      const int k0 = BLOCKDIAG ? (j < UR5_MAXRD ? 0 : UR5_MAXRD + 6 * ((j - UR5_MAXRD) / 6)) : 0;
+      const int bj = j < UR5_MAXRD ? -1 : (j - UR5_MAXRD) / 6;                      // compile-time after unrolling
+      const int kb = j < UR5_MAXRD ? 0 : UR5_MAXRD + 6 * bj;
       real sacc = Lrow[j];
+      if (!BLOCKDIAG && bj >= 0 && (cpl >> bj & 1u)) {
+        if (cpl >> 31) {
 #pragma unroll
-      for (int k = 0; k < j; k++) if (k >= k0) sacc -= Lrow[k] * bcast(Lrow[k], j);
+          for (int k = 0; k < UR5_MAXRD; k++) sacc -= Lrow[k] * bcast(Lrow[k], j);
+        }
+#pragma unroll
+        for (int c = 0; c < (N - UR5_MAXRD) / 6; c++) {
+          if (c < bj && (cpl >> c & 1u)) {
+#pragma unroll
+            for (int k = UR5_MAXRD + 6 * c; k < UR5_MAXRD + 6 * c + 6; k++) sacc -= Lrow[k] * bcast(Lrow[k], j);
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < j; k++) if (k >= kb) sacc -= Lrow[k] * bcast(Lrow[k], j);
       real djj = bcast(sacc, j);
       djj = djj < (real)1e-15 ? (real)1e-15 : djj;
       real inv = rsqrt(djj);
