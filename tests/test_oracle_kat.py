@@ -189,3 +189,44 @@ def test_console_png_vector(model_2f):
     assert np.allclose(w, g["world"], atol=1e-6)
     px = c.world_2_pixel(w)
     assert (int(px[0]), int(px[1])) == tuple(g["pixel"])
+
+
+def test_console_png_phase_counts_replayed(model_2f):
+    """media/console.png's five step counts (an older script version: see tests/golden/console_png.json "replay_note") replayed on the
+    shipped model: every move succeeds as recorded and each count is within a factor 2 of the recording (two of them within 15 %)."""
+    from oracle.oracle import Oracle
+    with open(os.path.join(GOLD, "console_png.json")) as f:
+        g = json.load(f)
+    x, y = g["world"][0], g["world"][1]
+    o = Oracle(model_2f)
+    o.reset(20, 1, True)
+    res, steps = [], []
+    r, n = o.move_ee([x, y, 1.1], 0.05, 1000); res.append(r); steps.append(n)
+    o.open_gripper(True)
+    r, n = o.move_ee([x, y, 0.91], 0.01, 300); res.append(r); steps.append(n)       # today's table top (0.91; 0.89 in the recording)
+    o.stay(100)
+    o.close_gripper(300)
+    r, n = o.move_ee([0.0, -0.6, 1.1], 0.05, 1000); res.append(r); steps.append(n)
+    r, n = o.move_ee([0.6, 0.0, 1.15], 0.01, 1200); res.append(r); steps.append(n)
+    o.close_gripper(1000)
+    res.append(o.open_gripper(False)); steps.append(o.last_steps)
+    assert res == [0, 0, 0, 0, 0], res                                               # "success" five times, as in the recording
+    ratio = np.array(steps, dtype=float) / np.array(g["phase_steps"], dtype=float)
+    assert np.all(ratio > 0.4) and np.all(ratio < 2.0), (steps, g["phase_steps"])
+    assert abs(ratio[0] - 1) < 0.15 and abs(ratio[1] - 1) < 0.15 and abs(ratio[4] - 1) < 0.2, ratio
+
+
+def test_depth_statistics_match_the_references_mean_and_std(model_2f):
+    """The reference holds ONE statistic of its rendered observations: mean_and_std (normalize.py:14-66), depth mean 1.5318 m / std 0.4265
+    over 100 resets. Pure geometry (camera, table, bins, floor, robot, object placement): pins reset + ray caster of the oracle."""
+    from oracle.oracle import Oracle
+    with open(os.path.join(GOLD, "mean_and_std.json")) as f:
+        ref = json.load(f)
+    o = Oracle(model_2f)
+    cam = model_2f.camera_name2id("top_down")
+    ds = []
+    for s in range(12):                                                              # 12 resets: the statistic varies by < 1e-3 between resets
+        o.reset(20 + s, 1, True)
+        ds.append(o.render(cam, 200, 200, 0)[1])
+    d = np.array(ds, dtype=np.float64)
+    assert abs(d.mean() - ref["mean"][3]) < 0.004 and abs(d.std() - ref["std"][3]) < 0.004, (d.mean(), d.std(), ref)

@@ -74,3 +74,20 @@ def test_render_on_gpu(model_it1):
     sim.render_dev(img.data_ptr(), dep.data_ptr(), 1, 200, 200, 0)
     sim.sync()
     assert np.array_equal(dep.cpu().numpy(), depth) and np.array_equal(img.cpu().numpy(), rgb)
+
+
+@pytest.mark.gpu
+def test_depth_statistics_of_100_resets_match_the_references_mean_and_std(model_2f):
+    """normalize.py:14-66 on the HIP path: 100 x reset_model + get_observation of the in-tree 6-object scene, depth mean / std against the
+    reference-held mean_and_std (1.5318 m / 0.4265). Geometry only: reset sampling, settle, forward kinematics, the ray caster."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mean_and_std.json")) as f:
+        ref = json.load(f)
+    n = 100
+    env = GraspEnv(file=model_2f, show_obs=False, n_envs=n, observation="render")   # the reference's loop, batched: 100 scenes, one reset
+    obs = env.reset()
+    d = np.asarray(obs["depth"], dtype=np.float64)
+    assert d.shape == (n, 200, 200)
+    assert abs(d.mean() - ref["mean"][3]) < 0.003 and abs(d.std() - ref["std"][3]) < 0.003, (d.mean(), d.std(), ref["mean"][3], ref["std"][3])
+    assert env.sim.counters()["status"].max() == 0
