@@ -79,6 +79,13 @@ def test_grasp_attempt_matches_oracle_and_golden(native_mod, model_it1):
         assert pso.tolist() == ps[e].tolist()
         rel = np.abs(s2["qpos"][e][:8] - so["qpos"][:8]).max() / max(1.0, np.abs(so["qpos"][:8]).max())
         assert rel < 1e-4
+        # the objects are joints too. Scene e aims at box e % 4: the three boxes it never touches must agree like the arm does; the aimed
+        # one is carried over the drop bin and released 0.5 m above its floor (check_mode 0) -- a free fall onto an edge that amplifies
+        # rounding-level differences (the kernel sums contacts in another order): centimetres are its chaos horizon, not a defect
+        eo = np.abs(s2["qpos"][e][8:] - so["qpos"][8:]).reshape(-1, 7)[:, :3].max(axis=1)
+        others = np.delete(eo, e % 4)
+        assert others.max() < 1e-6, (e, eo)
+        assert eo[e % 4] < 5e-2, (e, eo)
         agree += 1
     assert agree == 8 and set(np.unique(rew)) == {0, 1}
     assert np.all(sim.counters()["status"] == 0)
@@ -157,15 +164,19 @@ def test_grasp_bit_agreement_statistics(native_mod, model_it1):
     rots = np.arange(n) % 6
     rew, ps, pr = sim.grasp_attempt(acts, rot=rots, check_mode=1)
     s2 = sim.get_state()["qpos"]
-    agree, worst = 0, 0.0
+    agree, worst, worst_obj = 0, 0.0, 0.0
     for e in range(n):
         o = Oracle(m)
         o.reset(int(seeds[e]), 1, True)
         r, pso, pro = o.grasp_attempt(acts[e], int(rots[e]), 1)
         agree += int(r == rew[e])
-        worst = max(worst, np.abs(s2[e][:8] - o.get_state()["qpos"][:8]).max() / max(1.0, np.abs(o.get_state()["qpos"][:8]).max()))
+        so = o.get_state()["qpos"]
+        worst = max(worst, np.abs(s2[e][:8] - so[:8]).max() / max(1.0, np.abs(so[:8]).max()))
+        if pso.tolist() == ps[e].tolist():
+            worst_obj = max(worst_obj, np.abs(s2[e][8:] - so[8:]).max())
     assert agree == n                    # bit-exact grasp outcomes
     assert worst < 1e-4                  # north_star: joint trajectories within 1e-4 rel
+    assert worst_obj < 1e-5, worst_obj   # ... the object joints included (IT1: the grasped box is still in the gripper / on the plate at the end)
     assert 0.1 < rew.mean() < 0.95
 
 

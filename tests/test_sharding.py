@@ -53,3 +53,64 @@ def test_two_rank_gloo_gather_equals_single_process(emul_lib, model_it1, tmp_pat
     rew, ps, pr = sim.grasp_attempt(aimed_actions(sim.get_state()["qpos"], 4), rot=0, check_mode=0)
     assert rec[:, 0].tolist() == [0, 1, 2, 3] and rec[:, 3].tolist() == rew.tolist()
     assert got[16:].astype(int).tolist() == ps[:2].ravel().tolist()       # rank 0's scenes: same step counts as the 1-rank run
+
+
+def _gpu_worker(rank, world, port, n_total, out):
+    """One rank of the real multi-GPU path, except that every rank sits on device 0 (the test box has one GPU) and the collective runs over
+    gloo: bench.py's round driver on the rank's shard with the real libur5sim.so."""
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from mujoco_rl_ur5_amd.model import load_model
+    from mujoco_rl_ur5_amd.native import BatchSim
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    m = load_model("it1_4box")
+    lo, hi = sharding.shard_range(n_total, rank, world)
+    sim = BatchSim(m, hi - lo, device_id=0)
+    sim.reset(sharding.global_seeds(bench.BASE_SEED, n_total, rank, world), 1, 1000.0)
+    sim.set_stream(torch.cuda.current_stream().cuda_stream)
+    wl = bench.It1Rounds(torch, m, sim, dev, lo, hi - lo, n_total, "aimed")
+    ids = torch.arange(lo, hi, dtype=torch.int32, device=dev)
+    recs = []
+    for r in range(5):                                                   # crosses an episode boundary for every scene
+        flags, seeds = wl.reset_flags(r)
+        sim.reset_dev(seeds.data_ptr(), flags.data_ptr(), 1000.0)
+        act, pixel = wl.actions(r)
+        rew = torch.zeros(hi - lo, dtype=torch.int32, device=dev)
+        sim.grasp_attempt_dev(act.data_ptr(), rew.data_ptr(), check_mode=1)
+        rec = torch.stack([ids, pixel, act[:, 3].to(torch.int32), rew], dim=1)
+        recs.append(sharding.gather_outcomes(rec).cpu().numpy())         # [n_total, 4] on every rank, ordered by scene id
+    sim.sync()
+    state = sim.get_state()["qpos"]
+    if world > 1:
+        parts = [None] * world
+        dist.all_gather_object(parts, state)
+        state = np.concatenate(parts)
+        dist.barrier()
+    if rank == 0:
+        np.savez(out, recs=np.stack(recs), state=state)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_equal_one_rank_bit_for_bit(tmp_path):
+    """results must not depend on how the batch is sharded. 1 x 64 scenes and 2 x 32 scenes (both ranks on device 0,
+    gloo collective) through bench.py's stationary round driver: identical outcome records (scene id, pixel, rotation, reward) in every
+    round and bit-identical final states."""
+    import torch.multiprocessing as mp
+    n_total = 64
+    port = 29500 + (os.getpid() % 2000)
+    one, two = str(tmp_path / "one.npz"), str(tmp_path / "two.npz")
+    mp.spawn(_gpu_worker, args=(1, port, n_total, one), nprocs=1, join=True)
+    mp.spawn(_gpu_worker, args=(2, port + 1, n_total, two), nprocs=2, join=True)
+    a, b = np.load(one), np.load(two)
+    assert a["recs"].shape == (5, n_total, 4) and np.array_equal(a["recs"], b["recs"])
+    assert np.array_equal(a["state"], b["state"])
+    assert a["recs"][:, :, 1].max() > 0 and set(np.unique(a["recs"][:, :, 3])) == {0, 1}      # pixel field filled, both outcomes occur
