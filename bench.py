@@ -7,17 +7,19 @@ closing check (README.md:20 of the reference). A "step" is one grasp-attempt rou
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Workload (stationary by construction, stated in the JSON line as config.rule):
-  * every scene lives through episodes of EP = 4 rounds: reset_model (objects re-sampled from the scene's SplitMix64 stream, arm to
-    home, 1000 ms settle) and then one grasp attempt per round. Scene g starts its episodes at rounds r with (r + g) % 4 == 0, so in
-    every round exactly a quarter of the batch resets: the mix of settling / full-bin / nearly-empty-bin scenes is the same in every
-    round, warm-up or timed.
+  * every scene lives through episodes of EP = 4 rounds: one grasp attempt per round, and after the last one reset_model (objects
+    re-sampled from the scene's SplitMix64 stream, arm to home, 1000 ms settle). Scene g ends an episode in the rounds r with
+    (r + 1 + g) % 4 == 0, so in every round exactly a quarter of the batch resets: the mix of settling / full-plate / nearly-empty-plate
+    scenes is the same in every round, warm-up or timed. Attempt and reset of a scene run in ONE launch (ur5_grasp_attempt_reset_dev).
   * rule "aimed" (headline): in round j of its episode scene g aims at the CURRENT position of the first of boxes (g + j + i) % 4,
     i = 0.., that still lies on the pick plate (read from the engine's state records on the device), z = 0.91, rotation cycling;
     an empty plate gets an attempt at its centre.
   * rule "uniform" (second figure, SURVEY.md section 8d's own rule): a uniformly drawn pixel of the 200x200 top-down image whose
     back-projection lies on the table (the agent's rejection rule, Grasping_Agent_multidiscrete.py:266-280), rotation 0, z = 0.91.
-Everything a round needs (seeds, flags, action records) is produced on the device on the SAME HIP stream as the engine's kernels
-(ur5_set_stream): no host synchronisation inside a round except the outcome all_gather's own.
+Everything a round needs (seeds, action records, dispatch order) is produced on the device on the SAME HIP stream as the engine's
+kernel (ur5_set_stream): no host synchronisation inside a round except the outcome all_gather's own. A launch ends with its slowest
+scene, so scenes are dispatched longest-expected-first (ur5_set_order_dev): episode-ending scenes (attempt + 500 settle steps), then
+scenes with a box to carry, then attempts on an empty plate. The order changes the makespan only, never a result.
 
 Prints ONE JSON line on rank 0. value = env-steps/s of the whole job (2 ms physics steps actually executed, summed over all scenes
 and ranks, / max-over-ranks wall time of the K timed rounds); grasp-attempts/s next to it. N > 1: scenes shard over ranks
@@ -69,17 +71,30 @@ class It1Rounds:
             self.table_pixels = torch.from_numpy(np.flatnonzero(ok.ravel())).to(dev)       # flat index = y * 200 + x
             self.gen = torch.Generator(device=dev).manual_seed(BASE_SEED)
 
-    def reset_flags(self, r):
-        """(flags uint8 [n], seeds int64 [n]) for round r: scene g starts an episode when (r + g) % EP == 0 (not at r = 0: the
-        untimed reset before the first round already is episode 0)."""
-        torch = self.torch
-        k = self.gid + r
-        flags = ((k % EP) == 0) & torch.tensor(r > 0, device=k.device)
+    def reset_seeds(self, r):
+        """int64 [n] (read as uint64 by the engine): the seed of the episode that scene g starts after round r's attempt when
+        (r + 1 + g) % EP == 0, else 0 = no reset. Episode 0 is the untimed reset before the first round."""
+        k = self.gid + r + 1
         seeds = BASE_SEED + self.gid + self.n_total * (k // EP)                  # == sharding.global_seeds(20, n_total, ..., episode)
-        return flags.to(torch.uint8), seeds
+        return self.torch.where((k % EP) == 0, seeds, self.torch.zeros_like(seeds))
+
+    def launch(self, r, reward_row, check_mode=1):
+        """One round on the engine's stream: action records from the current state, longest-expected-first dispatch order, ONE launch of
+        attempt (+ episode reset). Returns (action records [n, 8], aimed pixel [n])."""
+        torch = self.torch
+        seeds = self.reset_seeds(r)
+        act, pixel, any_on = self.actions(r)
+        est = torch.where(any_on, 2300, 1300) + torch.where(seeds != 0, 500, 0)   # expected physics steps of the scene in this launch
+        order = torch.argsort(est, descending=True, stable=True).to(torch.int32)
+        self.sim.set_order_dev(order.data_ptr())
+        self.sim.grasp_attempt_reset_dev(act.data_ptr(), reward_row.data_ptr(), seeds.data_ptr(), check_mode=check_mode, table_height=0.91,
+                                         settle_ms=1000.0)
+        self._alive = (seeds, act, order)                                        # until the next round's launch is queued behind this one
+        return act, pixel
 
     def actions(self, r):
-        """[n, 8] f64 action records (x y z rot skip - - -) and the aimed pixel index [n] int32, from the CURRENT state on the device."""
+        """[n, 8] f64 action records (x y z rot skip - - -), the aimed pixel index [n] int32 and whether a box is aimed at [n] bool, from the
+        CURRENT state on the device."""
         torch = self.torch
         a = torch.zeros((self.n, 8), dtype=torch.float64, device=self.gid.device)
         a[:, 2] = 0.91
@@ -97,12 +112,13 @@ class It1Rounds:
             a[:, :2] = torch.where(any_on[:, None], xy, centre)
             a[:, 3] = ((self.gid // EP + r) % 6).double()
         else:
+            any_on = torch.zeros(self.n, dtype=torch.bool, device=self.gid.device)   # a uniformly drawn pixel rarely has a box under it
             idx = self.table_pixels[torch.randint(len(self.table_pixels), (self.n,), device=self.gid.device, generator=self.gen)]
             a[:, 0] = self.px0[0] + self.dxdpx * (idx % 200).double()
             a[:, 1] = self.px0[1] + self.dydpy * (idx // 200).double()
         px = ((a[:, 0] - self.px0[0]) / self.dxdpx).round().clamp(0, 199)
         py = ((a[:, 1] - self.px0[1]) / self.dydpy).round().clamp(0, 199)
-        return a, (py * 200 + px).to(torch.int32)
+        return a, (py * 200 + px).to(torch.int32), any_on
 
 
 def cpu_baseline(model, budget_s=12.0, many=False):
@@ -228,10 +244,7 @@ def main():
 
     def run_rounds(wl, r0, r1, reward):
         for r in range(r0, r1):
-            flags, seeds = wl.reset_flags(r)
-            sim.reset_dev(seeds.data_ptr(), flags.data_ptr(), 1000.0)              # reset_model of the scenes starting an episode, then their settle
-            act, pixel = wl.actions(r)                                             # stream-ordered after the settle launch
-            sim.grasp_attempt_dev(act.data_ptr(), reward[r].data_ptr(), check_mode=1, table_height=0.91)
+            act, pixel = wl.launch(r, reward[r])                                   # attempt (+ reset_model for the scenes whose episode ends)
             rec = torch.stack([ids, pixel, act[:, 3].to(torch.int32), reward[r]], dim=1)
             gathered = sharding.gather_outcomes(rec)                               # the path's only collective: 16 B per scene per round
         return gathered
@@ -302,8 +315,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                          "traffic_source": traffic_src, "kernel": "ur5_run_kernel<32>", "bytes_per_env_step": bytes_per_step,
                          "kernel_ms_per_round": kernel_ms / args.steps, "env_steps_per_round": steps_local / args.steps,
-                         "note": "algorithmic state bytes x env-steps / summed HIP-event time of the engine kernels of the timed rounds (settle + "
-                                 "grasp launches, rank 0). A scene stays in LDS for a whole launch, so the algorithmic figure is an accounting "
+                         "note": "algorithmic state bytes x env-steps / summed HIP-event time of the engine kernels of the timed rounds (one "
+                                 "attempt + episode-reset launch per round, rank 0). A scene stays in LDS for a whole launch, so the algorithmic figure is an accounting "
                                  "unit, not the traffic: the step is latency / VALU-issue bound (DESIGN.md section 3)"},
         }
         if world == 1 and not args.no_extras:

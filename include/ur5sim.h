@@ -78,6 +78,15 @@ int ur5_grasp_attempt(ur5_sim* h, const double* action, const uint8_t* skip, int
 /* same with HIP device pointers: action_dev [n][8] doubles (x y z rot skip - - -), reward_dev [n] int32; asynchronous.
    skip != 0: the scene sits the launch out with reward 0 -- GraspEnv.step's rule for targets off the table (GraspingEnv.py:124-131) */
 int ur5_grasp_attempt_dev(ur5_sim* h, const double* action_dev, int check_mode, double table_height, int* reward_dev);
+/* GraspEnv.step followed, for the scenes whose episode ends with it, by GraspEnv.reset_model (GraspingEnv.py:409-477) in the SAME launch:
+   reset_seeds_dev[n] uint64 (device; 0 = the scene does not reset, NULL = none does) seeds the re-sampling exactly as ur5_reset /
+   ur5_reset_dev do, then the scene settles for settle_ms. The reward is the attempt's. Saves the separate, poorly filled settle launch. */
+int ur5_grasp_attempt_reset_dev(ur5_sim* h, const double* action_dev, int check_mode, double table_height, int* reward_dev,
+                                const uint64_t* reset_seeds_dev, double settle_ms);
+/* Dispatch order of the following grasp-attempt / settle launches: order_dev[n] int32 (HIP device pointer, caller-owned, must stay valid
+   until changed) is a permutation of the scene ids; the engine starts scenes in that order. Results do not depend on it -- only the
+   makespan does: a launch ends with its slowest scene, so callers list the scenes with the most work first. NULL = scene order. */
+int ur5_set_order_dev(ur5_sim* h, const int* order_dev);
 int ur5_sync(ur5_sim* h);
 /* Queue the handle's launches on a caller-owned HIP stream (hipStream_t, e.g. torch.cuda.current_stream().cuda_stream) so that the
    caller's own device work (action tensors, the CNN) is ordered with them without host synchronisation. external = 1: use hip_stream

@@ -103,6 +103,52 @@ struct Ur5DevModel {
   double timestep, tolerance, impratio, gravity[3], jnt_solref[2], jnt_solimp[5], meaninertia;
 };
 
+#include <stdint.h>
+#include <math.h>
+#if defined(__HIPCC__)
+#define UR5_HD __host__ __device__
+#else
+#define UR5_HD
+#endif
+struct Ur5SplitMix {
+  uint64_t s;
+  UR5_HD uint64_t next() {
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+  }
+  UR5_HD double uniform() { return (double)(next() >> 11) * (1.0 / 9007199254740992.0); }
+  UR5_HD double uniform(double lo, double hi) { return lo + (hi - lo) * uniform(); }
+};
+
+// GraspEnv.reset_model (GraspingEnv.py:409-477) for ONE scene record: MujocoEnv.reset() -> sim.reset() [3P] (qpos0, zero velocity /
+// warm start / ctrl / time; the controller's PID state persists), arm teleported to the home pose (:418), objects re-sampled from
+// the scene's own SplitMix64 stream (:420-430 free-joint piles; :435-463 the IT4 slide+ball objects). Shared by the host path
+// (ur5_reset) and the device path (ur5_reset_dev) so that both produce the same record.
+UR5_HD inline void ur5_reset_record(const Ur5DevModel& M, const double* qpos0, double* r, uint64_t seed) {
+  const double home[7] = {0, -1.57, 1.57, -1.57, -1.57, 0.0, 0.3};   // GraspingEnv.py:418
+  for (int i = 0; i < M.nq; i++) r[UR5_REC_QPOS + i] = qpos0[i];
+  for (int i = 0; i < M.nv; i++) { r[UR5_REC_QVEL + i] = 0; r[UR5_REC_WARM + i] = 0; }
+  for (int a = 0; a < M.nu; a++) { r[UR5_REC_CTRL + a] = 0; r[UR5_REC_QPOS + M.act_dof[a]] = home[a]; r[UR5_REC_TARGET + a] = home[a]; }
+  r[UR5_REC_MISC + 2] = 0; r[UR5_REC_MISC + 3] = 0;
+  Ur5SplitMix rng{seed};
+  const double two_pi = 6.283185307179586476925286766559;
+  for (int k = 0; k < M.nobj; k++) {
+    double* q = r + UR5_REC_QPOS + M.nrd + 7 * k;
+    if (M.obj_kind[k] == 1) {  // GraspingEnv.py:420-430
+      q[0] = rng.uniform(-0.25, 0.25); q[1] = rng.uniform(-0.77, -0.43); q[2] = rng.uniform(1.0, 1.5);
+      double r1 = rng.uniform(), r2 = rng.uniform(), r3 = rng.uniform();
+      q[3] = sqrt(1.0 - r1) * sin(two_pi * r2); q[4] = sqrt(1.0 - r1) * cos(two_pi * r2);
+      q[5] = sqrt(r1) * sin(two_pi * r3); q[6] = sqrt(r1) * cos(two_pi * r3);
+    } else {                   // GraspingEnv.py:435-463 (IT4)
+      q[0] = rng.uniform(-0.25, 0.25); q[1] = rng.uniform(-0.17, 0.17); q[2] = 0.0;
+      q[3] = 1; q[4] = q[5] = q[6] = 0;
+    }
+  }
+}
+
+
 // run-time parameters of one launch (wave-uniform unless per-env arrays are given)
 enum { UR5_OP_MOVE = 0, UR5_OP_STAY = 1, UR5_OP_MOVE_EE = 2, UR5_OP_GRASP = 3, UR5_OP_STEP = 4, UR5_OP_FORWARD = 5, UR5_OP_IK = 6 };
 struct Ur5Launch {
@@ -121,6 +167,11 @@ struct Ur5Launch {
   double* out;                  // [n][8] (IK: 5 joint angles)
   double* debug;                // optional [n][UR5_DEBUG_STRIDE] introspection dump (FORWARD)
   double* hess;                 // many-object variant: [n][UR5_HESS_STRIDE] envelope storage of the Newton Hessian / its factor
+  // GRASP: scenes whose reset_seeds entry is non-zero end the launch with GraspEnv.reset_model (ur5_reset_record + reset_chunks x 10 settle steps)
+  const uint64_t* reset_seeds;  // optional [n]
+  const double* qpos0;          // model reference pose [nq] (device), needed with reset_seeds
+  int reset_chunks;
+  const int* order;             // optional [n] permutation: workgroup slot i simulates scene order[i] (longest-first dispatch, ur5_set_order_dev)
 };
 #ifndef UR5_MANY
 #define UR5_DEBUG_STRIDE 2048

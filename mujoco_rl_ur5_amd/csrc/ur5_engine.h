@@ -2925,10 +2925,18 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
               break;
             case 18:  // :345 rotate back
               write_target(5, (real)0); pr.mask = mask_all(); pr.tol = (real)0.05; pr.max_steps = 500; slot = 11; break;
-            default:  // :347
+            case 19:  // :347; then, for a scene whose episode ends here, GraspEnv.reset_model (GraspingEnv.py:409-477) inside the same launch
               write_kp0(20);
               result = grasped ? 1 : 0;
-              pr.done = true; break;
+              if (P.reset_seeds && P.reset_seeds[env] != 0) {
+                SYNC();
+                if (UR5_LANE == 0) ur5_reset_record(M, P.qpos0, S.rec, P.reset_seeds[env]);
+                SYNC();
+                pr.mask = mask_all(); pr.tol = (real)1e-7; pr.max_steps = 10; pr.repeat = P.reset_chunks;   // :473 stay(1000)
+                if (pr.repeat <= 0) pr.done = true;
+              } else pr.done = true;
+              break;
+            default: pr.done = true; break;
           }
         }
       } else if (op == UR5_OP_STEP) {
@@ -3126,10 +3134,18 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
                   break;
                 case 18:  // :345 rotate back
                   write_target(5, (real)0); pr.mask = mask_all(); pr.tol = (real)0.05; pr.max_steps = 500; slot = 11; break;
-                default:  // :347
+                case 19:  // :347; then, for a scene whose episode ends here, GraspEnv.reset_model (GraspingEnv.py:409-477) inside the same launch
                   write_kp0(20);
                   result = grasped ? 1 : 0;
-                  pr.done = true; break;
+                  if (P.reset_seeds && P.reset_seeds[env] != 0) {
+                    SYNC();
+                    if (UR5_LANE == 0) ur5_reset_record(M, P.qpos0, S.rec, P.reset_seeds[env]);
+                    SYNC();
+                    pr.mask = mask_all(); pr.tol = (real)1e-7; pr.max_steps = 10; pr.repeat = P.reset_chunks;   // :473 stay(1000)
+                    if (pr.repeat <= 0) pr.done = true;
+                  } else pr.done = true;
+                  break;
+                default: pr.done = true; break;
               }
             }
           } else if (op == UR5_OP_STEP) {

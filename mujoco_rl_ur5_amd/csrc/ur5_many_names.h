@@ -25,7 +25,9 @@
 #define ur5_ik ur5m_ik
 #define ur5_grasp_attempt ur5m_grasp_attempt
 #define ur5_grasp_attempt_dev ur5m_grasp_attempt_dev
+#define ur5_grasp_attempt_reset_dev ur5m_grasp_attempt_reset_dev
 #define ur5_sync ur5m_sync
+#define ur5_set_order_dev ur5m_set_order_dev
 #define ur5_set_stream ur5m_set_stream
 #define ur5_last_launch_ms ur5m_last_launch_ms
 #define ur5_get_counters ur5m_get_counters

@@ -27,8 +27,11 @@
 #endif
 template <int NV, int GS>
 __global__ void UR5_KERNEL_ATTR(GS) ur5_run_kernel(double* __restrict__ rec, Ur5Launch P) {
-  const int env = blockIdx.x * (UR5_NT / GS) + (int)threadIdx.x / GS;
-  const bool live = env < P.n_env;                 // a half-filled last workgroup: the lanes of the missing scene idle
+  const int slot = blockIdx.x * (UR5_NT / GS) + (int)threadIdx.x / GS;
+  const bool live = slot < P.n_env;                // a half-filled last workgroup: the lanes of the missing scene idle
+  // workgroups are dispatched in blockIdx order: a caller that knows which scenes have the most work ahead of them (an episode reset to
+  // settle first, a box to carry) lists those first, so that the short ones fill the tail of the launch
+  const int env = (live && P.order) ? P.order[slot] : slot;
   ur5::Engine<double, NV, GS> eng;
   double* r = rec + (size_t)(live ? env : 0) * UR5_REC_STRIDE;
   if (live) eng.load(r, P.pid_dt, P.contacts_enabled);

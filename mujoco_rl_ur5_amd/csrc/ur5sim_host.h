@@ -389,48 +389,8 @@ static int build_model(const void* data, size_t nbytes, int ee_body, Ur5DevModel
 static const double PID_KP[7] = {7 * 3.0, 10 * 3.0, 5 * 3.0, 7 * 3.0, 5 * 3.0, 5 * 3.0, 2.5 * 3.0};
 static const double PID_SP[7] = {0, -1.57, 1.57, -1.57, -1.57, 0, 0};
 
-#if defined(__HIPCC__)
-#define UR5_HD __host__ __device__
-#else
-#define UR5_HD
-#endif
-struct SplitMix {
-  uint64_t s;
-  UR5_HD uint64_t next() {
-    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-  }
-  UR5_HD double uniform() { return (double)(next() >> 11) * (1.0 / 9007199254740992.0); }
-  UR5_HD double uniform(double lo, double hi) { return lo + (hi - lo) * uniform(); }
-};
-
-// GraspEnv.reset_model (GraspingEnv.py:409-477) for ONE scene record: MujocoEnv.reset() -> sim.reset() [3P] (qpos0, zero velocity /
-// warm start / ctrl / time; the controller's PID state persists), arm teleported to the home pose (:418), objects re-sampled from
-// the scene's own SplitMix64 stream (:420-430 free-joint piles; :435-463 the IT4 slide+ball objects). Shared by the host path
-// (ur5_reset) and the device path (ur5_reset_dev) so that both produce the same record.
-UR5_HD inline void reset_record(const Ur5DevModel& M, const double* qpos0, double* r, uint64_t seed) {
-  const double home[7] = {0, -1.57, 1.57, -1.57, -1.57, 0.0, 0.3};   // GraspingEnv.py:418
-  for (int i = 0; i < M.nq; i++) r[UR5_REC_QPOS + i] = qpos0[i];
-  for (int i = 0; i < M.nv; i++) { r[UR5_REC_QVEL + i] = 0; r[UR5_REC_WARM + i] = 0; }
-  for (int a = 0; a < M.nu; a++) { r[UR5_REC_CTRL + a] = 0; r[UR5_REC_QPOS + M.act_dof[a]] = home[a]; r[UR5_REC_TARGET + a] = home[a]; }
-  r[UR5_REC_MISC + 2] = 0; r[UR5_REC_MISC + 3] = 0;
-  SplitMix rng{seed};
-  const double two_pi = 6.283185307179586476925286766559;
-  for (int k = 0; k < M.nobj; k++) {
-    double* q = r + UR5_REC_QPOS + M.nrd + 7 * k;
-    if (M.obj_kind[k] == 1) {  // GraspingEnv.py:420-430
-      q[0] = rng.uniform(-0.25, 0.25); q[1] = rng.uniform(-0.77, -0.43); q[2] = rng.uniform(1.0, 1.5);
-      double r1 = rng.uniform(), r2 = rng.uniform(), r3 = rng.uniform();
-      q[3] = sqrt(1.0 - r1) * sin(two_pi * r2); q[4] = sqrt(1.0 - r1) * cos(two_pi * r2);
-      q[5] = sqrt(r1) * sin(two_pi * r3); q[6] = sqrt(r1) * cos(two_pi * r3);
-    } else {                   // GraspingEnv.py:435-463 (IT4)
-      q[0] = rng.uniform(-0.25, 0.25); q[1] = rng.uniform(-0.17, 0.17); q[2] = 0.0;
-      q[3] = 1; q[4] = q[5] = q[6] = 0;
-    }
-  }
-}
+using ::Ur5SplitMix;
+UR5_HD inline void reset_record(const Ur5DevModel& M, const double* qpos0, double* r, uint64_t seed) { ur5_reset_record(M, qpos0, r, seed); }
 
 }  // namespace ur5host
 
@@ -451,6 +411,7 @@ struct ur5_sim {
   size_t img_cap = 0;
   unsigned* d_mask = nullptr;
   double *d_target = nullptr, *d_tol = nullptr, *d_debug = nullptr, *d_hess = nullptr, *d_qpos0 = nullptr;
+  const int* d_order = nullptr;   // caller-owned dispatch order of the scripted launches (ur5_set_order_dev), NULL = scene order
   double kernel_ms_total = 0;   // engine-kernel time of every launch since ur5_create (HIP events on the handle's stream)
   int *d_max = nullptr, *d_result = nullptr, *d_steps = nullptr, *d_ps = nullptr, *d_pr = nullptr;
   std::vector<double> h_rec;
@@ -479,6 +440,7 @@ static Ur5Launch base_launch(ur5_sim* h, int op) {
   memset(&P, 0, sizeof P);
   P.op = op; P.n_env = h->n; P.contacts_enabled = h->contacts_enabled; P.pid_dt = h->pid_dt; P.table_height = 0.91;
   P.hess = h->d_hess;
+  P.order = (op == UR5_OP_GRASP || op == UR5_OP_STAY) ? h->d_order : nullptr;
 #ifdef UR5_PROFILE
   if (!h->d_debug) h->d_debug = (double*)be_alloc(h, (size_t)h->n * UR5_DEBUG_STRIDE * 8);
   P.debug = h->d_debug;
@@ -486,6 +448,12 @@ static Ur5Launch base_launch(ur5_sim* h, int op) {
   return P;
 }
 template <class T> static int upload(ur5_sim* h, T* dst, const T* src, size_t count) { return be_h2d(h, dst, src, count * sizeof(T)); }
+static int ensure_qpos0(ur5_sim* h) {
+  if (h->d_qpos0) return 0;
+  h->d_qpos0 = (double*)be_alloc(h, h->qpos0.size() * 8);
+  if (!h->d_qpos0) return fail(UR5_ERR_DEVICE, "device allocation failed (qpos0)");
+  return be_h2d(h, h->d_qpos0, h->qpos0.data(), h->qpos0.size() * 8);
+}
 }  // namespace ur5host
 
 // One library, two engines: this header is compiled twice. The many-object translation unit (-DUR5_MANY, ur5sim_many.hip)
@@ -511,11 +479,12 @@ int ur5m_reset_dev(ur5_sim* h, const uint64_t* seeds_dev, const uint8_t* mask_de
 int ur5m_move_group(ur5_sim* h, const uint32_t* mask, const double* target, const double* tol, const int* max_steps, int* result, int* steps);
 int ur5m_move_ee(ur5_sim* h, const double* xyz, const double* tol, const int* max_steps, int* result, int* steps);
 int ur5m_grasp_attempt_dev(ur5_sim* h, const double* action_dev, int check_mode, double table_height, int* reward_dev);
+int ur5m_grasp_attempt_reset_dev(ur5_sim* h, const double* action_dev, int check_mode, double table_height, int* reward_dev, const uint64_t* reset_seeds_dev, double settle_ms);
 int ur5m_grasp_attempt(ur5_sim* h, const double* action, const uint8_t* skip, int check_mode, double table_height, int* reward, int* phase_steps, int* phase_result);
 int ur5m_ik(ur5_sim* h, const double* xyz, double* q5, int* result);
 int ur5m_render_dev(ur5_sim* h, int camera_id, int width, int height, int depth_mode, uint8_t* rgb_dev, float* depth_dev);
 int ur5m_render(ur5_sim* h, int camera_id, int width, int height, int depth_mode, uint8_t* rgb, float* depth);
-int ur5m_sync(ur5_sim* h); int ur5m_set_stream(ur5_sim* h, void* s, int external); double ur5m_last_launch_ms(ur5_sim* h); void* ur5m_state_device_ptr(ur5_sim* h);
+int ur5m_sync(ur5_sim* h); int ur5m_set_order_dev(ur5_sim* h, const int* order_dev); int ur5m_set_stream(ur5_sim* h, void* s, int external); double ur5m_last_launch_ms(ur5_sim* h); void* ur5m_state_device_ptr(ur5_sim* h);
 int ur5m_forward_debug(ur5_sim* h, double* out); int ur5m_body_xpos(ur5_sim* h, double* out); int ur5m_profile_read(ur5_sim* h, double* out);
 }
 #endif
@@ -694,12 +663,7 @@ int ur5_reset_dev(ur5_sim* h, const uint64_t* seeds_dev, const uint8_t* mask_dev
   UR5_FWD(reset_dev, (h, seeds_dev, mask_dev, settle_ms));
   using namespace ur5host;
   if (!seeds_dev) return fail(UR5_ERR_ARG, "ur5_reset_dev: seeds_dev is NULL");
-  if (!h->d_qpos0) {
-    h->d_qpos0 = (double*)be_alloc(h, h->qpos0.size() * 8);
-    if (!h->d_qpos0) return fail(UR5_ERR_DEVICE, "device allocation failed (qpos0)");
-    int rc0 = be_h2d(h, h->d_qpos0, h->qpos0.data(), h->qpos0.size() * 8);
-    if (rc0) return rc0;
-  }
+  { int rc0 = ensure_qpos0(h); if (rc0) return rc0; }
   const int chunks = settle_ms > 0 ? (int)std::ceil(settle_ms / 1000.0 / h->hm.timestep / 10.0 - 1e-9) : 0;
   int rc = be_reset_dev(h, seeds_dev, mask_dev, chunks, h->d_max);   // samples the flagged records, d_max[e] = flagged ? chunks : 0
   if (rc || chunks == 0) return rc;
@@ -758,14 +722,24 @@ int ur5_move_ee(ur5_sim* h, const double* xyz, const double* tol, const int* max
   return rc;
 }
 
-int ur5_grasp_attempt_dev(ur5_sim* h, const double* action_dev, int check_mode, double table_height, int* reward_dev) {
-  UR5_FWD(grasp_attempt_dev, (h, action_dev, check_mode, table_height, reward_dev));
+int ur5_grasp_attempt_reset_dev(ur5_sim* h, const double* action_dev, int check_mode, double table_height, int* reward_dev,
+                                const uint64_t* reset_seeds_dev, double settle_ms) {
+  UR5_FWD(grasp_attempt_reset_dev, (h, action_dev, check_mode, table_height, reward_dev, reset_seeds_dev, settle_ms));
   using namespace ur5host;
   if (!action_dev || !reward_dev) return fail(UR5_ERR_ARG, "ur5_grasp_attempt_dev: NULL pointer");
   Ur5Launch P = base_launch(h, UR5_OP_GRASP);
   P.target = action_dev; P.check_mode = check_mode; P.table_height = table_height;
   P.result = reward_dev; P.steps = h->d_steps; P.phase_steps = h->d_ps; P.phase_result = h->d_pr;
+  if (reset_seeds_dev) {
+    int rc = ensure_qpos0(h);
+    if (rc) return rc;
+    P.reset_seeds = reset_seeds_dev; P.qpos0 = h->d_qpos0;
+    P.reset_chunks = settle_ms > 0 ? (int)std::ceil(settle_ms / 1000.0 / h->hm.timestep / 10.0 - 1e-9) : 0;
+  }
   return be_launch(h, P);
+}
+int ur5_grasp_attempt_dev(ur5_sim* h, const double* action_dev, int check_mode, double table_height, int* reward_dev) {
+  return ur5_grasp_attempt_reset_dev(h, action_dev, check_mode, table_height, reward_dev, nullptr, 0.0);
 }
 int ur5_grasp_attempt(ur5_sim* h, const double* action, const uint8_t* skip, int check_mode, double table_height, int* reward, int* phase_steps, int* phase_result) {
   UR5_FWD(grasp_attempt, (h, action, skip, check_mode, table_height, reward, phase_steps, phase_result));
@@ -823,6 +797,8 @@ int ur5_render(ur5_sim* h, int camera_id, int width, int height, int depth_mode,
   if (!rc) rc = be_d2h(h, depth, h->d_depth, px * 4);
   return rc;
 }
+int ur5_set_order_dev(ur5_sim* h, const int* order_dev) {
+  UR5_FWD(set_order_dev, (h, order_dev)); h->d_order = order_dev; return 0; }
 int ur5_sync(ur5_sim* h) {
   UR5_FWD(sync, (h)); return be_sync(h); }
 int ur5_set_stream(ur5_sim* h, void* hip_stream, int external) {

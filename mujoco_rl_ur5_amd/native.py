@@ -19,7 +19,7 @@ RES_NONE, RES_SUCCESS, RES_MAX_STEPS, RES_IK_FAIL = -1, 0, 1, 2
 _VARIANT = {0: (6, 2048, 192, 30), 1: (40, 4096, 832, 160)}
 EXPORTS = ["ur5_last_error", "ur5_create", "ur5_destroy", "ur5_num_envs", "ur5_nq", "ur5_nv", "ur5_nu", "ur5_reset", "ur5_reset_dev", "ur5_kernel_ms_total",
            "ur5_set_state", "ur5_get_state", "ur5_set_ctrl", "ur5_get_ctrl", "ur5_step", "ur5_move_group", "ur5_stay",
-           "ur5_move_ee", "ur5_ik", "ur5_grasp_attempt", "ur5_grasp_attempt_dev", "ur5_sync", "ur5_set_stream", "ur5_last_launch_ms",
+           "ur5_move_ee", "ur5_ik", "ur5_grasp_attempt", "ur5_grasp_attempt_dev", "ur5_grasp_attempt_reset_dev", "ur5_sync", "ur5_set_stream", "ur5_set_order_dev", "ur5_last_launch_ms",
            "ur5_get_counters", "ur5_body_xpos", "ur5_render", "ur5_render_dev", "ur5_state_device_ptr", "ur5_forward_debug"]
 
 
@@ -48,6 +48,7 @@ def load(path=None):
         getattr(L, f).argtypes = [vp]
     L.ur5_reset.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int, C.c_double]
     L.ur5_set_stream.argtypes = [vp, vp, C.c_int]
+    L.ur5_set_order_dev.argtypes = [vp, vp]
     L.ur5_reset_dev.argtypes = [vp, vp, vp, C.c_double]
     L.ur5_kernel_ms_total.argtypes = [vp]
     L.ur5_kernel_ms_total.restype = C.c_double
@@ -62,6 +63,7 @@ def load(path=None):
     L.ur5_ik.argtypes = [vp, dp, dp, ip]
     L.ur5_grasp_attempt.argtypes = [vp, dp, C.POINTER(C.c_uint8), C.c_int, C.c_double, ip, ip, ip]
     L.ur5_grasp_attempt_dev.argtypes = [vp, vp, C.c_int, C.c_double, vp]
+    L.ur5_grasp_attempt_reset_dev.argtypes = [vp, vp, C.c_int, C.c_double, vp, vp, C.c_double]
     L.ur5_last_launch_ms.argtypes = [vp]
     L.ur5_last_launch_ms.restype = C.c_double
     L.ur5_get_counters.argtypes = [vp, C.POINTER(C.c_int64)]
@@ -212,6 +214,12 @@ class BatchSim:
         self._check(self.lib.ur5_grasp_attempt_dev(self._h, C.c_void_p(action_ptr), int(check_mode), float(table_height),
                                                    C.c_void_p(reward_ptr)), "ur5_grasp_attempt_dev")
 
+    def grasp_attempt_reset_dev(self, action_ptr, reward_ptr, reset_seeds_ptr, check_mode=0, table_height=0.91, settle_ms=1000.0):
+        """grasp_attempt_dev + reset_model (and its settle) for the scenes whose uint64 entry of reset_seeds_ptr is non-zero, one launch."""
+        self._check(self.lib.ur5_grasp_attempt_reset_dev(self._h, C.c_void_p(action_ptr), int(check_mode), float(table_height), C.c_void_p(reward_ptr),
+                                                         C.c_void_p(reset_seeds_ptr) if reset_seeds_ptr else None, float(settle_ms)),
+                    "ur5_grasp_attempt_reset_dev")
+
     def sync(self):
         self._check(self.lib.ur5_sync(self._h), "ur5_sync")
 
@@ -222,6 +230,10 @@ class BatchSim:
             self._check(self.lib.ur5_set_stream(self._h, None, 0), "ur5_set_stream")
         else:
             self._check(self.lib.ur5_set_stream(self._h, C.c_void_p(int(hip_stream)) if hip_stream else None, 1), "ur5_set_stream")
+
+    def set_order_dev(self, order_ptr):
+        """Dispatch order of the following grasp / settle launches: device pointer to an int32 [n] permutation (caller keeps it alive); None = scene order."""
+        self._check(self.lib.ur5_set_order_dev(self._h, C.c_void_p(order_ptr) if order_ptr else None), "ur5_set_order_dev")
 
     def last_launch_ms(self):
         return float(self.lib.ur5_last_launch_ms(self._h))

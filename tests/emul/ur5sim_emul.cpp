@@ -28,7 +28,8 @@ static int be_reset_dev(ur5_sim* h, const uint64_t* seeds, const uint8_t* mask, 
 template <int NV> static void run_all(ur5_sim* h, const Ur5Launch& P) {
   typedef ur5::Lds<double, NV> L;
   L* lds = new L();
-  for (int e = 0; e < h->n; e++) {
+  for (int i = 0; i < h->n; i++) {
+    const int e = P.order ? P.order[i] : i;
     memset((void*)lds, 0, sizeof(L));
     ur5_emul_lds = lds;
     ur5_emul_model = h->dm;

@@ -17,11 +17,9 @@ def _run(model, sim, dev, n, rounds, rule="aimed"):
     rew = torch.zeros((rounds, n), dtype=torch.int32, device=dev)
     acts = []
     for r in range(rounds):
-        flags, seeds = wl.reset_flags(r)
-        assert flags.tolist() == [int(r > 0 and (r + g) % bench.EP == 0) for g in range(n)]
-        sim.reset_dev(seeds.data_ptr(), flags.data_ptr(), 1000.0)
-        act, pixel = wl.actions(r)
-        sim.grasp_attempt_dev(act.data_ptr(), rew[r].data_ptr(), check_mode=1)
+        seeds = wl.reset_seeds(r)
+        assert [int(x != 0) for x in seeds.tolist()] == [int((r + 1 + g) % bench.EP == 0) for g in range(n)]
+        act, pixel = wl.launch(r, rew[r])
         sim.sync()
         acts.append(act.clone())
     return rew, acts

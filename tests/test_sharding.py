@@ -79,11 +79,8 @@ def _gpu_worker(rank, world, port, n_total, out):
     ids = torch.arange(lo, hi, dtype=torch.int32, device=dev)
     recs = []
     for r in range(5):                                                   # crosses an episode boundary for every scene
-        flags, seeds = wl.reset_flags(r)
-        sim.reset_dev(seeds.data_ptr(), flags.data_ptr(), 1000.0)
-        act, pixel = wl.actions(r)
         rew = torch.zeros(hi - lo, dtype=torch.int32, device=dev)
-        sim.grasp_attempt_dev(act.data_ptr(), rew.data_ptr(), check_mode=1)
+        act, pixel = wl.launch(r, rew)
         rec = torch.stack([ids, pixel, act[:, 3].to(torch.int32), rew], dim=1)
         recs.append(sharding.gather_outcomes(rec).cpu().numpy())         # [n_total, 4] on every rank, ordered by scene id
     sim.sync()
