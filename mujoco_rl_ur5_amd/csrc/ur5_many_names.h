@@ -39,6 +39,8 @@
 #define ur5_profile_read ur5m_profile_read
 #define ur5_run_kernel ur5m_run_kernel
 #define ur5_render_kernel ur5m_render_kernel
+#define ur5_render_pose_kernel ur5m_render_pose_kernel
+#define Ur5GeomPose Ur5mGeomPose
 #define ur5_cmodel ur5m_cmodel
 #define ur5_smem ur5m_smem
 #define Ur5DevModel Ur5mDevModel

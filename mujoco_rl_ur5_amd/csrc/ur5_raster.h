@@ -111,7 +111,9 @@ UR5_RFN void geom_pose(const Ur5RenderModel& R, const Ur5DevModel& M, const floa
 
 // One pixel of the FINAL image (after the reference's flipud + fliplr): x right-to-left, y as in pixel_2_world
 // (MujocoController.py:783-806). Returns depth along the optical axis in metres (zfar when nothing is hit) and an RGB triple.
-UR5_RFN float shade_pixel(const Ur5RenderModel& R, const float (*gposes)[12], int cam, int W, int H, int px, int py, uint8_t* rgb) {
+// `list` / `nlist` (optional): the geoms to test, in ascending order (a tile's survivors of geom_screen_box); NULL = every geom.
+UR5_RFN float shade_pixel(const Ur5RenderModel& R, const float (*gposes)[12], int cam, int W, int H, int px, int py, uint8_t* rgb,
+                          const short* list = nullptr, int nlist = 0) {
   const float f = 0.5f * (float)H / tanf(R.cam_fovy[cam] * 3.14159265358979f / 360.0f);
   // GL pixel (i, j): i = W-1-px, j = H-1-py (the two flips); camera looks along -Z, +Y up, +X right
   const float xc = ((float)(W - 1 - px) + 0.5f - 0.5f * (float)W) / f, yc = ((float)(H - 1 - py) + 0.5f - 0.5f * (float)H) / f;
@@ -121,7 +123,9 @@ UR5_RFN float shade_pixel(const Ur5RenderModel& R, const float (*gposes)[12], in
   float tbest = R.zfar;
   F3 nbest = f3(0, 0, 1);
   int gbest = -1;
-  for (int g = 0; g < R.ngeom; g++) {
+  const int ntest = list ? nlist : R.ngeom;
+  for (int gi = 0; gi < ntest; gi++) {
+    const int g = list ? (int)list[gi] : gi;
     const float* gp = gposes[g];
     const F3 c = f3(gp[0], gp[1], gp[2]);
     const int type = R.g_type[g];
@@ -210,6 +214,27 @@ UR5_RFN float shade_pixel(const Ur5RenderModel& R, const float (*gposes)[12], in
     rgb[k] = (uint8_t)(v > 255.0f ? 255.0f : v);
   }
   return tbest;
+}
+
+// Conservative pixel box [x0, x1] x [y0, y1] (final image coordinates, inclusive, clipped) that contains every pixel whose ray can meet
+// geom g's bounding sphere; box[0] > box[1] = off screen. Planes and spheres that reach the near plane cover the whole image.
+UR5_RFN void geom_screen_box(const Ur5RenderModel& R, const float* gp, int g, int cam, int W, int H, short* box) {
+  box[0] = 0; box[1] = (short)(W - 1); box[2] = 0; box[3] = (short)(H - 1);
+  if (R.g_type[g] == UR5_GEOM_PLANE) return;
+  const float f = 0.5f * (float)H / tanf(R.cam_fovy[cam] * 3.14159265358979f / 360.0f);
+  const F3 pc = mulmT(R.cam_mat[cam], f3(gp[0] - R.cam_pos[cam][0], gp[1] - R.cam_pos[cam][1], gp[2] - R.cam_pos[cam][2]));
+  const float r = R.g_rbound[g] * 1.0001f + 1e-6f, D = -pc.z;
+  if (D - r <= R.znear) { if (D + r <= 0) { box[0] = 1; box[1] = 0; } return; }       // behind the camera entirely / straddles the near plane
+  const float xlo = (pc.x - r) / (pc.x - r <= 0 ? D - r : D + r), xhi = (pc.x + r) / (pc.x + r >= 0 ? D - r : D + r);
+  const float ylo = (pc.y - r) / (pc.y - r <= 0 ? D - r : D + r), yhi = (pc.y + r) / (pc.y + r >= 0 ? D - r : D + r);
+  // GL pixel i = f xc + W/2 - 1/2 ; final pixel px = W - 1 - i (the two flips of get_image_data); one pixel of slack on each side
+  const float ilo = f * xlo + 0.5f * (float)W - 0.5f, ihi = f * xhi + 0.5f * (float)W - 0.5f;
+  const float jlo = f * ylo + 0.5f * (float)H - 0.5f, jhi = f * yhi + 0.5f * (float)H - 0.5f;
+  float x0 = (float)(W - 1) - ihi - 1.0f, x1 = (float)(W - 1) - ilo + 1.0f, y0 = (float)(H - 1) - jhi - 1.0f, y1 = (float)(H - 1) - jlo + 1.0f;
+  x0 = floorf(x0); y0 = floorf(y0); x1 = ceilf(x1); y1 = ceilf(y1);
+  if (x1 < 0 || y1 < 0 || x0 > (float)(W - 1) || y0 > (float)(H - 1)) { box[0] = 1; box[1] = 0; return; }
+  box[0] = (short)(x0 < 0 ? 0 : x0); box[1] = (short)(x1 > (float)(W - 1) ? (float)(W - 1) : x1);
+  box[2] = (short)(y0 < 0 ? 0 : y0); box[3] = (short)(y1 > (float)(H - 1) ? (float)(H - 1) : y1);
 }
 
 // window-space depth in [0, 1] as sim.render returns it, so that depth_2_meters (MujocoController.py:737-740) inverts it

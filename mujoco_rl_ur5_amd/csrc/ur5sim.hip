@@ -45,23 +45,57 @@ __global__ void UR5_KERNEL_ATTR(GS) ur5_run_kernel(double* __restrict__ rec, Ur5
 // the model sits in __constant__ memory (one copy per device); a handle re-uploads it only when another handle used the device last
 static ur5_sim* g_model_owner[64] = {nullptr};
 
-// One 16x16 pixel tile of one scene per block: thread 0 runs the (serial) forward kinematics of the scene, the first ngeom
-// threads place the geoms, then every thread casts the ray of its pixel against the geoms staged in LDS.
-__global__ void __launch_bounds__(256) ur5_render_kernel(const Ur5RenderModel* __restrict__ R, const double* __restrict__ rec, int cam, int W, int H,
-                                                         int mode, uint8_t* __restrict__ rgb, float* __restrict__ depth) {
+// RGB-D observation in two launches. (1) ur5_render_pose_kernel, one 64-thread block per scene: the (serial, fp64) forward kinematics of
+// the scene ONCE, then every render geom's world pose and its conservative screen box. (2) ur5_render_kernel, one block per 16x16 pixel tile
+// of one scene: the tile stages the scene's geom poses in LDS, keeps (in geom order) only the geoms whose box meets the tile, and every
+// thread casts the ray of its pixel against that short list.
+struct Ur5GeomPose { float p[12]; short box[4]; };
+__global__ void __launch_bounds__(64) ur5_render_pose_kernel(const Ur5RenderModel* __restrict__ R, const double* __restrict__ rec, int n, int cam, int W, int H,
+                                                             Ur5GeomPose* __restrict__ gpose) {
   __shared__ float bp[UR5_MAXB][12];
+  const int scene = blockIdx.x;
+  if (scene >= n) return;
+  if (threadIdx.x == 0) ur5r::body_poses(ur5_cmodel, rec + (size_t)scene * UR5_REC_STRIDE, bp);
+  __syncthreads();
+  for (int g = threadIdx.x; g < R->ngeom; g += blockDim.x) {
+    Ur5GeomPose* o = gpose + (size_t)scene * UR5_R_MAXG + g;
+    float gp[12];
+    ur5r::geom_pose(*R, ur5_cmodel, bp, g, gp);
+    ur5r::geom_screen_box(*R, gp, g, cam, W, H, o->box);
+#pragma unroll
+    for (int k = 0; k < 12; k++) o->p[k] = gp[k];
+  }
+}
+__global__ void __launch_bounds__(256) ur5_render_kernel(const Ur5RenderModel* __restrict__ R, const Ur5GeomPose* __restrict__ gpose, int cam, int W, int H,
+                                                         int mode, uint8_t* __restrict__ rgb, float* __restrict__ depth) {
   __shared__ float gp[UR5_R_MAXG][12];
+  __shared__ short list[UR5_R_MAXG];
+  __shared__ unsigned long long votes[4];
   const int scene = blockIdx.y, tiles_x = (W + 15) / 16;
   const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-  const double* r = rec + (size_t)scene * UR5_REC_STRIDE;
-  if (threadIdx.x == 0) ur5r::body_poses(ur5_cmodel, r, bp);
+  const int x0 = tx * 16, y0 = ty * 16, x1 = x0 + 15, y1 = y0 + 15;
+  const int ngeom = R->ngeom;
+  static_assert(UR5_R_MAXG <= 256, "one geom per thread");
+  const int g = threadIdx.x;
+  bool keep = false;
+  if (g < ngeom) {
+    const Ur5GeomPose* s = gpose + (size_t)scene * UR5_R_MAXG + g;
+#pragma unroll
+    for (int k = 0; k < 12; k++) gp[g][k] = s->p[k];
+    keep = s->box[0] <= s->box[1] && s->box[0] <= x1 && s->box[1] >= x0 && s->box[2] <= y1 && s->box[3] >= y0;
+  }
+  const unsigned long long vote = __ballot(keep);
+  if ((threadIdx.x & 63) == 0) votes[threadIdx.x >> 6] = vote;
   __syncthreads();
-  for (int g = threadIdx.x; g < R->ngeom; g += blockDim.x) ur5r::geom_pose(*R, ur5_cmodel, bp, g, gp[g]);
+  int before = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < 4; w++) { const int c = __popcll(votes[w]); if (w < (int)(threadIdx.x >> 6)) before += c; total += c; }
+  if (keep) list[before + __popcll(vote & ((1ull << (threadIdx.x & 63)) - 1ull))] = (short)g;
   __syncthreads();
-  const int px = tx * 16 + (threadIdx.x & 15), py = ty * 16 + (threadIdx.x >> 4);
+  const int px = x0 + (threadIdx.x & 15), py = y0 + (threadIdx.x >> 4);
   if (px >= W || py >= H) return;
   uint8_t c[3];
-  float z = ur5r::shade_pixel(*R, gp, cam, W, H, px, py, c);
+  float z = ur5r::shade_pixel(*R, gp, cam, W, H, px, py, c, list, total);
   const size_t o = ((size_t)scene * H + py) * W + px;
   rgb[3 * o] = c[0]; rgb[3 * o + 1] = c[1]; rgb[3 * o + 2] = c[2];
   depth[o] = mode == 0 ? z : ur5r::gl_depth(*R, z);
@@ -217,8 +251,13 @@ static int be_render(ur5_sim* h, int cam, int W, int Hh, int mode, uint8_t* rgb_
   hipEvent_t ev0, ev1;
   if (be_event_pair(h, b, &ev0, &ev1)) return ur5host::fail(UR5_ERR_DEVICE, "hipEventCreate failed");
   HIPCHK(hipEventRecord(ev0, b->stream));
+  if (!h->d_gpose) {
+    h->d_gpose = be_alloc(h, (size_t)h->n * UR5_R_MAXG * sizeof(Ur5GeomPose));
+    if (!h->d_gpose) return ur5host::fail(UR5_ERR_DEVICE, "device allocation failed (render geom poses)");
+  }
+  hipLaunchKernelGGL(ur5_render_pose_kernel, dim3(h->n), dim3(64), 0, b->stream, h->d_rm, h->d_rec, h->n, cam, W, Hh, (Ur5GeomPose*)h->d_gpose);
   dim3 grid(((W + 15) / 16) * ((Hh + 15) / 16), h->n), block(256);
-  hipLaunchKernelGGL(ur5_render_kernel, grid, block, 0, b->stream, h->d_rm, h->d_rec, cam, W, Hh, mode, rgb_dev, depth_dev);
+  hipLaunchKernelGGL(ur5_render_kernel, grid, block, 0, b->stream, h->d_rm, (const Ur5GeomPose*)h->d_gpose, cam, W, Hh, mode, rgb_dev, depth_dev);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(ev1, b->stream));
   return 0;

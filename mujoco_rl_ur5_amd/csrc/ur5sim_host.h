@@ -411,6 +411,7 @@ struct ur5_sim {
   size_t img_cap = 0;
   unsigned* d_mask = nullptr;
   double *d_target = nullptr, *d_tol = nullptr, *d_debug = nullptr, *d_hess = nullptr, *d_qpos0 = nullptr;
+  void* d_gpose = nullptr;        // render: per-scene geom poses + screen boxes (HIP backend)
   const int* d_order = nullptr;   // caller-owned dispatch order of the scripted launches (ur5_set_order_dev), NULL = scene order
   double kernel_ms_total = 0;   // engine-kernel time of every launch since ur5_create (HIP events on the handle's stream)
   int *d_max = nullptr, *d_result = nullptr, *d_steps = nullptr, *d_ps = nullptr, *d_pr = nullptr;
@@ -555,7 +556,7 @@ int ur5_create(const void* blob, size_t nbytes, int n_env, int device_id, const 
 void ur5_destroy(ur5_sim* h) {
   UR5_FWD_VOID(destroy, (h));
   if (!h) return;
-  void* ptrs[] = {h->dm, h->d_rec, h->d_mask, h->d_target, h->d_tol, h->d_max, h->d_result, h->d_steps, h->d_ps, h->d_pr, h->d_debug, h->d_rm, h->d_rgb, h->d_depth, h->d_hess, h->d_qpos0};
+  void* ptrs[] = {h->dm, h->d_rec, h->d_mask, h->d_target, h->d_tol, h->d_max, h->d_result, h->d_steps, h->d_ps, h->d_pr, h->d_debug, h->d_rm, h->d_rgb, h->d_depth, h->d_hess, h->d_qpos0, h->d_gpose};
   for (void* p : ptrs) if (p) be_free(h, p);
   be_close(h);
   delete h;
