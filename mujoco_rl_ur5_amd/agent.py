@@ -8,8 +8,8 @@ simulating GPU, the network runs there (PyTorch-ROCm / MIOpen), actions go back 
 as one; per round only the 16-byte outcome records cross ranks (``sharding.gather_outcomes``, RCCL all_gather).
 
 Differences that follow from batching, all deliberate: epsilon decays per transition (``steps_done`` advances by N per round); one
-optimiser step per round on 12 sampled transitions (the reference learns once per env step); colour jitter (torchvision, :120-126) is
-not applied -- depth noise is.
+optimiser step per round on 12 sampled transitions (the reference learns once per env step); colour jitter (torchvision's
+ColorJitter, :120-126) and the depth noise run on the device (``color_jitter`` below).
 """
 from __future__ import annotations
 
@@ -27,6 +27,66 @@ MEMORY_SIZE = 2000            # Grasping_Agent_multidiscrete.py:26-38
 BATCH_SIZE = 12
 LEARNING_RATE = 0.001
 EPS_START, EPS_END, EPS_DECAY = 1.0, 0.2, 8000
+
+
+def _gray(img):
+    return (0.2989 * img[:, 0] + 0.587 * img[:, 1] + 0.114 * img[:, 2]).unsqueeze(1)
+
+
+def _rgb_to_hsv(img):
+    r, g, b = img[:, 0], img[:, 1], img[:, 2]
+    maxc, minc = img.max(dim=1).values, img.min(dim=1).values
+    eqc = maxc == minc
+    cr = maxc - minc
+    ones = torch.ones_like(maxc)
+    s = cr / torch.where(eqc, ones, maxc)
+    crd = torch.where(eqc, ones, cr)
+    rc, gc, bc = (maxc - r) / crd, (maxc - g) / crd, (maxc - b) / crd
+    hr = (maxc == r) * (bc - gc)
+    hg = ((maxc == g) & (maxc != r)) * (2.0 + rc - bc)
+    hb = ((maxc != g) & (maxc != r)) * (4.0 + gc - rc)
+    h = torch.fmod((hr + hg + hb) / 6.0 + 1.0, 1.0)
+    return torch.stack((h, s, maxc), dim=1)
+
+
+def _hsv_to_rgb(img):
+    h, s, v = img[:, 0], img[:, 1], img[:, 2]
+    i = torch.floor(h * 6.0)
+    f = h * 6.0 - i
+    i = i.to(torch.int32) % 6
+    p, q, t = (v * (1.0 - s)).clamp(0, 1), (v * (1.0 - s * f)).clamp(0, 1), (v * (1.0 - s * (1.0 - f))).clamp(0, 1)
+    mask = i.unsqueeze(1) == torch.arange(6, device=img.device).view(1, -1, 1, 1)
+    a1 = torch.stack((v, q, p, p, t, v), dim=1)
+    a2 = torch.stack((t, v, v, q, p, p), dim=1)
+    a3 = torch.stack((p, p, t, v, v, q), dim=1)
+    a4 = torch.stack((a1, a2, a3), dim=1)                     # [N, 3, 6, H, W]
+    return (a4 * mask.unsqueeze(1).to(img.dtype)).sum(dim=2)
+
+
+def color_jitter(rgb, generator=None, brightness=0.5, contrast=0.5, saturation=0.5, hue=0.5):
+    """torchvision ``T.ColorJitter(brightness=0.5, contrast=0.5, saturation=0.5, hue=0.5)`` (Grasping_Agent_multidiscrete.py:120-126) for a
+    whole batch ON THE DEVICE: rgb float [N, 3, H, W] in [0, 1]. Every image draws its own four factors -- brightness / contrast / saturation
+    from U(1 - x, 1 + x), hue from U(-x, x) -- and its own order of the four operations, as torchvision's forward() does per call; the
+    operations are torchvision's tensor definitions (blend with black / mean grey / grey image, hue through HSV). The reference goes through
+    a uint8 PIL image between ToPILImage and ToTensor; this stays in float."""
+    n, dev = rgb.shape[0], rgb.device
+    u = torch.rand((n, 4), device=dev, generator=generator)
+    fb = (1 - brightness + 2 * brightness * u[:, 0]).view(n, 1, 1, 1)
+    fc = (1 - contrast + 2 * contrast * u[:, 1]).view(n, 1, 1, 1)
+    fs = (1 - saturation + 2 * saturation * u[:, 2]).view(n, 1, 1, 1)
+    fh = (-hue + 2 * hue * u[:, 3]).view(n, 1, 1)
+    order = torch.argsort(torch.rand((n, 4), device=dev, generator=generator), dim=1)    # a random permutation of the 4 ops per image
+    out = rgb
+    for pos in range(4):
+        op = order[:, pos].view(n, 1, 1, 1)
+        bright = (out * fb).clamp(0, 1)
+        contr = (fc * out + (1 - fc) * _gray(out).mean(dim=(1, 2, 3), keepdim=True)).clamp(0, 1)
+        satur = (fs * out + (1 - fs) * _gray(out)).clamp(0, 1)
+        hsv = _rgb_to_hsv(out)
+        hsv = torch.stack((torch.remainder(hsv[:, 0] + fh, 1.0), hsv[:, 1], hsv[:, 2]), dim=1)
+        huesh = _hsv_to_rgb(hsv)
+        out = torch.where(op == 0, bright, torch.where(op == 1, contr, torch.where(op == 2, satur, huesh)))
+    return out
 
 
 class BatchedGraspAgent:
@@ -66,6 +126,8 @@ class BatchedGraspAgent:
             dmax = depth.amax(dim=(1, 2), keepdim=True)
             depth = (depth - dmin) / (dmax - dmin).clamp_min(1e-12)                                      # :319-321
         rgb = observation["rgb"].to(self.device).permute(0, 3, 1, 2).float() / 255.0                    # ToTensor (:128)
+        if normalize and jitter_and_noise:
+            rgb = color_jitter(rgb, self._gen)                                                          # self.normal_rgb (:117-123, :334-335)
         return torch.cat((rgb, depth.unsqueeze(1)), dim=1)
 
     # ------------------------------------------------------------------ action selection

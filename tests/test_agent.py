@@ -82,3 +82,25 @@ def test_agent_rounds_on_gpu(model_it1):
         assert out["reward"].is_cuda
     assert out["loss"] is not None and np.isfinite(out["loss"]) and len(agent.memory) == 32
     assert env.sim.counters()["status"].max() == 0
+
+
+def test_color_jitter_is_torchvisions_colorjitter_for_a_batch():
+    """ColorJitter(0.5, 0.5, 0.5, 0.5) of Grasping_Agent_multidiscrete.py:120-126 on the device: torchvision's tensor definitions of the four
+    operations, per-image factors and operation order."""
+    from mujoco_rl_ur5_amd.agent import color_jitter, _rgb_to_hsv, _hsv_to_rgb, _gray
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(6, 3, 8, 8, generator=g)
+    assert torch.allclose(_hsv_to_rgb(_rgb_to_hsv(x)), x, atol=1e-6)                      # HSV round trip
+    red = torch.zeros(1, 3, 2, 2); red[:, 0] = 1.0
+    hsv = _rgb_to_hsv(red); hsv[:, 0] = (hsv[:, 0] + 1.0 / 3.0) % 1.0
+    assert torch.allclose(_hsv_to_rgb(hsv), torch.tensor([0.0, 1.0, 0.0]).view(1, 3, 1, 1).expand(1, 3, 2, 2), atol=1e-6)   # red + 120 deg = green
+    assert torch.allclose(color_jitter(x, torch.Generator().manual_seed(1), 0.0, 0.0, 0.0, 0.0), x, atol=1e-6)   # all factors 1 / 0: identity
+    y = color_jitter(x, torch.Generator().manual_seed(1))
+    assert y.shape == x.shape and float(y.min()) >= 0 and float(y.max()) <= 1 and not torch.allclose(y, x)
+    # brightness only: every image is its input times one factor in [0.5, 1.5] (clamped), a different one per image
+    yb = color_jitter(0.5 * x, torch.Generator().manual_seed(2), 0.5, 0.0, 0.0, 0.0)
+    f = (yb.flatten(1).sum(1) / (0.5 * x).flatten(1).sum(1))
+    assert torch.allclose(yb, (0.5 * x) * f.view(6, 1, 1, 1), atol=1e-5) and float(f.min()) >= 0.5 - 1e-5 and float(f.max()) <= 1.5 + 1e-5
+    assert f.unique().numel() == 6
+    # saturation 0 end of the range collapses to the grey image (torchvision: blend(img, gray, s))
+    assert torch.allclose(0.0 * x + 1.0 * _gray(x).expand_as(x), _gray(x).expand_as(x))

@@ -61,3 +61,54 @@ def test_replay_buffer_semantics():
     nb.push(torch.zeros(4, 4, 4, 4), torch.arange(4), torch.zeros(4))
     nb.push(torch.zeros(4, 4, 4, 4), 4 + torch.arange(4), torch.ones(4))
     assert nb.position == 2 and len(nb) == 6 and nb.action[:, 0].tolist() == [6, 7, 2, 3, 4, 5]
+
+
+def _learn_step(device):
+    """Grasp_Agent.learn() (Grasping_Agent_multidiscrete.py:388-446) with this package's network and BatchedGraspAgent's loss / optimiser
+    settings on the batch the reference's Modules.py was run on (tools/gen_golden_qnet.py "learn_step")."""
+    import torch.nn.functional as F
+    g = GOLD["learn_step"]
+    torch.manual_seed(0)
+    net = qnet.MULTIDISCRETE_RESNET(6).train()
+    gen = torch.Generator().manual_seed(3)
+    state = torch.rand(12, 4, 40, 40, generator=gen)
+    action = torch.randint(0, 6 * 40 * 40, (12, 1), generator=gen)
+    reward = torch.randint(0, 2, (12, 1), generator=gen)
+    net, state, action, reward = net.to(device), state.to(device), action.to(device), reward.to(device)
+    opt = torch.optim.Adam(net.parameters(), lr=0.001, weight_decay=0.00002)
+    q_pred = net(state).reshape(12, -1).gather(1, action)
+    loss = F.binary_cross_entropy(q_pred, reward.float())
+    loss.backward()
+    opt.step()
+    opt.zero_grad()
+    net.eval()
+    with torch.no_grad():
+        y2 = net(state[:2])
+    return g, float(loss), q_pred.detach().reshape(-1).cpu().numpy(), float(y2.double().sum()), float(y2.double().abs().sum())
+
+
+def test_learn_step_equals_the_reference():
+    g, loss, q, s, a = _learn_step("cpu")
+    assert abs(loss - g["loss"]) < 1e-5 and np.allclose(q, g["q_pred"], atol=1e-5)
+    assert abs(s - g["after_sum"]) < 1e-3 * abs(g["after_sum"]) and abs(a - g["after_abs_sum"]) < 1e-3 * g["after_abs_sum"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,make", [("MULTIDISCRETE_RESNET_6", lambda: qnet.MULTIDISCRETE_RESNET(6)), ("RESNET", qnet.RESNET)])
+def test_network_equals_the_reference_on_gpu(tag, make):
+    """The reference-pinned vectors evaluated on the MI355X (MIOpen convolutions): same weights (seed 0, same layer order), same inputs."""
+    g = GOLD[tag]
+    torch.manual_seed(0)
+    net = make().eval().cuda()
+    x = torch.randn(2, 4, 40, 40, generator=torch.Generator().manual_seed(1)).cuda()
+    with torch.no_grad():
+        flat = net(x).reshape(-1).cpu()
+    assert np.allclose(flat[torch.tensor(g["sample_idx"])].numpy(), g["sample"], rtol=1e-3, atol=1e-4)
+    assert abs(float(flat.double().sum()) - g["sum"]) < 2e-3 * max(1.0, abs(g["sum"]))
+
+
+@pytest.mark.gpu
+def test_learn_step_equals_the_reference_on_gpu():
+    g, loss, q, s, a = _learn_step("cuda")
+    assert abs(loss - g["loss"]) < 1e-3 and np.allclose(q, g["q_pred"], atol=1e-3)
+    assert abs(s - g["after_sum"]) < 1e-2 * abs(g["after_sum"]) and abs(a - g["after_abs_sum"]) < 1e-2 * g["after_abs_sum"]

@@ -48,6 +48,26 @@ for i in range(8):
     buf.push(i, 10 * i, i % 2)
 out["replay"] = {"len": len(buf), "position": buf.position, "stored_states": [t.state for t in buf.memory],
                  "sample_last": [buf.sample(3)[-1].state for _ in range(4)]}
+# one optimiser step of Grasp_Agent.learn() (Grasping_Agent_multidiscrete.py:388-446, GAMMA = 0, BATCH_SIZE 12, Adam lr 1e-3 / weight decay 2e-5
+# :27-38,153-156) on a fixed batch, with the reference's network: loss before the step, outputs after it
+import torch.nn.functional as F  # noqa: E402
+torch.manual_seed(0)
+net = R.MULTIDISCRETE_RESNET(6).train()
+opt = torch.optim.Adam(net.parameters(), lr=0.001, weight_decay=0.00002)
+g = torch.Generator().manual_seed(3)
+state = torch.rand(12, 4, 40, 40, generator=g)
+action = torch.randint(0, 6 * 40 * 40, (12, 1), generator=g)
+reward = torch.randint(0, 2, (12, 1), generator=g)
+q_pred = net(state).view(12, -1).gather(1, action)
+loss = F.binary_cross_entropy(q_pred, reward.float())
+loss.backward()
+opt.step()
+opt.zero_grad()
+net.eval()
+with torch.no_grad():
+    y2 = net(state[:2])
+out["learn_step"] = {"loss": float(loss), "q_pred": [float(v) for v in q_pred.detach().reshape(-1)],
+                     "after_sum": float(y2.double().sum()), "after_abs_sum": float(y2.double().abs().sum())}
 with open(os.path.join(ROOT, "tests", "golden", "qnet_reference.json"), "w") as f:
     json.dump(out, f, indent=1)
 print({k: (v.get("n_params"), v.get("out_shape")) for k, v in out.items() if "keys" in v})
