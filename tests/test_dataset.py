@@ -27,3 +27,22 @@ def test_files_have_the_reference_layout(tmp_path):
     assert np.allclose(clean, (dep - dep.min()) / (dep.max() - dep.min()), atol=1e-6)
     batch = next(iter(torch.utils.data.DataLoader(ds, batch_size=4)))       # train.py:73
     assert batch[0].shape == (4, 4, 8, 8) and batch[1].shape == (4,)
+
+
+def test_a_written_file_read_by_the_references_own_class():
+    """tests/golden/offline_rl/grasping_data_1.pt was written by GraspingDataWriter and read by the reference's Offline RL/grasping_dataset.py
+    (tools/gen_golden_dataset.py): the reference accepted the layout, and this package's reader returns the same items from the same file."""
+    import json
+    import os
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = json.load(open(os.path.join(gold, "dataset_reference.json")))
+    ds = Grasping_Dataset(os.path.join(gold, g["file"]), seed=0)
+    assert len(ds) == g["len"] == FILE_SIZE
+    items = [ds[i] for i in range(len(ds))]
+    assert [int(a) for _, a, _ in items] == g["actions"] and [int(r) for _, _, r in items] == g["rewards"]
+    assert list(items[0][0].shape) == g["shape"] and str(items[0][0].dtype) == g["dtype"]
+    for i, ref in enumerate(g["states"]):
+        ref = np.array(ref).reshape(g["shape"])
+        mine = ds.transform_observation(ds.state_list[i], jitter_and_noise=False).numpy()
+        assert np.array_equal(mine[:3], ref[:3].astype(np.float32))                 # ToTensor: rgb / 255, channel first
+        assert np.abs(mine[3] - ref[3]).max() < 0.03                                 # depth: the reference's draw of its N(0, 1e-3) noise apart
