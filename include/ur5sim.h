@@ -112,8 +112,6 @@ int ur5_render(ur5_sim* h, int camera_id, int width, int height, int depth_mode,
 int ur5_render_dev(ur5_sim* h, int camera_id, int width, int height, int depth_mode, uint8_t* rgb_dev, float* depth_dev);
 /* raw device pointer of the [n][192] double state records (layout: csrc/ur5_devmodel.h) */
 void* ur5_state_device_ptr(ur5_sim* h);
-/* test hook: runs forward dynamics once without integrating and dumps internals, [n][2048] doubles host */
-int ur5_forward_debug(ur5_sim* h, double* out);
 
 #ifdef __cplusplus
 }

@@ -9,6 +9,7 @@
 #include <string>
 #include <vector>
 #include "../../include/ur5sim.h"
+#include "../../include/ur5sim_test.h"
 #include "ur5_devmodel.h"
 #include "ur5_raster.h"
 

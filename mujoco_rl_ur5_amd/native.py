@@ -20,7 +20,8 @@ _VARIANT = {0: (6, 2048, 192, 30), 1: (40, 4096, 832, 160)}
 EXPORTS = ["ur5_last_error", "ur5_create", "ur5_destroy", "ur5_num_envs", "ur5_nq", "ur5_nv", "ur5_nu", "ur5_reset", "ur5_reset_dev", "ur5_kernel_ms_total",
            "ur5_set_state", "ur5_get_state", "ur5_set_ctrl", "ur5_get_ctrl", "ur5_step", "ur5_move_group", "ur5_stay",
            "ur5_move_ee", "ur5_ik", "ur5_grasp_attempt", "ur5_grasp_attempt_dev", "ur5_grasp_attempt_reset_dev", "ur5_sync", "ur5_set_stream", "ur5_set_order_dev", "ur5_last_launch_ms",
-           "ur5_get_counters", "ur5_body_xpos", "ur5_render", "ur5_render_dev", "ur5_state_device_ptr", "ur5_forward_debug"]
+           "ur5_get_counters", "ur5_body_xpos", "ur5_render", "ur5_render_dev", "ur5_state_device_ptr"]
+TEST_EXPORTS = ["ur5_forward_debug"]   # include/ur5sim_test.h: introspection for tests/ and tools/, not part of the boundary
 
 
 class Config(C.Structure):

@@ -11,14 +11,15 @@ from conftest import ROOT
 from mujoco_rl_ur5_amd import native
 
 
-def _declared_symbols():
-    src = open(os.path.join(ROOT, "include", "ur5sim.h")).read()
+def _declared_symbols(header="ur5sim.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(ur5_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_header_and_binding_agree():
     assert _declared_symbols() == sorted(native.EXPORTS)
+    assert _declared_symbols("ur5sim_test.h") == sorted(native.TEST_EXPORTS)      # the test hooks live in their own header
 
 
 def test_library_exports_every_declared_symbol():
@@ -26,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     if shutil.which("hipcc"):      # rebuilds only when a source is newer than the library
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "mujoco_rl_ur5_amd", "csrc"), "-s", "libur5sim.so"])
     lib = C.CDLL(native.DEFAULT_LIB)
-    for sym in _declared_symbols():
+    for sym in _declared_symbols() + _declared_symbols("ur5sim_test.h"):
         assert hasattr(lib, sym), sym
 
 
