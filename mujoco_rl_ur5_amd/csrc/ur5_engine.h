@@ -171,6 +171,9 @@ enum { PF_KIN = 0, PF_CRB, PF_VEL, PF_BROAD, PF_NARROW, PF_ROWS, PF_NEWTON_INIT,
 #ifndef UR5_INL_DUMP
 #define UR5_INL_DUMP 0   // the introspection dump (FORWARD op only) stays a real function: inlined into the flat kernel it made the kernel fault (gfx950, ROCm 7.2)
 #endif
+#ifndef UR5_EMUL
+namespace {   // internal linkage for every engine function: lets -enable-ipra drop the callee-saved register spills of the phase functions
+#endif
 namespace ur5 {
 
 enum { RES_NONE = -1, RES_SUCCESS = 0, RES_MAX_STEPS = 1, RES_IK_FAIL = 2 };
@@ -3249,3 +3252,6 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
 #undef M
 
 }  // namespace ur5
+#ifndef UR5_EMUL
+}  // anonymous namespace
+#endif
