@@ -154,7 +154,7 @@ template <int W, class T> __device__ __forceinline__ T ur5_wave_max(T v) {   // 
 #define PROF(id) ((void)0)
 #endif
 enum { PF_KIN = 0, PF_CRB, PF_VEL, PF_BROAD, PF_NARROW, PF_ROWS, PF_NEWTON_INIT, PF_IMAGES, PF_LINESEARCH, PF_GRADG, PF_HASM, PF_CHOL, PF_SOLVE,
-       PF_INTEGRATE, PF_PID, PF_IK, PF_CORECLK, PF_REALCLK, PF_COUNT };   // the last two: start / end of the scene's wave in 100 MHz ticks (s_memrealtime)
+       PF_INTEGRATE, PF_PID, PF_IK, PF_CORECLK, PF_REALCLK, PF_X0, PF_X1, PF_X2, PF_X3, PF_X4, PF_X5, PF_X6, PF_X7, PF_COUNT };   // the last two: start / end of the scene's wave in 100 MHz ticks (s_memrealtime)
 
 #ifndef UR5_INL_POW
 #define UR5_INL_POW 1
@@ -818,10 +818,30 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     } else if (s.type == UR5_GEOM_MESH) {
       real best = -1e300;
       int bi = 0;
-      for (int i = (W > 1 ? sl : 0); i < s.vnum; i += W) {
-        const double* p = M.hullvert[s.vadr + i];
-        real v = (real)p[0] * d.x + (real)p[1] * d.y + (real)p[2] * d.z;
-        if (v > best) { best = v; bi = i; }
+      if constexpr (W == 1) {
+        for (int i = 0; i < s.vnum; i++) {
+          const double* p = M.hullvert[s.vadr + i];
+          real v = (real)p[0] * d.x + (real)p[1] * d.y + (real)p[2] * d.z;
+          if (v > best) { best = v; bi = i; }
+        }
+      } else {
+        // 4 vertices per lane and trip, all 12 loads issued before the first use (the hulls live in constant memory: one L1 / L2 round trip
+        // per trip instead of one per vertex)
+        for (int base = 0; base < s.vnum; base += 4 * W) {
+          real px[4], py[4], pz[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const int i = base + sl + W * k;
+            const double* p = M.hullvert[s.vadr + (i < s.vnum ? i : s.vnum - 1)];
+            px[k] = (real)p[0]; py[k] = (real)p[1]; pz[k] = (real)p[2];
+          }
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const int i = base + sl + W * k;
+            const real v = px[k] * d.x + py[k] * d.y + pz[k] * d.z;
+            if (i < s.vnum && v > best) { best = v; bi = i; }
+          }
+        }
       }
 #ifndef UR5_EMUL
       if constexpr (W == 8) {
@@ -1217,10 +1237,16 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
 #endif
     }
   }
+  UR5_FN v3 geom_position(int g) const { const int dg = M.g_dg[g]; return dg < 0 ? v3(M.g_pos[g]) : v3(S.dgpos[dg]); }
   UR5_BIG bool cull(int g1, int g2, real margin) const {  // true = cannot touch
-    GeomPose A = geom_pose(g1), B = geom_pose(g2);
     int t1 = M.g_type[g1], t2 = M.g_type[g2];
     real r1 = (real)M.g_rbound[g1], r2 = (real)M.g_rbound[g2];
+    if (t1 != UR5_GEOM_PLANE) {   // bounding spheres first, from the two positions alone: most pairs end here, before any rotation matrix is fetched
+      v3 d0 = geom_position(g2) - geom_position(g1);
+      real rr0 = r1 + r2 + margin;
+      if (dot(d0, d0) > rr0 * rr0) return true;
+    }
+    GeomPose A = geom_pose(g1), B = geom_pose(g2);
     if (t1 == UR5_GEOM_PLANE) return dot(B.pos - A.pos, A.mat.col(2)) > r2 + margin;
     v3 d = B.pos - A.pos;
     real rr = r1 + r2 + margin;
@@ -1245,6 +1271,36 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     return k == UR5_KIND_STATIC ? -1 : (k == UR5_KIND_ROBOT ? M.g_owner[g] : M.nrd + M.g_owner[g]);
   }
 
+#if !defined(UR5_EMUL) && !defined(UR5_MANY)
+  // General convex pairs (hull against hull / box / ...): Minkowski portal refinement with 8 lanes per pair. The lanes of a sub-group run the
+  // same MPR on the same pair (sub-group-uniform control flow) and share the hull scans of its support calls; GS / 8 pairs are in flight at
+  // once. S.couple / S.ncouple (filled by narrow()) are free until make_constraints rebuilds them. Its own function in the 256-register
+  // kernel: the portal (five Minkowski points with their witnesses) and two shapes are ~170 registers by themselves.
+  UR5_CALL void mpr_pass_fn() { mpr_pass_body(); }
+  UR5_BIG void mpr_pass_body() {
+    {
+      const int nm = S.ncouple < UR5_MAXCON ? S.ncouple : UR5_MAXCON;
+      const int sub = UR5_LANE >> 3, sl = UR5_LANE & 7;
+      for (int base = 0; base < nm; base += GS / 8) {
+        const int idx = base + sub;
+        if (idx < nm) {
+          const int p = S.couple[idx];
+          Sink sink;
+          sink.mode = 0; sink.slot = 0; sink.n = 0;
+          sink.g1 = M.pair_g1[p]; sink.g2 = M.pair_g2[p];
+          const real margin = maxv((real)M.g_margin[sink.g1], (real)M.g_margin[sink.g2]);
+          Shape sa = make_shape(sink.g1, margin), sb = make_shape(sink.g2, margin);
+          real depth;
+          v3 nrm, pos;
+          const bool hit = mpr<8>(sa, sb, &depth, &nrm, &pos, sl);
+          const real dist = margin - depth;
+          if (hit && dist < margin && sl == 0) emit(sink, pos, nrm, dist);
+        }
+      }
+      SYNC();
+    }
+  }
+#endif
   UR5_CALL void collision_fn() { collision_body(); }
   UR5_FN void collision() { if constexpr (FLAT) collision_body(); else collision_fn(); }
   UR5_PHASE_A void collision_body() {
@@ -1310,30 +1366,9 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       }
     }
     SYNC();
+    PROF(PF_X0);   // profile builds: the one-candidate-per-lane pass (analytic pairs, box-box); PF_NARROW then is the cooperative MPR pass
 #if !defined(UR5_EMUL) && !defined(UR5_MANY)
-    {   // general convex pairs (hull against hull / box / ...): Minkowski portal refinement with 8 lanes per pair. The lanes of a sub-group
-        // run the same MPR on the same pair (sub-group-uniform control flow) and share the hull scans of its support calls; GS / 8
-        // pairs are in flight at once. S.couple / S.ncouple are free until make_constraints rebuilds them.
-      const int nm = S.ncouple < UR5_MAXCON ? S.ncouple : UR5_MAXCON;
-      const int sub = UR5_LANE >> 3, sl = UR5_LANE & 7;
-      for (int base = 0; base < nm; base += GS / 8) {
-        const int idx = base + sub;
-        if (idx < nm) {
-          const int p = S.couple[idx];
-          Sink sink;
-          sink.mode = 0; sink.slot = 0; sink.n = 0;
-          sink.g1 = M.pair_g1[p]; sink.g2 = M.pair_g2[p];
-          const real margin = maxv((real)M.g_margin[sink.g1], (real)M.g_margin[sink.g2]);
-          Shape sa = make_shape(sink.g1, margin), sb = make_shape(sink.g2, margin);
-          real depth;
-          v3 nrm, pos;
-          const bool hit = mpr<8>(sa, sb, &depth, &nrm, &pos, sl);
-          const real dist = margin - depth;
-          if (hit && dist < margin && sl == 0) emit(sink, pos, nrm, dist);
-        }
-      }
-      SYNC();
-    }
+    if constexpr (FLAT) mpr_pass_body(); else mpr_pass_fn();
 #endif
     if (UR5_LANE == 0) {
       int n = S.ncon;
@@ -1821,6 +1856,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     const int nv = M.nv, LD = L::LD;
     PAR(idx, nv * nv) { int i = idx / nv, j = idx % nv; if (j <= i) S.H[UR5_HIDX(i, j)] = 0; }
     SYNC();
+    PROF(PF_X1);   // zeroing H
     PAR(idx, M.nrd * M.nrd) {
       int d = idx / M.nrd, e = idx % M.nrd;
       if (e > d) continue;
@@ -1868,6 +1904,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       S.H[UR5_HIDX(di, dj)] = v;
     }
     SYNC();
+    PROF(PF_X2);   // diagonal blocks; PF_HASM then is the coupling loop
     // coupling blocks: contacts between two movable bodies, one contact at a time (entries may collide across contacts)
     for (int q = 0; q < S.ncouple; q++) {
       int c = S.couple[q], A = S.cA[c], B = S.cB[c];
@@ -1895,7 +1932,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
 #else
     (void)LD;
     if constexpr (FLAT) factor_solve_rows_body<false>(); else factor_solve_rows<false>();
-    PROF(PF_SOLVE);
+    PROF_RE();   // profile builds: the routine books its own sub-intervals (x3..x6)
 #endif
 #endif   // UR5_MANY
     return false;
@@ -1990,10 +2027,12 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     constexpr int N = NV_;
     static_assert(NV_ <= GS, "one Hessian row per lane of the scene's group");
     const int lane = UR5_LANE, nv = M.nv;
+    PROF_T0();
     real Lrow[N];
 #pragma unroll
     for (int j = 0; j < N; j++) Lrow[j] = (lane < nv && j <= lane) ? S.H[UR5_HIDX(lane, j)] : (j == lane ? (real)1 : (real)0);
     real myinv = 1;
+    PROF(PF_X3);   // rows of H into registers
     // Structure of H (dof order: robot 0-7, then 6 per object): an object that shares no contact with another movable body only has its
     // own diagonal block; the others ("coupled": S.cplmask) may reach the robot columns (if any contact joins the robot and an object)
     // and the blocks of earlier coupled objects (direct coupling or fill-in). Every skipped product has an exactly zero factor, so the
@@ -2026,12 +2065,14 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       Lrow[j] = lane == j ? djj * inv : (lane > j ? sacc * inv : (real)0);
       if (lane == j) myinv = inv;
     }
+    PROF(PF_X4);   // factorisation
     real b = lane < nv ? S.search[lane] : (real)0;
 #pragma unroll
     for (int j = 0; j < N; j++) {
       real yj = bcast(b * myinv, j);
       b = lane == j ? yj : (lane > j ? b - Lrow[j] * yj : b);
     }
+    PROF(PF_X5);   // forward substitution
     // transpose the factor through LDS (H is free now): lane j then holds column j, i.e. row j of L^T
     SYNC();
     if (lane < nv) {
@@ -2048,6 +2089,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     }
     if (lane < nv) S.search[lane] = -b;
     SYNC();
+    PROF(PF_X6);   // transposition through LDS + backward substitution
   }
 #endif
 

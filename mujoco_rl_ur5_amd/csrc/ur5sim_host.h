@@ -831,7 +831,7 @@ int ur5_profile_read(ur5_sim* h, double* out) {
   std::vector<double> dbg((size_t)h->n * UR5_DEBUG_STRIDE);
   int rc = be_d2h(h, dbg.data(), h->d_debug, dbg.size() * 8);
   if (rc) return rc;
-  for (int e = 0; e < h->n; e++) memcpy(out + (size_t)e * 18, dbg.data() + (size_t)e * UR5_DEBUG_STRIDE, 18 * 8);
+  for (int e = 0; e < h->n; e++) memcpy(out + (size_t)e * 26, dbg.data() + (size_t)e * UR5_DEBUG_STRIDE, 26 * 8);
   return 0;
 }
 #endif

@@ -12,7 +12,7 @@ m = load_model("/UR5+gripper/UR5gripper_2_finger_many_objects.xml" if MANY else 
 sim = BatchSim(m, n, lib_path=os.environ.get("UR5_PROF_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), "libur5sim_prof.so")))
 sim.lib.ur5_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
 def read():
-    out = np.zeros((n, 18)); sim.lib.ur5_profile_read(sim._h, out.ctypes.data_as(C.POINTER(C.c_double))); return out
+    out = np.zeros((n, 26)); sim.lib.ur5_profile_read(sim._h, out.ctypes.data_as(C.POINTER(C.c_double))); return out
 seeds = np.arange(n, dtype=np.uint64) + 20
 sim.reset(seeds, 1, 1000.0)
 c0 = sim.counters(); p = read()
@@ -38,7 +38,8 @@ rew, ps, pr = sim.grasp_attempt(acts, rot=0, check_mode=0)
 c1 = sim.counters(); p = read(); steps = (c1["total_steps"] - c0["total_steps"]).astype(float)
 print("grasp: kernel %.1f ms, mean %d steps/env, success %.2f" % (sim.last_launch_ms(), steps.mean(), rew.mean()))
 for k, nm in enumerate(NAMES): print("  %-12s %10.0f" % (nm, (p[:, k] / steps).mean()))
-print("  %-12s %10.0f  (%s; kernel %.2f ms)" % ("sum", (p[:, :16].sum(1) / steps).mean(), life(p), sim.last_launch_ms()))
+print("  sub-intervals x0..x7 (cycles/step): %s" % (p[:, 18:26] / steps[:, None]).mean(0).round(0).tolist())
+print("  %-12s %10.0f  (%s; kernel %.2f ms)" % ("sum", (p[:, :16].sum(1) / steps).mean() + (p[:, 18:26].sum(1) / steps).mean(), life(p), sim.last_launch_ms()))
 lt = (p[:, 17] - p[:, 16]) / 1e5
 print("  lifetime percentiles (ms) 10/50/90/99/max: %s; steps 10/50/90/max: %s; us per step 10/50/90/max: %s" % (
     np.percentile(lt, [10, 50, 90, 99, 100]).round(1).tolist(), np.percentile(steps, [10, 50, 90, 100]).tolist(),
