@@ -20,6 +20,9 @@ Everything a round needs (seeds, action records, dispatch order) is produced on 
 kernel (ur5_set_stream): no host synchronisation inside a round except the outcome all_gather's own. A launch ends with its slowest
 scene, so scenes are dispatched longest-expected-first (ur5_set_order_dev): episode-ending scenes (attempt + 500 settle steps), then
 scenes with a box to carry, then attempts on an empty plate. The order changes the makespan only, never a result.
+For the same reason the rank's scenes are simulated as --groups G = 2 scene groups (one engine handle + one HIP stream each, half of the
+scenes each): the next round of one group is queued behind its current one while the other group's round is still running, so the wave
+slots that the tail of a launch leaves empty are taken by the other group's launch. Scenes, seeds and results are those of one group.
 
 Prints ONE JSON line on rank 0. value = env-steps/s of the whole job (2 ms physics steps actually executed, summed over all scenes
 and ranks, / max-over-ranks wall time of the K timed rounds); grasp-attempts/s next to it. N > 1: scenes shard over ranks
@@ -208,6 +211,7 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: 4096 scenes per GPU; strong: 4096 scenes in total, 4096 / N per GPU (SURVEY.md section 8e)")
     ap.add_argument("--rule", choices=("aimed", "uniform"), default="aimed", help="action rule of the timed rounds (see the module docstring)")
+    ap.add_argument("--groups", type=int, default=2, help="scene groups per GPU, one engine handle + HIP stream each, rounds pipelined (1 = one handle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the uniform-rule figure and the it4 / many sub-results (N = 1 only)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for 2 ranks on one device)")
@@ -235,42 +239,66 @@ def main():
     n_local = args.envs if args.envs else (4096 if args.scaling == "weak" else 4096 // world)
     n_total = n_local * world
     lo, hi = sharding.shard_range(n_total, rank, world)
-    sim = BatchSim(model, n_local, device_id=dev_id)
-    sim.reset(sharding.global_seeds(BASE_SEED, n_total, rank, world), 1, 1000.0)    # episode 0 of every scene (GraspingEnv.py:409-477), untimed
-    sim.set_stream(torch.cuda.current_stream().cuda_stream)
+    G = args.groups if n_local % max(1, args.groups) == 0 else 1
+    n_g = n_local // G
     rounds = args.warmup + args.steps
-    reward = torch.zeros((rounds, n_local), dtype=torch.int32, device=dev)
-    ids = torch.arange(lo, hi, dtype=torch.int32, device=dev)
 
-    def run_rounds(wl, r0, r1, reward):
+    class Group:
+        """One scene group of the rank: engine handle, its HIP stream (torch's, so that action tensors are stream-ordered with the launches)."""
+        def __init__(self, g, rule):
+            self.lo = lo + g * n_g
+            self.sim = BatchSim(model, n_g, device_id=dev_id)
+            self.sim.reset(BASE_SEED + np.arange(self.lo, self.lo + n_g, dtype=np.uint64), 1, 1000.0)   # episode 0 (GraspingEnv.py:409-477), untimed
+            self.stream = torch.cuda.Stream(device=dev) if G > 1 else torch.cuda.current_stream()
+            self.sim.set_stream(self.stream.cuda_stream)
+            with torch.cuda.stream(self.stream):
+                self.wl = It1Rounds(torch, model, self.sim, dev, self.lo, n_g, n_total, rule)
+                self.reward = torch.zeros((rounds + 8, n_g), dtype=torch.int32, device=dev)
+                self.ids = torch.arange(self.lo, self.lo + n_g, dtype=torch.int32, device=dev)
+
+    groups = [Group(g, args.rule) for g in range(G)]
+    torch.cuda.synchronize()
+
+    def run_rounds(r0, r1, wls=None):
+        gathered = None
         for r in range(r0, r1):
-            act, pixel = wl.launch(r, reward[r])                                   # attempt (+ reset_model for the scenes whose episode ends)
-            rec = torch.stack([ids, pixel, act[:, 3].to(torch.int32), reward[r]], dim=1)
-            gathered = sharding.gather_outcomes(rec)                               # the path's only collective: 16 B per scene per round
+            for k, gr in enumerate(groups):
+                with torch.cuda.stream(gr.stream):
+                    wl = gr.wl if wls is None else wls[k]
+                    act, pixel = wl.launch(r, gr.reward[r])                        # attempt (+ reset_model for the scenes whose episode ends)
+                    rec = torch.stack([gr.ids, pixel, act[:, 3].to(torch.int32), gr.reward[r]], dim=1)
+                    gathered = sharding.gather_outcomes(rec)                       # the path's only collective: 16 B per scene per round
         return gathered
 
-    def timed(wl, r0, r1, reward):
-        sim.sync()
-        c0, k0 = sim.counters(), sim.kernel_ms_total()
+    def counters():
+        cs = [gr.sim.counters() for gr in groups]
+        return {k: np.concatenate([c[k] for c in cs]) for k in cs[0]}
+
+    def timed(r0, r1, wls=None):
+        for gr in groups:
+            gr.sim.sync()
+        c0, k0 = counters(), sum(gr.sim.kernel_ms_total() for gr in groups)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        g = run_rounds(wl, r0, r1, reward)
+        g = run_rounds(r0, r1, wls)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         elapsed = time.perf_counter() - t0
-        sim.sync()                                                                 # resolves the HIP event pairs of the region's launches
-        c1, k1 = sim.counters(), sim.kernel_ms_total()
+        for gr in groups:
+            gr.sim.sync()                                                          # resolves the HIP event pairs of the region's launches
+        c1, k1 = counters(), sum(gr.sim.kernel_ms_total() for gr in groups)
         return elapsed, c0, c1, k1 - k0, g
 
-    wl = It1Rounds(torch, model, sim, dev, lo, n_local, n_total, args.rule)
-    run_rounds(wl, 0, args.warmup, reward)
-    elapsed, c0, c1, kernel_ms, gathered = timed(wl, args.warmup, rounds, reward)
-    assert gathered.shape == (n_total, 4)
+    run_rounds(0, args.warmup)
+    elapsed, c0, c1, kernel_ms, gathered = timed(args.warmup, rounds)
+    assert gathered.shape == (n_g * world, 4)
+    reward = torch.cat([gr.reward[:rounds] for gr in groups], dim=1)
     steps_local = int((c1["total_steps"] - c0["total_steps"]).sum())
     per_round = reward[args.warmup:].double().mean(dim=1)
+    elapsed_local = elapsed
     stats = torch.tensor([elapsed, float(steps_local), float(reward[args.warmup:].sum().item())], dtype=torch.float64, device=dev)
     if world > 1:
         tmax = stats[:1].clone()
@@ -285,7 +313,9 @@ def main():
         # algorithmic HBM bytes per env-step: (nq + 2 nv + 5 nu + 8) words, read + written, fp64
         words = model.nq + 2 * model.nv + 5 * model.nu + 8
         bytes_per_step = 2 * words * 8
-        achieved = steps_local * bytes_per_step / (kernel_ms * 1e-3) / 1e9
+        # G launches (one per scene group) are in flight at once and share the chip: the rate is taken over the wall time of the timed region,
+        # which the engine kernels of the G streams cover back to back (their HIP-event durations are reported next to it)
+        achieved = steps_local * bytes_per_step / elapsed_local / 1e9
         traffic, traffic_src = None, "not measured in this run (PMC passes are separate rocprofv3 runs)"
         tp = os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")
         if os.path.exists(tp):
@@ -309,31 +339,39 @@ def main():
                                    "(+ 1000 ms settle) for the quarter of the batch that starts an episode in the round",
                        "rule": ("aimed: current position of a box still on the pick plate, read from the state records on the device" if args.rule == "aimed"
                                 else "uniform: uniformly drawn table pixel, rotation 0 (SURVEY.md 8d / Grasping_Agent_multidiscrete.py:266-280)"),
-                       "scenes_per_gpu": n_local, "scenes_total": n_total, "solver": "Newton (MuJoCo default; north_star says PGS, see DESIGN.md D1), "
+                       "scenes_per_gpu": n_local, "scenes_total": n_total, "scene_groups_per_gpu": G, "solver": "Newton (MuJoCo default; north_star says PGS, see DESIGN.md D1), "
                        f"tolerance 1e-10, iteration cap {model.opt['iterations']}", "timestep_s": model.opt["timestep"],
                        "parallelism": f"scenes sharded x{world}, 1 all_gather of 16 B outcome records per round"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                          "traffic_source": traffic_src, "kernel": "ur5_run_kernel<32>", "bytes_per_env_step": bytes_per_step,
-                         "kernel_ms_per_round": kernel_ms / args.steps, "env_steps_per_round": steps_local / args.steps,
-                         "note": "algorithmic state bytes x env-steps / summed HIP-event time of the engine kernels of the timed rounds (one "
-                                 "attempt + episode-reset launch per round, rank 0). A scene stays in LDS for a whole launch, so the algorithmic figure is an accounting "
+                         "avg_launch_ms": kernel_ms / (args.steps * G), "launches_per_round": G, "launch_concurrency": G,
+                         "env_steps_per_launch": steps_local / (args.steps * G),
+                         "kernel_ms_per_round": 1e3 * elapsed_local / args.steps, "env_steps_per_round": steps_local / args.steps,
+                         "note": "algorithmic state bytes x env-steps of the timed rounds / their wall time on rank 0: one attempt + episode-reset "
+                                 "launch per scene group and round, the groups' launches overlapping on their own HIP streams (avg_launch_ms = "
+                                 "HIP-event duration of one launch; achieved = launch_concurrency x bytes per launch / avg_launch_ms up to the "
+                                 "overlap at the region's ends). A scene stays in LDS for a whole launch, so the algorithmic figure is an accounting "
                                  "unit, not the traffic: the step is latency / VALU-issue bound (DESIGN.md section 3)"},
         }
         if world == 1 and not args.no_extras:
             # second figure: SURVEY.md 8d's own action rule, same episode structure, a few rounds continuing from the current state
-            wl_u = It1Rounds(torch, model, sim, dev, lo, n_local, n_total, "uniform")
-            ur = max(2, min(4, args.steps))
-            rew_u = torch.zeros((rounds + 1 + ur, n_local), dtype=torch.int32, device=dev)
-            run_rounds(wl_u, rounds, rounds + 1, rew_u)
-            e_u, cu0, cu1, k_u, _ = timed(wl_u, rounds + 1, rounds + 1 + ur, rew_u)
+            wls_u = []
+            for gr in groups:
+                with torch.cuda.stream(gr.stream):
+                    wls_u.append(It1Rounds(torch, model, gr.sim, dev, gr.lo, n_g, n_total, "uniform"))
+            ur = max(2, min(4, args.steps))                                        # rounds + 1 + ur <= rounds + 8 rows of the reward buffers
+            run_rounds(rounds, rounds + 1, wls_u)
+            e_u, cu0, cu1, k_u, _ = timed(rounds + 1, rounds + 1 + ur, wls_u)
             st_u = int((cu1["total_steps"] - cu0["total_steps"]).sum())
+            succ_u = sum(float(gr.reward[rounds + 1:rounds + 1 + ur].sum().item()) for gr in groups)
             out["uniform_rule"] = {"rounds": ur, "env_steps_per_s": st_u / e_u, "grasp_attempts_per_s": ur * n_local / e_u,
-                                   "grasp_success_rate": float(rew_u[rounds + 1:].sum().item()) / (ur * n_local),
+                                   "grasp_success_rate": succ_u / (ur * n_local),
                                    "env_steps_per_attempt": st_u / (ur * n_local),
                                    "rule": "uniformly drawn table pixel, rotation 0, z = 0.91 (SURVEY.md section 8d config 2)"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model)
-    sim.close()
+    for gr in groups:
+        gr.sim.close()
     if rank == 0 and world == 1 and not args.no_extras:
         torch.cuda.synchronize()
         out["it4"] = rendered_sub_result(torch, dev, dev_id, "it4", 4096, 2, 1)

@@ -43,7 +43,15 @@ __global__ void UR5_KERNEL_ATTR(GS) ur5_run_kernel(double* __restrict__ rec, Ur5
 }
 
 // the model sits in __constant__ memory (one copy per device); a handle re-uploads it only when another handle used the device last
+// (several handles with the SAME model -- scene groups on separate streams -- share the copy: the upload is keyed by a hash of the struct)
 static ur5_sim* g_model_owner[64] = {nullptr};
+static uint64_t g_model_hash[64] = {0};
+static uint64_t model_hash(const Ur5DevModel& m) {
+  const unsigned char* p = reinterpret_cast<const unsigned char*>(&m);
+  uint64_t h = 1469598103934665603ull;
+  for (size_t i = 0; i < sizeof(Ur5DevModel); i++) { h ^= p[i]; h *= 1099511628211ull; }
+  return h ? h : 1;
+}
 
 // RGB-D observation in two launches. (1) ur5_render_pose_kernel, one 64-thread block per scene: the (serial, fp64) forward kinematics of
 // the scene ONCE, then every render geom's world pose and its conservative screen box. (2) ur5_render_kernel, one block per 16x16 pixel tile
@@ -159,7 +167,7 @@ static int be_open(ur5_sim* h, int device_id) {
 }
 static void be_close(ur5_sim* h) {
   HipBackend* b = (HipBackend*)h->be;
-  if (g_model_owner[h->device & 63] == h) g_model_owner[h->device & 63] = nullptr;
+  if (g_model_owner[h->device & 63] == h) g_model_owner[h->device & 63] = nullptr;   // the constant-memory copy stays valid for handles with the same hash
   if (!b) return;
   (void)hipSetDevice(h->device);
   if (b->stream) (void)hipStreamSynchronize(b->stream);
@@ -237,8 +245,12 @@ static int be_reset_dev(ur5_sim* h, const uint64_t* seeds_dev, const uint8_t* ma
 }
 static int be_upload_model(ur5_sim* h) {
   if (g_model_owner[h->device & 63] != h) {
-    HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(ur5_cmodel), &h->hm, sizeof(Ur5DevModel), 0, hipMemcpyHostToDevice));
+    if (!h->model_hash) h->model_hash = model_hash(h->hm);
+    if (g_model_hash[h->device & 63] != h->model_hash) {
+      HIPCHK(hipDeviceSynchronize());
+      HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(ur5_cmodel), &h->hm, sizeof(Ur5DevModel), 0, hipMemcpyHostToDevice));
+      g_model_hash[h->device & 63] = h->model_hash;
+    }
     g_model_owner[h->device & 63] = h;
   }
   return 0;

@@ -414,6 +414,7 @@ struct ur5_sim {
   double *d_target = nullptr, *d_tol = nullptr, *d_debug = nullptr, *d_hess = nullptr, *d_qpos0 = nullptr;
   void* d_gpose = nullptr;        // render: per-scene geom poses + screen boxes (HIP backend)
   const int* d_order = nullptr;   // caller-owned dispatch order of the scripted launches (ur5_set_order_dev), NULL = scene order
+  uint64_t model_hash = 0;        // of hm: handles with equal models share the device's constant-memory copy
   double kernel_ms_total = 0;   // engine-kernel time of every launch since ur5_create (HIP events on the handle's stream)
   int *d_max = nullptr, *d_result = nullptr, *d_steps = nullptr, *d_ps = nullptr, *d_pr = nullptr;
   std::vector<double> h_rec;
