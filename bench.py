@@ -149,7 +149,9 @@ def cpu_baseline(model, budget_s=12.0, many=False):
 
 def rendered_sub_result(torch, dev, local_rank, workload, n, rounds, warmup):
     """Short N=1 measurement of the render + grasp-round shape of BASELINE.json configs[2] (it4) / configs[3] (many) so that the driver's
-    one line also times them: `rounds` timed rounds after `warmup`, actions aimed (from the reset state) at distinct objects per round."""
+    one line also times them: `rounds` timed rounds after `warmup`. Every round renders the 200x200 RGB-D observation and aims at the pixel
+    over one of the objects in the pick bin (a different one per round); the grasp height comes from the rendered depth at that pixel
+    (GraspEnv.step, GraspingEnv.py:100-104), on the device."""
     from mujoco_rl_ur5_amd.model import load_model
     from mujoco_rl_ur5_amd.native import BatchSim
     many = workload == "many"
@@ -158,15 +160,23 @@ def rendered_sub_result(torch, dev, local_rank, workload, n, rounds, warmup):
     sim.reset(BASE_SEED + np.arange(n, dtype=np.uint64), 1, 1000.0)
     nobj = (model.nv - 8) // 6
     xpos = sim.body_xpos()[:, 8:8 + nobj]
+    from mujoco_rl_ur5_amd.controller import MJ_Controller
+    ctl = MJ_Controller(model, sim, None)
     acts = np.zeros((warmup + rounds, n, 8))
+    pix = np.zeros((warmup + rounds, n, 2), dtype=np.int64)
     for r in range(warmup + rounds):
         for e in range(n):
             objs = xpos[e]
             inbin = np.where((np.abs(objs[:, 0]) < 0.2) & (np.abs(objs[:, 1] + 0.6) < 0.13) & (objs[:, 2] > 0.85))[0]
             k = inbin[(e + r) % len(inbin)] if len(inbin) else 0
-            acts[r, e, :3] = [objs[k, 0], objs[k, 1], objs[k, 2] + 0.02]       # 2 cm above the centre: what the depth image gives
+            px, py = ctl.world_2_pixel(objs[k], 200, 200)                      # the pixel over the object's centre
+            pix[r, e] = [min(max(int(px), 0), 199), min(max(int(py), 0), 199)]
+            acts[r, e, :2] = objs[k, :2]
             acts[r, e, 3] = (e + r) % 6
     actions = torch.from_numpy(acts).to(dev)
+    pix_t = torch.from_numpy(pix).to(dev)
+    cam_z = float(model.cam_pos0[model.camera_name2id("top_down")][2])
+    scene = torch.arange(n, device=dev)
     img = torch.zeros((n, 200, 200, 3), dtype=torch.uint8, device=dev)
     dep = torch.zeros((n, 200, 200), dtype=torch.float32, device=dev)
     reward = torch.zeros((warmup + rounds, n), dtype=torch.int32, device=dev)
@@ -174,7 +184,8 @@ def rendered_sub_result(torch, dev, local_rank, workload, n, rounds, warmup):
     sim.set_stream(torch.cuda.current_stream().cuda_stream)
 
     def one(r):
-        sim.render_dev(img.data_ptr(), dep.data_ptr(), cam, 200, 200, 1)            # get_observation (GraspingEnv.py:390-406)
+        sim.render_dev(img.data_ptr(), dep.data_ptr(), cam, 200, 200, 0)            # get_observation (GraspingEnv.py:390-406), metric depth
+        actions[r, :, 2] = cam_z - dep[scene, pix_t[r, :, 1], pix_t[r, :, 0]].double()   # top-down camera: world z of what the pixel shows
         sim.grasp_attempt_dev(actions[r].data_ptr(), reward[r].data_ptr(), check_mode=0, table_height=0.91)
     for r in range(warmup):
         one(r)
@@ -375,7 +386,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_extras:
         torch.cuda.synchronize()
         out["it4"] = rendered_sub_result(torch, dev, dev_id, "it4", 4096, 2, 1)
-        out["many"] = rendered_sub_result(torch, dev, dev_id, "many", 512, 2, 1)
+        out["many"] = rendered_sub_result(torch, dev, dev_id, "many", 2048, 1, 1)   # BASELINE configs[3]: 2048 piles per GPU
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
