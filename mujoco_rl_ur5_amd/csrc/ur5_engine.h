@@ -3041,9 +3041,6 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     if (UR5_LANE == 0) {
       if (P.result) P.result[env] = result;
       if (P.steps) P.steps[env] = S.last_steps;
-#if defined(UR5_PROFILE) && !defined(UR5_EMUL)
-      if (P.debug && P.op != UR5_OP_FORWARD) for (int i = 0; i < PF_COUNT; i++) P.debug[(size_t)UR5_DEBUG_STRIDE * env + i] = S.prof[i];
-#endif
     }
   }
 
@@ -3053,6 +3050,12 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
   // scripts; with this shape they still execute every physics step together, and only the short control code of (a) diverges.
   UR5_FN void run(const Ur5Launch& P, int env, bool live = true) {
     if constexpr (FLAT) run_flat(P, env, live); else { if (live) run_nested(P, env); }
+#if defined(UR5_PROFILE) && !defined(UR5_EMUL)
+    if (live && UR5_LANE == 0 && P.debug && P.op != UR5_OP_FORWARD) {   // [PF_CORECLK] = start, [PF_REALCLK] = end of the scene's wave, 100 MHz ticks
+      S.prof[PF_REALCLK] = (double)wall_clock64();
+      for (int i = 0; i < PF_COUNT; i++) P.debug[(size_t)UR5_DEBUG_STRIDE * env + i] = S.prof[i];
+    }
+#endif
   }
   UR5_FN void run_flat(const Ur5Launch& P, int env, bool live) {
     const int op = P.op;
@@ -3248,10 +3251,6 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     if (live && UR5_LANE == 0) {
       if (P.result) P.result[env] = result;
       if (P.steps) P.steps[env] = S.last_steps;
-#if defined(UR5_PROFILE) && !defined(UR5_EMUL)
-      S.prof[PF_REALCLK] = (double)wall_clock64();   // [PF_CORECLK] = start, [PF_REALCLK] = end of the scene's wave, 100 MHz ticks
-      if (P.debug && P.op != UR5_OP_FORWARD) for (int i = 0; i < PF_COUNT; i++) P.debug[(size_t)UR5_DEBUG_STRIDE * env + i] = S.prof[i];
-#endif
     }
   }
 

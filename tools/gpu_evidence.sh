@@ -6,7 +6,7 @@ TAG=${1:-ev}
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
-CMD="python $REPO/bench.py --steps 3 --warmup 2 --no-extras --no-cpu-baseline"
+CMD="python $REPO/bench.py --steps 4 --warmup 2 --no-extras --no-cpu-baseline"
 cd /tmp; export TMPDIR=/tmp
 timeout 300 $CMD > $OUT/bench_plain.json 2> $OUT/bench_plain.err
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o r -- $CMD > $OUT/bench_stats.json 2> $OUT/stats.err
@@ -14,5 +14,5 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_
   d=$OUT/pmc_$(echo $grp | cut -d' ' -f1)
   timeout 400 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $d -o r -- $CMD > $d.json 2> $d.err
 done
-python $REPO/tools/rocprof_summary.py $OUT $OUT/bench_plain.json $OUT/r02_d > $OUT/summary.json 2> $OUT/summary.err
+python $REPO/tools/rocprof_summary.py $OUT $OUT/bench_plain.json $OUT/r02_f > $OUT/summary.json 2> $OUT/summary.err
 ls $OUT

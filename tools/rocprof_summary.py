@@ -23,7 +23,9 @@ def main():
     d, bench_json, prefix = sys.argv[1], sys.argv[2], sys.argv[3]
     bench = json.loads([l for l in open(bench_json) if l.startswith("{")][-1])
     steps = bench["steps"]
-    env_steps = bench["roofline"].get("env_steps_per_round", bench["roofline"].get("env_steps_per_launch"))   # one engine launch per round
+    lpr = int(bench["roofline"].get("launches_per_round", 1))            # one engine launch per scene group and round
+    env_steps = bench["roofline"].get("env_steps_per_launch", bench["roofline"].get("env_steps_per_round"))
+    launches = steps * lpr
     # kernel stats
     for p in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
         rs = rows(p)
@@ -44,7 +46,7 @@ def main():
     lines = []
     for name, disp in sorted(per.items()):
         vals = [v for _, v in sorted(disp.items())]
-        timed = vals[-steps:]                      # the warm-up and reset launches come first
+        timed = vals[-launches:]                      # the warm-up and reset launches come first
         out[name] = sum(timed) / len(timed)
         lines.append(f"{name} = {out[name]:.4e}   (mean of the {len(timed)} timed launches; all launches: {['%.3e' % v for v in vals]})")
     if lines:
