@@ -352,7 +352,7 @@ def main():
                                 else "uniform: uniformly drawn table pixel, rotation 0 (SURVEY.md 8d / Grasping_Agent_multidiscrete.py:266-280)"),
                        "scenes_per_gpu": n_local, "scenes_total": n_total, "scene_groups_per_gpu": G, "solver": "Newton (MuJoCo default; north_star says PGS, see DESIGN.md D1), "
                        f"tolerance 1e-10, iteration cap {model.opt['iterations']}", "timestep_s": model.opt["timestep"],
-                       "parallelism": f"scenes sharded x{world}, 1 all_gather of 16 B outcome records per round"},
+                       "parallelism": f"scenes sharded x{world}, 1 all_gather of 16 B outcome records per scene group and round"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                          "traffic_source": traffic_src, "kernel": "ur5_run_kernel<32>", "bytes_per_env_step": bytes_per_step,
                          "avg_launch_ms": kernel_ms / (args.steps * G), "launches_per_round": G, "launch_concurrency": G,

@@ -104,3 +104,37 @@ def test_color_jitter_is_torchvisions_colorjitter_for_a_batch():
     assert f.unique().numel() == 6
     # saturation 0 end of the range collapses to the grey image (torchvision: blend(img, gray, s))
     assert torch.allclose(0.0 * x + 1.0 * _gray(x).expand_as(x), _gray(x).expand_as(x))
+
+
+@pytest.mark.gpu
+def test_graspenv_step_on_gpu_host_path_equals_device_path_and_the_oracle(model_it1):
+    """GraspEnv.step (GraspingEnv.py:62-156) on the MI355X through its HOST surface -- pixel action, depth lookup, back-projection, skip rule,
+    one kernel launch, reward, new observation -- against (a) step_device on the same actions and (b) the oracle's move_and_grasp from the
+    same coordinates for the non-skipped scenes."""
+    from oracle.oracle import Oracle
+    n = 6
+    a = GraspEnv(file=model_it1, n_envs=n, show_obs=False, observation="render")
+    b = GraspEnv(file=model_it1, n_envs=n, show_obs=False, observation="render")
+    a.reset(); b.reset()
+    q = a.sim.get_state()["qpos"]
+    act = np.zeros((n, 2), dtype=np.int64)
+    for e in range(n):
+        k = e % 4
+        px, py = a.controller.world_2_pixel([q[e][8 + 7 * k], -0.6 + q[e][8 + 7 * k + 1], 0.951])
+        act[e] = [py * 200 + px, e % 6]
+    act[5] = [3 * 200 + 3, 0]                                                 # a corner pixel: the floor beside the table -> skipped (:124)
+    obs, reward, done, info = a.step(act)
+    dev = b.observation_device()
+    r_dev, skipped = b.step_device(torch.from_numpy(act).cuda(), dev["depth"])
+    assert done is False and obs["depth"].shape == (n, 200, 200) and np.array_equal(reward, r_dev.cpu().numpy())
+    assert info["skipped"].tolist() == skipped.cpu().tolist() == [False] * 5 + [True]
+    # the two paths back-project the pixel in different arithmetic (numpy on the host, torch on the device): last-bit differences of the target
+    assert np.allclose(a.sim.get_state()["qpos"][:, :8], b.sim.get_state()["qpos"][:, :8], atol=1e-6)
+    x, y = act[:, 0] % 200, act[:, 0] // 200
+    depth0 = dev["depth"].cpu().numpy()
+    coords = a.controller.pixel_2_world_batch(x, y, depth0[np.arange(n), y, x])
+    for e in (0, 3):
+        o = Oracle(model_it1)
+        o.reset(20 + e, 1, True)
+        r, ps, pr = o.grasp_attempt(coords[e], int(act[e, 1]), 0)
+        assert r == reward[e] and ps.tolist() == info["phase_steps"][e].tolist()
