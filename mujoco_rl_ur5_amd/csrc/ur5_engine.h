@@ -2794,10 +2794,14 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
   UR5_FN unsigned mask_all() const { return (1u << M.nu) - 1u; }
 
   // ee_link pose for the 6 arm angles; every lane computes it (wave-uniform)
-  UR5_BIG void arm_fk(const real* q6, v3* p, m3* Rout, v3* axes, v3* anchors) const {
+  // (loops over the 6 arm joints / the 5 x 6 normal equations have compile-time bounds and are fully unrolled: q, the axes, J and A then
+  // live in registers -- with run-time indices they were scratch-memory arrays and one IK call cost as much as 6 physics steps)
+  UR5_BIG void arm_fk(const real (&q6)[6], v3* p, m3* Rout, v3 (&axes)[6], v3 (&anchors)[6]) const {
     v3 pos;
     q4 quat{1, 0, 0, 0};
-    for (int d = 0; d <= M.ee_cbody; d++) {
+#pragma unroll
+    for (int d = 0; d < 6; d++) {
+      if (d > M.ee_cbody) continue;
       pos = pos + mul(qmat(quat), v3(M.rd_pos[d]));
       quat = qmul(quat, q4{(real)M.rd_quat[d][0], (real)M.rd_quat[d][1], (real)M.rd_quat[d][2], (real)M.rd_quat[d][3]});
       m3 Rb = qmat(quat);
@@ -2825,25 +2829,59 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       v3 xe = R.col(0);
       real r[6] = {p.x - tgt.x, p.y - tgt.y, p.z - tgt.z, xe.x, xe.y, xe.z + 1};
       real J[6][5];
+#pragma unroll
       for (int j = 0; j < 5; j++) {
         v3 dp = cross(ax[j], p - an[j]), dx = cross(ax[j], xe);
         J[0][j] = dp.x; J[1][j] = dp.y; J[2][j] = dp.z; J[3][j] = dx.x; J[4][j] = dx.y; J[5][j] = dx.z;
       }
       real A[5][6];
+#pragma unroll
       for (int i = 0; i < 5; i++) {
-        for (int j = 0; j < 5; j++) { real s = 0; for (int k = 0; k < 6; k++) s += J[k][i] * J[k][j]; A[i][j] = s; }
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+          real s = 0;
+#pragma unroll
+          for (int k = 0; k < 6; k++) s += J[k][i] * J[k][j];
+          A[i][j] = s;
+        }
         A[i][i] += lambda;
-        real s = 0; for (int k = 0; k < 6; k++) s += J[k][i] * r[k];
+        real s = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) s += J[k][i] * r[k];
         A[i][5] = -s;
       }
+#pragma unroll
       for (int c = 0; c < 5; c++) {
         int piv = c;
-        for (int i = c + 1; i < 5; i++) if (fabs(A[i][c]) > fabs(A[piv][c])) piv = i;
-        for (int k = 0; k < 6; k++) { real t = A[c][k]; A[c][k] = A[piv][k]; A[piv][k] = t; }
-        for (int i = c + 1; i < 5; i++) { real f = A[i][c] / A[c][c]; for (int k = c; k < 6; k++) A[i][k] -= f * A[c][k]; }
+        real best = fabs(A[c][c]);
+#pragma unroll
+        for (int i = c + 1; i < 5; i++) { const real v = fabs(A[i][c]); if (v > best) { best = v; piv = i; } }   // = "if |A[i][c]| > |A[piv][c]|"
+#pragma unroll
+        for (int k = 0; k < 6; k++) {   // swap rows c and piv without a run-time row index
+          const real rc = A[c][k];
+          real rp = rc;
+#pragma unroll
+          for (int i = c + 1; i < 5; i++) rp = piv == i ? A[i][k] : rp;
+#pragma unroll
+          for (int i = c + 1; i < 5; i++) A[i][k] = piv == i ? rc : A[i][k];
+          A[c][k] = rp;
+        }
+#pragma unroll
+        for (int i = c + 1; i < 5; i++) {
+          const real f = A[i][c] / A[c][c];
+#pragma unroll
+          for (int k = c; k < 6; k++) A[i][k] -= f * A[c][k];
+        }
       }
       real dq[5];
-      for (int i = 4; i >= 0; i--) { real s = A[i][5]; for (int k = i + 1; k < 5; k++) s -= A[i][k] * dq[k]; dq[i] = s / A[i][i]; }
+#pragma unroll
+      for (int i = 4; i >= 0; i--) {
+        real s = A[i][5];
+#pragma unroll
+        for (int k = i + 1; k < 5; k++) s -= A[i][k] * dq[k];
+        dq[i] = s / A[i][i];
+      }
+#pragma unroll
       for (int j = 0; j < 5; j++) q[j] = clampv(q[j] + clampv(dq[j], (real)-0.5, (real)0.5), (real)M.rd_lo[j], (real)M.rd_hi[j]);
     }
     v3 p; m3 R; v3 ax[6], an[6];
