@@ -1661,7 +1661,9 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       if (S.cdim[c] == 1) {
         if (e0 < 0) { c0 += (real)0.5 * D * e0 * e0; g1 += D * e0 * j0; g2 += D * j0 * j0; }
       } else {
-        for (int k = 1; k < S.cdim[c]; k++) {
+#pragma unroll
+        for (int k = 1; k < NB; k++) {
+          if (k >= S.cdim[c]) continue;
           real mu = row_mu(c, k);
           real ek = mu * (S.ce[c][k] + alpha * S.cde[c][k]), jk = mu * S.cde[c][k];
           real rp = e0 + ek, rm = e0 - ek;
@@ -1691,12 +1693,17 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
   // base-space forces fb and the "arrow" weight matrix W (w[0] = W_00, w[k] = W_0k, w[NB-1+k] = W_kk) of contact c at S.ce
   UR5_FN void contact_weights(int c, real* fb, real* w) const {
     real D = S.cD[c], e0 = S.ce[c][0];
+#pragma unroll
     for (int k = 0; k < NB; k++) fb[k] = 0;
+#pragma unroll
     for (int k = 0; k < 2 * NB - 1; k++) w[k] = 0;
     if (S.cdim[c] == 1) {
       if (e0 < 0) { fb[0] = -D * e0; w[0] = D; }
     } else {
-      for (int k = 1; k < S.cdim[c]; k++) {
+      const int cdim = S.cdim[c];
+#pragma unroll
+      for (int k = 1; k < NB; k++) {   // compile-time trip count: fb / w stay in registers (a run-time bound made them scratch-memory arrays)
+        if (k >= cdim) continue;
         real mu = row_mu(c, k), ek = mu * S.ce[c][k];
         real rp = e0 + ek, rm = e0 - ek;
         real ap = rp < 0 ? (real)1 : (real)0, am = rm < 0 ? (real)1 : (real)0;
@@ -2615,12 +2622,16 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
         real ew[NB], es[NB];
         contact_image(c, S.tw[slA], S.tw[slB], hasA, hasB, ew);
         contact_image(c, S.WB[slA], S.WB[slB], hasA, hasB, es);
+#pragma unroll
         for (int k = 0; k < NB; k++) { ew[k] += S.ceoff[c][k]; es[k] += S.ceoff[c][k]; S.ce[c][k] = ew[k]; S.cde[c][k] = es[k]; }
         const real D = S.cD[c];
         if (S.cdim[c] == 1) {
           if (ew[0] < 0) c_w += (real)0.5 * D * ew[0] * ew[0];
           if (es[0] < 0) c_s += (real)0.5 * D * es[0] * es[0];
-        } else for (int k = 1; k < S.cdim[c]; k++) {
+        } else
+#pragma unroll
+        for (int k = 1; k < NB; k++) {   // compile-time trip count keeps ew / es in registers
+          if (k >= S.cdim[c]) continue;
           const real mu = row_mu(c, k);
           real rp = ew[0] + mu * ew[k], rm = ew[0] - mu * ew[k];
           if (rp < 0) c_w += (real)0.5 * D * rp * rp;
