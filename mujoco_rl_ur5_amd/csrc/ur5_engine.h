@@ -267,13 +267,8 @@ template <class real, int NV_> struct Lds {
   real Lr[UR5_MAXRD][UR5_MAXRD + 1], Ld[UR5_MAXRD][UR5_MAXRD + 1];   // GPU build: the two factors live in registers (Fact)
 #endif
   real Mobj[6 * UR5_MAXOBJ];
-#ifdef UR5_EMUL
-  static constexpr int HSIZE = NV_ * (NV_ + 1);      // unpacked staging, generic LDS Cholesky
-#define UR5_HIDX(i, j) ((i) * (NV_ + 1) + (j))
-#else
-  static constexpr int HSIZE = NV_ * (NV_ + 1) / 2;  // packed lower triangle
+  static constexpr int HSIZE = NV_ * (NV_ + 1) / 2;  // packed lower triangle (GPU and lane emulation alike)
 #define UR5_HIDX(i, j) ((i) * ((i) + 1) / 2 + (j))
-#endif
   // The Hessian staging area shares its LDS with everything that is dead once the constraint rows exist: per-step
   // kinematic temporaries, body velocities and the moving geoms' poses are all recomputed by the next step.
   union {
@@ -1931,11 +1926,21 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       SYNC();
     }
     PROF(PF_HASM);
-#ifdef UR5_EMUL
-    cholesky(S.H, nv, LD);
-    chol_solve(S.H, nv, LD, S.search);
-    PAR(i, nv) S.search[i] = -S.search[i];
-    SYNC();
+#ifdef UR5_EMUL   // lane emulation: the same packed H, factored and solved in place (the GPU keeps row i in the registers of lane i)
+    for (int j = 0; j < nv; j++) {
+      real d = S.H[UR5_HIDX(j, j)];
+      for (int k = 0; k < j; k++) d -= S.H[UR5_HIDX(j, k)] * S.H[UR5_HIDX(j, k)];
+      d = sqrt(d < (real)1e-15 ? (real)1e-15 : d);
+      S.H[UR5_HIDX(j, j)] = d;
+      for (int i = j + 1; i < nv; i++) {
+        real v = S.H[UR5_HIDX(i, j)];
+        for (int k = 0; k < j; k++) v -= S.H[UR5_HIDX(i, k)] * S.H[UR5_HIDX(j, k)];
+        S.H[UR5_HIDX(i, j)] = v / d;
+      }
+    }
+    for (int i = 0; i < nv; i++) { real v = S.search[i]; for (int k = 0; k < i; k++) v -= S.H[UR5_HIDX(i, k)] * S.search[k]; S.search[i] = v / S.H[UR5_HIDX(i, i)]; }
+    for (int i = nv - 1; i >= 0; i--) { real v = S.search[i]; for (int k = i + 1; k < nv; k++) v -= S.H[UR5_HIDX(k, i)] * S.search[k]; S.search[i] = v / S.H[UR5_HIDX(i, i)]; }
+    for (int i = 0; i < nv; i++) S.search[i] = -S.search[i];
 #else
     (void)LD;
     if constexpr (FLAT) factor_solve_rows_body<false>(); else factor_solve_rows<false>();
