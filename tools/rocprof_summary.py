@@ -56,6 +56,11 @@ def main():
             for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"):
                 if k in out:
                     f.write(f"{k} per env-step: {out[k] / env_steps:.0f}\n")
+            if "SQ_THREAD_CYCLES_VALU" in out and "SQ_ACTIVE_INST_VALU" in out and out["SQ_ACTIVE_INST_VALU"] > 0:
+                # thread-cycles spent in VALU instructions over (cycles VALU instructions were executing x 64 lanes): the share of lanes doing work
+                f.write(f"VALU lane utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU) = {out['SQ_THREAD_CYCLES_VALU'] / (64.0 * out['SQ_ACTIVE_INST_VALU']):.3f}\n")
+            if "SQ_ACTIVE_INST_VALU" in out and "SQ_WAVE_CYCLES" in out:
+                f.write(f"VALU busy share of resident-wave time = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES = {out['SQ_ACTIVE_INST_VALU'] / out['SQ_WAVE_CYCLES']:.3f}\n")
     if "FETCH_SIZE" in out and "WRITE_SIZE" in out:
         # rocprofv3 reports both in KiB. MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE counts 128-byte read requests as 64 bytes for
         # wide coalesced streams -- double it; narrow accesses and WRITE_SIZE are uncalibrated. This kernel's traffic is register-spill
