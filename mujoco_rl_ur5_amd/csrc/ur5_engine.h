@@ -1045,6 +1045,14 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     v3 q0 = ic + Iu * inu + Iv * inv_, q1 = ic - Iu * inu + Iv * inv_, q2 = ic - Iu * inu - Iv * inv_, q3 = ic + Iu * inu - Iv * inv_;
     real u0 = dot(q0 - rc, Ru), u1 = dot(q1 - rc, Ru), u2 = dot(q2 - rc, Ru), u3 = dot(q3 - rc, Ru);
     real w0 = dot(q0 - rc, Rv), w1 = dot(q1 - rc, Rv), w2 = dot(q2 - rc, Rv), w3 = dot(q3 - rc, Rv);
+    // Ties (a corner ON a reference edge line: equal boxes stacked flush, as in the model's own qpos0) are decided once, here: a
+    // coordinate within `tie` of +-h IS +-h. Then every vertex of the closed intersection polygon has exactly one owner below --
+    // incident corners in the closed rectangle; reference corners in the closed incident face that are not also incident corners;
+    // crossings strictly inside both edges -- which is the vertex set the oracle's clipping yields whichever way the ties round.
+    const real tie = (real)(sizeof(real) == 8 ? 1e-9 : 1e-5);
+#define UR5_SNAP(x, h) x = fabs(fabs(x) - h) <= tie ? (x < 0 ? -h : h) : x;
+    UR5_SNAP(u0, hu) UR5_SNAP(u1, hu) UR5_SNAP(u2, hu) UR5_SNAP(u3, hu) UR5_SNAP(w0, hv) UR5_SNAP(w1, hv) UR5_SNAP(w2, hv) UR5_SNAP(w3, hv)
+#undef UR5_SNAP
 #define UR5_INC(q, u, w) if (fabs(u) <= hu && fabs(w) <= hv) { real d = dot(q - rc, nref); if (d < margin) emit(out, q - nref * ((real)0.5 * d), n, d); }
     UR5_INC(q0, u0, w0) UR5_INC(q1, u1, w1) UR5_INC(q2, u2, w2) UR5_INC(q3, u3, w3)
 #undef UR5_INC
@@ -1058,7 +1066,9 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
         v3 c0 = rc + Ru * ((k & 1) ? hu : -hu) + Rv * ((k & 2) ? hv : -hv);
         real d = dot(ic - c0, ninc) / den;
         v3 pc = c0 + nref * d;
-        if (fabs(dot(pc - ic, Iu)) < inu && fabs(dot(pc - ic, Iv)) < inv_ && d < margin) emit(out, pc - nref * ((real)0.5 * d), n, d);
+        real cu = fabs(dot(pc - ic, Iu)), cv = fabs(dot(pc - ic, Iv));
+        bool on_corner = fabs(cu - inu) <= tie && fabs(cv - inv_) <= tie;      // coincides with an incident corner: emitted above
+        if (cu <= inu + tie && cv <= inv_ + tie && !on_corner && d < margin) emit(out, pc - nref * ((real)0.5 * d), n, d);
       }
     }
     // incident edge (qa -> qb) against the four reference edge lines
@@ -1069,7 +1079,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
         real Oa = sd < 2 ? wa : ua, Ob = sd < 2 ? wb : ub, olim = sd < 2 ? hv : hu;                                 \
         if ((La - lim) * (Lb - lim) < 0) {                                                                          \
           real tt = (lim - La) / (Lb - La);                                                                         \
-          if (fabs(Oa + tt * (Ob - Oa)) < olim) {                                                                   \
+          if (fabs(Oa + tt * (Ob - Oa)) < olim - tie) {                                                             \
             v3 pe = qa + (qb - qa) * tt;                                                                            \
             real d = dot(pe - rc, nref);                                                                            \
             if (d < margin) emit(out, pe - nref * ((real)0.5 * d), n, d);                                           \

@@ -49,6 +49,8 @@ def lib():
         L.ur5o_reset.argtypes = [vp, C.c_uint64, C.c_int, C.c_int]
         L.ur5o_move_group.argtypes = [vp, C.c_uint, dp, C.c_double, C.c_int, ip]
         L.ur5o_move_group.restype = C.c_int
+        L.ur5o_move_group_plot.argtypes = [vp, C.c_uint, dp, C.c_double, C.c_int, C.c_int, C.c_int, ip, dp, ip, ip]
+        L.ur5o_move_group_plot.restype = C.c_int
         L.ur5o_stay.argtypes = [vp, C.c_double]
         L.ur5o_ik.argtypes = [vp, dp, dp]
         L.ur5o_ik.restype = C.c_int
@@ -150,6 +152,16 @@ class Oracle:
         t = None if target is None else np.ascontiguousarray(target, dtype=np.float64)
         r = lib().ur5o_move_group(self._h, mask, _dp(t), tol, max_steps, C.byref(steps))
         return r, steps.value
+
+    def move_group_plot(self, mask, target, tol, max_steps, every=2, cap=4096):
+        """move_group with the reference's plot=True recording: (result, steps, plot_steps[n], plot_q[n, group size])."""
+        nj = bin(mask).count("1")
+        ps, pq = np.zeros(cap, dtype=np.int32), np.zeros((cap, nj))
+        n, steps = C.c_int(0), C.c_int(0)
+        t = np.ascontiguousarray(target, dtype=np.float64)
+        r = lib().ur5o_move_group_plot(self._h, mask, _dp(t), tol, max_steps, every, cap, ps.ctypes.data_as(C.POINTER(C.c_int)), _dp(pq),
+                                       C.byref(n), C.byref(steps))
+        return r, steps.value, ps[:n.value], pq[:n.value]
 
     def stay(self, ms):
         lib().ur5o_stay(self._h, float(ms))

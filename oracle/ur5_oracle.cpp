@@ -926,6 +926,8 @@ struct Sim {
       for (int k = 0; k < np; k++) {
         V3 p0 = poly[k], p1 = poly[(k + 1) % np];
         double d0 = dot(p0 - rc, pn) - lim, d1 = dot(p1 - rc, pn) - lim;
+        if (std::fabs(d0) <= 1e-9) d0 = 0;  // a vertex ON the clip line stays, and an edge ALONG it yields no crossing: without this a
+        if (std::fabs(d1) <= 1e-9) d1 = 0;  // flush stack of equal boxes (the model's own qpos0) gets vertices where the rounding falls
         if (d0 <= 0) tmp[nn++] = p0;
         if ((d0 < 0 && d1 > 0) || (d0 > 0 && d1 < 0)) tmp[nn++] = p0 + (p1 - p0) * (d0 / (d0 - d1));
       }
@@ -1387,6 +1389,9 @@ struct Sim {
 
   // ------------------------------------------------------------------ controller layer
   // MujocoController.py:269-393. group_mask bit j = actuator j belongs to the group; target may be null.
+  int plot_every = 0, plot_cap = 0, plot_n = 0, plot_stride = 0;  // plot=True of move_group_to_joint_target (:275,303-304)
+  int* plot_steps = nullptr;
+  double* plot_q = nullptr;
   int move_group(unsigned group_mask, const double* tgt, double tolerance, int max_steps) {
     int k = 0;
     if (tgt) for (int j = 0; j < nu; j++) if (group_mask >> j & 1) target[j] = tgt[k++];
@@ -1399,6 +1404,12 @@ struct Sim {
         double q = qpos[M.jnt_qposadr[M.act_jntid[j]]];
         ctrl[j] = pid[j].eval(q, pid_dt);
         if (group_mask >> j & 1) maxdelta = std::max(maxdelta, std::fabs(target[j] - q));
+      }
+      if (plot_every && steps % plot_every == 0 && plot_n < plot_cap) {  // fill_plot_list, :338-339,639-652
+        plot_steps[plot_n] = steps;
+        int c = 0;
+        for (int j = 0; j < nu; j++) if (group_mask >> j & 1) plot_q[plot_n * plot_stride + c++] = qpos[M.jnt_qposadr[M.act_jntid[j]]];
+        plot_n++;
       }
       if (maxdelta < tolerance) { result = RES_SUCCESS; reached = true; }  // no break: one more sim.step() follows
       if (steps > max_steps) { result = RES_MAX_STEPS; break; }
@@ -1746,6 +1757,19 @@ void ur5o_reset(void* h, uint64_t seed, int mode, int settle) { ((Sim*)h)->reset
 int ur5o_move_group(void* h, unsigned mask, const double* target, double tol, int max_steps, int* steps) {
   Sim* s = (Sim*)h;
   int r = s->move_group(mask, target, tol, max_steps);
+  if (steps) *steps = s->last_steps;
+  return r;
+}
+// move_group with plot=True: the group's joint angles every `every` steps (the reference plots them, create_joint_angle_plot :654-705)
+int ur5o_move_group_plot(void* h, unsigned mask, const double* target, double tol, int max_steps, int every, int cap, int* plot_steps,
+                         double* plot_q, int* nplot, int* steps) {
+  Sim* s = (Sim*)h;
+  int stride = 0;
+  for (int j = 0; j < s->nu; j++) stride += mask >> j & 1;
+  s->plot_every = every; s->plot_cap = cap; s->plot_n = 0; s->plot_stride = stride; s->plot_steps = plot_steps; s->plot_q = plot_q;
+  int r = s->move_group(mask, target, tol, max_steps);
+  s->plot_every = 0;
+  if (nplot) *nplot = s->plot_n;
   if (steps) *steps = s->last_steps;
   return r;
 }

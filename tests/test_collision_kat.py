@@ -160,7 +160,33 @@ def case_capsules_parallel(model):
     return q, {g1, g2}, dict(dists=[-pen, -pen], points=pts, normal_axis=[0, 1, 0])
 
 
-CASES = [case_box_face_on_plate, case_box_edge_edge, case_cylinder_upright_on_plate, case_cylinder_tilted_on_plate, case_capsules_crossed,
+def _case_flush_cubes(model, shift, turn):
+    q, adr = _parked(model)
+    ga, gb = _geoms(model, BOX, [0.025, 0.025, 0.025])[:2]
+    a, pen, z0 = 0.025, 3e-4, 2.0
+    q[adr[ga]:adr[ga] + 7] = [0.0, -0.6, z0, 1, 0, 0, 0]
+    q[adr[gb]:adr[gb] + 7] = [shift, -0.6, z0 + 2 * a - pen, *_quat([0, 0, 1], turn)]
+    pts = [[x, -0.6 + y, z0 + a - 0.5 * pen] for x in (shift - a if shift > 0 else -a, a) for y in (-a, a)]
+    return q, {ga, gb}, dict(dists=[-pen] * 4, points=pts, normal_axis=[0, 0, 1])
+
+
+def case_equal_cubes_stacked_flush(model):
+    """Two equal cubes, one exactly on top of the other (what the reference's own qpos0 holds for its objects): every incident corner lies ON
+    two reference edge lines. Four contacts at the corners of the common face, whichever way those ties round."""
+    return _case_flush_cubes(model, 0.0, 0.0)
+
+
+def case_equal_cubes_flush_shifted(model):
+    """The upper cube shifted 1 cm along x: two of its edges run ALONG reference edge lines. The overlap rectangle's four corners."""
+    return _case_flush_cubes(model, 0.01, 0.0)
+
+
+def case_equal_cubes_flush_quarter_turn(model):
+    """The upper cube turned 90 deg about z (cos = 6e-17): ties that are off by rounding, not exact."""
+    return _case_flush_cubes(model, 0.0, np.pi / 2)
+
+
+CASES = [case_equal_cubes_stacked_flush, case_equal_cubes_flush_shifted, case_equal_cubes_flush_quarter_turn, case_box_face_on_plate, case_box_edge_edge, case_cylinder_upright_on_plate, case_cylinder_tilted_on_plate, case_capsules_crossed,
          case_capsules_parallel]
 
 
