@@ -91,3 +91,89 @@ def test_depth_statistics_of_100_resets_match_the_references_mean_and_std(model_
     assert d.shape == (n, 200, 200)
     assert abs(d.mean() - ref["mean"][3]) < 0.003 and abs(d.std() - ref["std"][3]) < 0.003, (d.mean(), d.std(), ref["mean"][3], ref["std"][3])
     assert env.sim.counters()["status"].max() == 0
+
+
+# ------------------------------------------------------------------------------------------------ media/overlay.png (reference-held image)
+def _overlay_json():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "overlay_png.json")) as f:
+        return json.load(f)
+
+
+def _overlay_gold():
+    return _overlay_json()["frame_edges_image_px"]
+
+
+def _check_layout_against_overlay(depth):
+    """Coarse layout of the whole picture: 'anything above the floor' on a 40 x 40 grid against the reference image's non-floor cells.
+    Sensitive to the image orientation (pedestal at the top, its extension on the LEFT: get_image_data's fliplr) and to what is where; cells
+    that straddle an outline in our image are skipped. The two pictures differ by a scene revision and blue objects read as floor: 97 %."""
+    ref = np.array([[ch == "#" for ch in row] for row in _overlay_json()["structure_mask_40x40"]])
+    ours, sure = np.zeros((40, 40), dtype=bool), np.zeros((40, 40), dtype=bool)
+    for i in range(40):
+        for j in range(40):
+            blk = depth[5 * i:5 * i + 5, 5 * j:5 * j + 5] < 1.95
+            ours[i, j], sure[i, j] = blk[2, 2], blk.all() or (~blk).all()
+    assert sure.sum() > 1400 and (ref == ours)[sure].mean() > 0.97, (ref == ours)[sure].mean()
+    assert ((ref == ours[:, ::-1])[sure[:, ::-1]].mean() < 0.93) and ((ref == ours[::-1])[sure[::-1]].mean() < 0.8)   # a flip would show
+
+
+def _frame_edges(depth):
+    """Outline of the pick bin's wall frame in a top-down depth image [m], imshow coordinates (pixel k centred on k)."""
+    hi = (depth < 1.2) & (depth > 1.05)                     # plate 1.09 m, wall tops 1.12 m below the camera
+    def run(line):                                          # the contiguous run through the image centre
+        a = b = 100
+        while a > 0 and line[a - 1]:
+            a -= 1
+        while b < len(line) - 1 and line[b + 1]:
+            b += 1
+        return a - 0.5, b + 0.5
+    (left, right), (top, bottom) = run(hi[47]), run(hi[:, 30])   # row 47 / column 30: along two wall tops, clear of the objects
+    return dict(left=left, right=right, top=top, bottom=bottom)
+
+
+def _check_frame_against_overlay(edges):
+    """The reference's picture is of the revision with wall tops at z = 0.86 (shipped: 0.88): same 0.66 m x 0.52 m outline, 2 cm further from
+    the camera at (0, -0.6, 2.0), so every edge sits (2 - 0.88) / (2 - 0.86) as far from the principal point (99.5 in imshow coordinates).
+    The overlay was read at 0.54 px resolution, ours is quantised to whole pixels: 1 px."""
+    gold, k = _overlay_gold(), (2.0 - 0.88) / (2.0 - 0.86)
+    for side, v in edges.items():
+        assert abs(99.5 + (v - 99.5) * k - gold[side]) < 1.0, (side, v, gold[side])
+    # size alone (independent of where the principal point falls inside a pixel): within 0.8 %
+    assert abs((edges["right"] - edges["left"]) * k / (gold["right"] - gold["left"]) - 1) < 0.008
+    assert abs((edges["bottom"] - edges["top"]) * k / (gold["bottom"] - gold["top"]) - 1) < 0.008
+
+
+def test_camera_model_reproduces_the_reference_overlay_image(model_2f):
+    """media/overlay.png is a 200x200 top-down observation plotted with pixel axes (tools/gen_golden_overlay.py): pins focal length
+    (fovy 45 deg -> 241.4 px), camera height, image orientation and the pick bin's place in the image for world_2_pixel and the ray caster."""
+    gold = _overlay_gold()
+
+    class _NoSim:
+        n = 1
+    c = MJ_Controller(model_2f, simulation=_NoSim())
+    c.create_camera_data(200, 200, "top_down")
+    f = c.cam_matrix[0, 0]
+    assert abs(0.66 * f / (2.0 - 0.86) / (gold["right"] - gold["left"]) - 1) < 0.005      # the frame's width in pixels: 0.2 %
+    assert abs(0.52 * f / (2.0 - 0.86) / (gold["bottom"] - gold["top"]) - 1) < 0.005      # and height: 0.3 %
+    # two opposite corners of the frame as the reference's world_2_pixel maps them (rounded to whole pixels; x is mirrored, fliplr)
+    px = c.world_2_pixel([-0.33, -0.6 + 0.26, 0.86])
+    assert abs(px[0] - 0.5 - gold["right"]) < 1.3 and abs(px[1] - 0.5 - gold["top"]) < 1.3, px
+    px = c.world_2_pixel([0.33, -0.6 - 0.26, 0.86])
+    assert abs(px[0] - 0.5 - gold["left"]) < 1.3 and abs(px[1] - 0.5 - gold["bottom"]) < 1.3, px
+    o = Oracle(model_2f)
+    o.reset(20, 1, True)
+    _, depth = o.render(model_2f.camera_name2id("top_down"), 200, 200, 0)
+    assert depth[:40, 100].min() < 1.9 and depth[170:, 100].min() > 1.9                    # pedestal at the TOP of the image, floor below the bin
+    _check_frame_against_overlay(_frame_edges(depth))
+    _check_layout_against_overlay(depth)
+
+
+@pytest.mark.gpu
+def test_hip_render_reproduces_the_reference_overlay_image(model_2f):
+    env = GraspEnv(file=model_2f, show_obs=False, n_envs=2, observation="render")
+    depth = np.asarray(env.reset()["depth"], dtype=np.float64)[1]
+    assert depth[:40, 100].min() < 1.9 and depth[170:, 100].min() > 1.9
+    _check_frame_against_overlay(_frame_edges(depth))
+    _check_layout_against_overlay(depth)

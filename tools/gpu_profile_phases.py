@@ -28,13 +28,11 @@ lt = (p[:, 17] - p[:, 16]) / 1e5
 print("  lifetime percentiles (ms) 10/50/90/99/max: %s; steps 10/50/90/max: %s; us per step 10/50/90/max: %s" % (
     np.percentile(lt, [10, 50, 90, 99, 100]).round(1).tolist(), np.percentile(steps, [10, 50, 90, 100]).tolist(),
     np.percentile(lt * 1e3 / steps, [10, 50, 90, 100]).round(1).tolist()))
-if MANY:
-    sys.exit(0)
 st = sim.get_state(); acts = np.zeros((n, 3))
 for e in range(n):
-    objs = st["qpos"][e][8:].reshape(-1, 7); k = e % 4
-    acts[e] = [objs[k, 0], -0.6 + objs[k, 1], 0.91]
-rew, ps, pr = sim.grasp_attempt(acts, rot=0, check_mode=0)
+    objs = st["qpos"][e][8:].reshape(-1, 7); k = e % (40 if MANY else 4)
+    acts[e] = [objs[k, 0], objs[k, 1], max(0.9, objs[k, 2])] if MANY else [objs[k, 0], -0.6 + objs[k, 1], 0.91]   # free joints hold world coordinates
+rew, ps, pr = sim.grasp_attempt(acts, rot=0, check_mode=0, table_height=0.89 if MANY else 0.91)
 c1 = sim.counters(); p = read(); steps = (c1["total_steps"] - c0["total_steps"]).astype(float)
 print("grasp: kernel %.1f ms, mean %d steps/env, success %.2f" % (sim.last_launch_ms(), steps.mean(), rew.mean()))
 for k, nm in enumerate(NAMES): print("  %-12s %10.0f" % (nm, (p[:, k] / steps).mean()))
