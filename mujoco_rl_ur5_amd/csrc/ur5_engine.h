@@ -93,7 +93,15 @@ __constant__ Ur5DevModel ur5_cmodel;
 #define UR5_LDS_PTR(T) (reinterpret_cast<T*>(ur5_smem) + (GS == UR5_NT ? 0 : (int)threadIdx.x / GS))
 #define UR5_MODEL ur5_cmodel
 #define PAR(i, n) for (int i = UR5_LANE; i < (n); i += GS)
+// SYNC orders the LDS traffic of the lanes that share a scene. With one wavefront per workgroup (UR5_NT == 64) the hardware already
+// executes a wave's LDS instructions in issue order, so all that is needed is that the COMPILER keeps the accesses on their side of
+// the line: wavefront-scope fences and a scheduling barrier, no instruction. __syncthreads() in a 64-thread workgroup costs an
+// `s_waitcnt lgkmcnt(0)` -- a full drain of the LDS queue and of every scalar load in flight -- at each of the several hundred SYNCs of a step.
+#if UR5_NT == 64 && !defined(UR5_BLOCK_SYNC)
+#define SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#else
 #define SYNC() __syncthreads()
+#endif
 #define UR5_LANE ((int)threadIdx.x & (GS - 1))
 #define UR5_GBASE ((int)threadIdx.x & ~(GS - 1))
 // Wave-wide sum / max with DPP (data-parallel primitives: the adder reads a neighbour lane's register directly) instead of
@@ -654,11 +662,11 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
 #pragma unroll
       for (int j = 0; j < UR5_MAXRD; j++) lt[lane * UR5_MAXRD + j] = r[j];
     }
-    __syncthreads();
+    SYNC();
     real t[UR5_MAXRD];
 #pragma unroll
     for (int k = 0; k < UR5_MAXRD; k++) t[k] = (k < b.size && k > b.loc) ? lt[(b.base + k) * UR5_MAXRD + b.loc] : (real)0;
-    __syncthreads();
+    SYNC();
 #pragma unroll
     for (int k = UR5_MAXRD - 1; k >= 0; k--) {
       const bool act = k < b.size;
@@ -2021,12 +2029,12 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       }
     } else { b.base = lane; b.loc = 0; b.size = 0; }
     real g = lane < nv ? S.grad[lane] : (real)0;
-    __syncthreads();   // every lane has read G / grad; H (aliased scratch) may be overwritten now
+    SYNC();     // every lane has read G / grad; H (aliased scratch) may be overwritten now
     PROF(PF_CHOL);     // profile builds: row assembly is booked under "chol", factor + solves under "solve"
     real myinv = blk_cholesky(r, b);
     real x = blk_solve(r, myinv, b, g, S.H);
     if (lane < nv) S.search[lane] = -x;
-    __syncthreads();
+    SYNC();
   }
 #endif
 
