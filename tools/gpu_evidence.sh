@@ -14,5 +14,5 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_
   d=$OUT/pmc_$(echo $grp | cut -d' ' -f1)
   timeout 400 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $d -o r -- $CMD > $d.json 2> $d.err
 done
-python $REPO/tools/rocprof_summary.py $OUT $OUT/bench_plain.json $OUT/r02_h > $OUT/summary.json 2> $OUT/summary.err
+python $REPO/tools/rocprof_summary.py $OUT $OUT/bench_plain.json $OUT/r02_r > $OUT/summary.json 2> $OUT/summary.err
 ls $OUT
