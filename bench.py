@@ -216,7 +216,7 @@ def rendered_sub_result(torch, dev, local_rank, workload, n, rounds, warmup):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--envs", type=int, default=None, help="scenes per GPU (default 4096 for --scaling weak, 4096 / gpus for strong)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
