@@ -148,3 +148,12 @@ def test_non_finite_state_is_flagged(model_it1, emul_lib):
     sim.step(2)
     c = sim.counters()
     assert c["status"][0] == 0 and c["status"][1] & 2
+
+
+def test_random_agent_attempts_take_the_same_exits_as_the_oracle(model_it1, emul_lib):
+    """Whole-image random pixels (the reference's example agent): IK failure and blocked-descent exits of the grasp script, result codes and
+    all 12 phase step counts equal to the oracle's. (-m gpu runs 96 scenes of it on the HIP engine.)"""
+    from mujoco_rl_ur5_amd.native import BatchSim
+    from test_gpu_parity import check_random_agent_parity
+    codes = check_random_agent_parity(BatchSim, model_it1, 20, lib_path=emul_lib)
+    assert any(c[3] == 2 for c in codes) and any(c[3] == 0 for c in codes)
