@@ -155,5 +155,8 @@ def test_random_agent_attempts_take_the_same_exits_as_the_oracle(model_it1, emul
     all 12 phase step counts equal to the oracle's. (-m gpu runs 96 scenes of it on the HIP engine.)"""
     from mujoco_rl_ur5_amd.native import BatchSim
     from test_gpu_parity import check_random_agent_parity
+    from mujoco_rl_ur5_amd.model import load_model
     codes = check_random_agent_parity(BatchSim, model_it1, 20, lib_path=emul_lib)
     assert any(c[3] == 2 for c in codes) and any(c[3] == 0 for c in codes)
+    codes = check_random_agent_parity(BatchSim, load_model("/UR5+gripper/UR5gripper_2_finger.xml"), 10, lib_path=emul_lib)   # 3 boxes + 3 spheres
+    assert any(c[3] == 2 for c in codes)

@@ -239,3 +239,41 @@ def check_random_agent_parity(BatchSim, model, n, **kw):
 def test_random_agent_attempts_take_the_same_exits_as_the_oracle(native_mod, model_it1):
     codes = check_random_agent_parity(native_mod.BatchSim, model_it1, 96)
     assert any(c[3] == 2 for c in codes) and any(c[3] == 1 for c in codes) and any(c[3] == 0 for c in codes)   # IK failure, blocked descent, plain
+
+
+def test_random_agent_attempts_on_the_six_object_scene(native_mod, model_2f):
+    """The same on the in-tree scene (3 boxes + 3 spheres, the 44-dof kernel instantiation)."""
+    codes = check_random_agent_parity(native_mod.BatchSim, model_2f, 64)
+    assert any(c[3] == 2 for c in codes) and any(c[3] == 0 for c in codes)
+
+
+def test_ik_values_and_move_ee_on_gpu(native_mod, model_it1):
+    """ur5_ik / ur5_move_ee directly: a grid of targets over the workspace, some unreachable; joint solutions equal the oracle's
+    to 1e-9, the same targets fail, and move_ee from the home pose takes the same number of steps to the same pose."""
+    from oracle.oracle import Oracle
+    m = model_it1
+    xs, ys, zs = np.meshgrid(np.linspace(-0.35, 0.65, 6), np.linspace(-0.9, 0.15, 6), [0.95, 1.1, 1.3])
+    targets = np.stack([xs.ravel(), ys.ravel(), zs.ravel()], axis=1)
+    targets = np.concatenate([targets, [[2.0, 2.0, 2.0], [0.0, 0.0, 3.0], [0.0, -0.6, 0.2]]])
+    n = len(targets)
+    sim = native_mod.BatchSim(m, n)
+    sim.reset(20 + np.arange(n, dtype=np.uint64), 1, 0.0)
+    q5, ok = sim.ik(targets)
+    o = Oracle(m)
+    o.reset(20, 1, False)
+    nfail = 0
+    for e in range(n):
+        oko, q5o = o.ik(targets[e])
+        assert bool(ok[e] == 0) == oko, (e, targets[e], ok[e], oko)
+        if oko:
+            assert np.abs(q5[e] - q5o).max() < 1e-9, (e, targets[e])
+        nfail += not oko
+    assert 3 <= nfail < n // 2
+    res, steps = sim.move_ee(targets, 0.02, 1500)
+    q = sim.get_state()["qpos"]
+    for e in range(0, n, 7):
+        o = Oracle(m)
+        o.reset(20 + e, 1, False)
+        r, s_ = o.move_ee(targets[e], 0.02, 1500)
+        assert r == res[e] and s_ == steps[e], (e, targets[e], r, res[e], s_, steps[e])
+        assert np.abs(q[e][:8] - o.qpos[:8]).max() < 1e-7
