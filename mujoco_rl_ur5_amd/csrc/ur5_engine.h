@@ -193,7 +193,10 @@ template <class T> struct V3 {
   UR5_FN V3() : x(0), y(0), z(0) {}
   UR5_FN V3(T a, T b, T c) : x(a), y(b), z(c) {}
   template <class U> UR5_FN explicit V3(const U* p) : x((T)p[0]), y((T)p[1]), z((T)p[2]) {}
-  UR5_FN T operator[](int i) const { return i == 0 ? x : (i == 1 ? y : z); }
+  // values first, then the selects: `i == 0 ? x : y` on members is a select between two ADDRESSES followed by one load (and what clang does not
+  // write that way, InstCombine turns into it: phi(load p, load q) -> load(phi(p, q))), which keeps the object in scratch memory behind a
+  // run-time offset: collision_fn and newton_direction_fn stored whole rotation matrices to scratch to read three of their entries back
+  UR5_FN T operator[](int i) const { const T a = x, b = y, c = z; return i == 0 ? a : (i == 1 ? b : c); }
   UR5_FN void set(int i, T v) { if (i == 0) x = v; else if (i == 1) y = v; else z = v; }
   template <class U> UR5_FN void store(U* p) const { p[0] = x; p[1] = y; p[2] = z; }
 };
@@ -223,10 +226,12 @@ template <class T> struct M3 {  // row-major
   T m[9];
   // selects instead of m[j]: a run-time index into a register array would push the matrix into scratch memory
   UR5_FN V3<T> col(int j) const {   // per-component scalar selects (a select between whole structs is lowered through scratch)
-    return V3<T>(j == 0 ? m[0] : (j == 1 ? m[1] : m[2]), j == 0 ? m[3] : (j == 1 ? m[4] : m[5]), j == 0 ? m[6] : (j == 1 ? m[7] : m[8]));
+    const T a0 = m[0], a1 = m[1], a2 = m[2], a3 = m[3], a4 = m[4], a5 = m[5], a6 = m[6], a7 = m[7], a8 = m[8];   // see V3::operator[]
+    return V3<T>(j == 0 ? a0 : (j == 1 ? a1 : a2), j == 0 ? a3 : (j == 1 ? a4 : a5), j == 0 ? a6 : (j == 1 ? a7 : a8));
   }
   UR5_FN V3<T> row(int i) const {
-    return V3<T>(i == 0 ? m[0] : (i == 1 ? m[3] : m[6]), i == 0 ? m[1] : (i == 1 ? m[4] : m[7]), i == 0 ? m[2] : (i == 1 ? m[5] : m[8]));
+    const T a0 = m[0], a1 = m[1], a2 = m[2], a3 = m[3], a4 = m[4], a5 = m[5], a6 = m[6], a7 = m[7], a8 = m[8];
+    return V3<T>(i == 0 ? a0 : (i == 1 ? a3 : a6), i == 0 ? a1 : (i == 1 ? a4 : a7), i == 0 ? a2 : (i == 1 ? a5 : a8));
   }
   // explicit element lists: in this very large kernel a counted loop over m[] is not always unrolled, and a run-time index
   // would move the whole matrix to scratch memory

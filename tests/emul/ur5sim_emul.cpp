@@ -10,7 +10,9 @@
 
 static int be_open(ur5_sim*, int) { return 0; }
 static void be_close(ur5_sim*) {}
-static void* be_alloc(ur5_sim*, size_t bytes) { return calloc(1, bytes); }
+// Device memory and LDS are NOT zero on the GPU (a kernel starts with whatever the previous one left in the CU's LDS; hipMalloc returns
+// recycled memory): poison both with 0xFF bytes (NaN doubles, -1 ints) so that a read-before-write in the engine shows up in the CPU suite.
+static void* be_alloc(ur5_sim*, size_t bytes) { void* p = malloc(bytes); if (p) memset(p, 0xFF, bytes); return p; }
 static void be_free(ur5_sim*, void* p) { free(p); }
 static int be_h2d(ur5_sim*, void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); return 0; }
 static int be_d2h(ur5_sim*, void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); return 0; }
@@ -30,7 +32,7 @@ template <int NV> static void run_all(ur5_sim* h, const Ur5Launch& P) {
   L* lds = new L();
   for (int i = 0; i < h->n; i++) {
     const int e = P.order ? P.order[i] : i;
-    memset((void*)lds, 0, sizeof(L));
+    memset((void*)lds, 0xFF, sizeof(L));
     ur5_emul_lds = lds;
     ur5_emul_model = h->dm;
     ur5::Engine<double, NV> eng;
