@@ -2804,13 +2804,18 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     make_constraints(); PROF(PF_ROWS);
     solve_newton();
   }
-  UR5_BIG void step() {  // sim.step(), MujocoController.py:379
+  UR5_BIG void step_body() {  // sim.step(), MujocoController.py:379
     Fact fr;
     forward(fr);
     PROF_T0();
     integrate(fr); PROF(PF_INTEGRATE);
     if (UR5_LANE == 0) S.total_steps++;
   }
+  // In the wavefront-per-scene kernel the step is a real function: the script interpreter, the IK and the PID around it then have their own
+  // register allocation, and nothing lane-derived (LDS addresses, lane predicates) that the step uses can be hoisted out of the script's
+  // loops and spilled there -- the kernel reloaded ~60 such values per step. With -enable-ipra the call itself saves no registers.
+  UR5_CALL void step_fn() { step_body(); }
+  UR5_FN void step() { if constexpr (FLAT) step_body(); else step_fn(); }
 
   // ------------------------------------------------------------------ controller layer (MujocoController.py)
   // :325-329 -- all 7 PIDs are evaluated every iteration; returns max |target - q| over the group

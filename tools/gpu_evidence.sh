@@ -1,8 +1,9 @@
 #!/bin/bash
 # Evidence run of a round (one gpurun call): rocprofv3 kernel stats + PMC passes of the bench command, summaries under gpurun_out/<tag>/.
-# usage: tools/gpu_evidence.sh <tag>      (then copy gpurun_out/<tag>/r02_* into profiles/)
+# usage: tools/gpu_evidence.sh <tag> [prefix]      (then copy gpurun_out/<tag>/<prefix>_* into profiles/; prefix defaults to r02_t)
 set -u
 TAG=${1:-ev}
+PFX=${2:-r02_t}
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
@@ -14,5 +15,5 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_
   d=$OUT/pmc_$(echo $grp | cut -d' ' -f1)
   timeout 400 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $d -o r -- $CMD > $d.json 2> $d.err
 done
-python $REPO/tools/rocprof_summary.py $OUT $OUT/bench_plain.json $OUT/r02_r > $OUT/summary.json 2> $OUT/summary.err
+python $REPO/tools/rocprof_summary.py $OUT $OUT/bench_plain.json $OUT/$PFX > $OUT/summary.json 2> $OUT/summary.err
 ls $OUT
