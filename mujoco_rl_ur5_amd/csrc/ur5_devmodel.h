@@ -9,11 +9,11 @@
 
 #define UR5_MAXRD 8                                // robot dofs == robot weld groups ("cbodies")
 #define UR5_MAXNU 8
-#define UR5_MAXRG 4                                // robot weld groups that carry collision geoms (wrist_3 group, two knuckle groups)
 #define UR5_MAXSR 16                               // equality + limit rows
 #ifndef UR5_MANY
 // ---- small scenes (UR5gripper_2_finger.xml, IT1): one 64-lane wavefront per scene, everything in LDS
 #define UR5_MAXOBJ 6                               // free objects handled by one wavefront
+#define UR5_MAXRG 4                                // robot weld groups that carry collision geoms (wrist_3 group, two knuckle groups)
 #define UR5_MAXG 48
 #define UR5_MAXDG 16                               // dynamic (robot / object) collidable geoms
 #define UR5_MAXPAIR 384
@@ -27,6 +27,8 @@ typedef int ur5_pair_t;
 // ---- many-object piles (UR5gripper_2_finger_many_objects.xml, IT5: 40 objects, condim 6): one multi-wave workgroup per
 // scene, state in LDS (~110 KB: one scene per CU), Newton Hessian in envelope (skyline) storage in global memory
 #define UR5_MAXOBJ 40
+#define UR5_MAXRG 8                                // every robot weld group may carry collision geoms: scenes compiled with the seven arm-link hulls
+                                                   // (mjcf.compile_mjcf(arm_collision=True), UR5gripper_2_finger_many_objects.xml:158-185) fit this variant
 #define UR5_MAXG 80
 #define UR5_MAXDG 56
 #define UR5_MAXPAIR 2560

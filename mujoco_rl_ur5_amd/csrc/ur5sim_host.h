@@ -304,7 +304,7 @@ static int build_model(const void* data, size_t nbytes, int ee_body, Ur5DevModel
   D.nrg = 0;
   for (int d = 0; d < nrd; d++) D.rd_gslot[d] = -1;
   for (int k = 0; k < ng; k++) if (D.g_kind[k] == UR5_KIND_ROBOT && D.rd_gslot[D.g_owner[k]] < 0) {
-    if (D.nrg >= UR5_MAXRG) return fail(UR5_ERR_MODEL, "more than 4 robot weld groups carry collision geoms");
+    if (D.nrg >= UR5_MAXRG) return fail(UR5_ERR_MODEL, "too many robot weld groups carry collision geoms for this engine variant (4 in the wavefront-per-scene engine: gripper only; 8 in the many-object engine)");
     D.rd_gslot[D.g_owner[k]] = D.nrg; D.rg_body[D.nrg++] = D.g_owner[k];
   }
   int np = 0;

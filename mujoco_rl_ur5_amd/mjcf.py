@@ -482,7 +482,8 @@ def compile_mjcf(path, *, objects=None, arm_collision=False, mesh_inertia="dedup
             name = g["mesh"]
             if name not in mesh_cache:
                 tris = load_stl(meshes[name])
-                hull = convex_hull_vertices(tris, 0 if name in _ARM_MESHES else maxhullvert)
+                # collision hulls are capped at maxhullvert vertices; an arm mesh that does not collide keeps its full hull (mass / inertia do not use it)
+                hull = convex_hull_vertices(tris, maxhullvert if (arm_collision or name not in _ARM_MESHES) else 0)
                 if mesh_inertia == "legacy":
                     mi = mesh_inertia_legacy(tris, density)
                 elif mesh_inertia == "signed":

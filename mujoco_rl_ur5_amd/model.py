@@ -181,6 +181,7 @@ KNOWN_MODELS = {
     "/UR5+gripper/UR5gripper_2_finger.xml": "ur5_2f.ur5m",
     "/UR5+gripper/UR5gripper_2_finger_many_objects.xml": "ur5_2f_many.ur5m",
     "it1_4box": "ur5_2f_it1_4box.ur5m",
+    "many_objects_arm_collision": "ur5_2f_many_armcol.ur5m",   # the 40-object scene with the arm-link hulls colliding
 }
 
 

@@ -318,3 +318,86 @@ def test_pile_grasp_bits_against_the_oracle_on_gpu(model_many):
     bits = sum(int(r == rew[e]) for e, (r, _) in enumerate(res))
     codes = sum(int(pro.tolist() == pr[e].tolist()) for e, (_, pro) in enumerate(res))
     assert bits >= n - 1 and codes >= n - 2, (bits, codes, rew.tolist(), [r for r, _ in res])   # piles are chaotic: one flip tolerated
+
+
+# ------------------------------------------------------------------ arm-link collision hulls
+ARM_MESHES = ("base", "shoulder", "upperarm", "forearm", "wrist1", "wrist2", "wrist3")
+
+
+def _arm_contact_state(model):
+    """Reset state of the pile scene with object 0 moved INTO the forearm link (5 cm above the middle of its axis): the only way the state
+    can be resolved is a contact between the object and the forearm's collision hull."""
+    names = model.names["body"]
+    o = Oracle(model)
+    o.reset(20, 1, False)
+    o.forward()
+    xp = o.body_xpos()
+    mid = 0.5 * (xp[names.index("forearm_link")] + xp[names.index("wrist_1_link")])
+    st = o.get_state()
+    q = st["qpos"].copy()
+    q[8:11] = mid + np.array([0.0, 0.0, 0.05])
+    o.set_state(qpos=q, qvel=st["qvel"], warmstart=st["warmstart"], pid=st["pid"])
+    return o, dict(qpos=q[None], qvel=st["qvel"][None], warmstart=st["warmstart"][None], pid=st["pid"][None])
+
+
+def _check_arm_hull_contact(model, sim, tol=(1e-9, 1e-9, 1e-9, 1e-7)):
+    """tol = (contact point, normal, depth, relative qacc); the GPU build runs MPR in fused arithmetic, see _forward_parity_from_engine_state"""
+    arm_geoms = {g for g in range(model.ngeom) if model.geom_meshid[g] >= 0 and model.names["mesh"][model.geom_meshid[g]] in ARM_MESHES}
+    assert len(arm_geoms) == 7 and all(model.geom_collide[g] for g in arm_geoms)
+    o, state = _arm_contact_state(model)
+    o.forward()
+    sim.set_state(**state)
+    d = sim.forward_debug()
+    oc = o.contacts()
+    on_arm = [c for c in oc if int(c[7]) in arm_geoms or int(c[8]) in arm_geoms]
+    assert len(on_arm) >= 1 and min(c[0] for c in on_arm) < -0.01           # the forearm hull holds the object, centimetres deep
+    assert d["ncon"][0] == len(oc)
+    ec = d["contacts"][0][:len(oc)]
+    for c in oc:
+        best = min(ec, key=lambda e: np.abs(e[1:4] - c[1:4]).sum())
+        assert np.abs(best[1:4] - c[1:4]).max() < tol[0] and np.abs(best[4:7] - c[4:7]).max() < tol[1] and abs(best[0] - c[0]) < tol[2], (best, c)
+        assert {int(best[7]), int(best[8])} == {int(c[7]), int(c[8])}
+    qacc = o.vec("qacc")
+    assert np.abs(qacc[:6]).max() > 1.0                                      # the arm feels it
+    assert np.abs(d["qacc"][0][:model.nv] - qacc).max() < tol[3] * max(1.0, np.abs(qacc).max())
+    assert sim.counters()["status"][0] == 0
+
+
+@pytest.fixture(scope="module")
+def model_many_armcol():
+    return load_model("many_objects_arm_collision")
+
+
+def test_arm_link_hulls_collide_in_the_many_object_engine(model_many_armcol, emul_lib):
+    """The reference collides the seven UR5 arm meshes (UR5gripper_2_finger_many_objects.xml:158-185). The many-object engine has a contact
+    slot for every robot weld group, so the pile scene compiled with those hulls runs on it: an object pushed into the forearm produces the
+    oracle's contact set and constrained acceleration, and the first steps of the drop agree as for the shipped scene."""
+    m = model_many_armcol
+    assert len(m.pair_geom1) > len(load_model(MANY).pair_geom1)
+    sim = BatchSim(m, 1, lib_path=emul_lib)
+    assert sim.variant == 1
+    _check_arm_hull_contact(m, sim)
+    sim.reset([20], 1, 0.0)
+    _drop_parity(m, sim, 0, 20, 25, 1e-9)
+
+
+def test_small_engine_rejects_arm_hulls_loudly(emul_lib):
+    """The wavefront-per-scene engine keeps four robot contact slots (gripper only: 8 scenes per CU); a small scene compiled with the arm hulls is
+    refused with a message, not silently simulated without them."""
+    mjcf = pytest.importorskip("mujoco_rl_ur5_amd.mjcf")
+    import os
+    src = "/root/reference/UR5+gripper/UR5gripper_2_finger.xml"
+    if not os.path.exists(src):
+        pytest.skip("needs the reference MJCF")
+    m = mjcf.compile_mjcf(src, arm_collision=True)
+    with pytest.raises(Exception, match="robot weld groups|moving collidable geoms"):
+        BatchSim(m, 1, lib_path=emul_lib)
+
+
+@pytest.mark.gpu
+def test_arm_link_hulls_on_gpu(model_many_armcol):
+    sim = BatchSim(model_many_armcol, 2)
+    assert sim.variant == 1
+    _check_arm_hull_contact(model_many_armcol, sim, tol=(2e-5, 1e-4, 1e-5, 5e-3))
+    sim.reset(20 + np.arange(2, dtype=np.uint64), 1, 0.0)
+    _drop_parity(model_many_armcol, sim, 1, 21, 25, 1e-9)

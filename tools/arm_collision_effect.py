@@ -28,10 +28,7 @@ src = "/root/reference/UR5+gripper/UR5gripper_2_finger.xml"
 objs = [dict(name=f"box_{k + 1}", type="box", size=[0.02, 0.02, 0.02], pos=[0.0, -0.6, 0.95 + 0.1 * k], joints="slide3ball",
              rgba=(0.5, 0.5, 0.5, 1)) for k in range(4)]
 m_off = mj.compile_mjcf(src, objects=objs)
-full = mj.convex_hull_vertices
-mj.convex_hull_vertices = lambda v, mx=0: full(v, mx if mx > 0 else 32)
 m_on = mj.compile_mjcf(src, objects=objs, arm_collision=True)
-mj.convex_hull_vertices = full
 
 
 class _NoSim:

@@ -22,10 +22,7 @@ SRC = "/root/reference/UR5+gripper/UR5gripper_2_finger_many_objects.xml"
 def models():
     import mujoco_rl_ur5_amd.mjcf as mj
     m_off = mj.compile_mjcf(SRC)
-    full = mj.convex_hull_vertices
-    mj.convex_hull_vertices = lambda v, mx=0: full(v, mx if mx > 0 else 32)
     m_on = mj.compile_mjcf(SRC, arm_collision=True)
-    mj.convex_hull_vertices = full
     return m_off, m_on
 
 
