@@ -188,7 +188,11 @@ static void* be_alloc(ur5_sim* h, size_t bytes) {
   void* p = nullptr;
   (void)hipSetDevice(h->device);
   if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
-  (void)hipMemset(p, 0, bytes);
+  // zero it ON THE HANDLE'S STREAM and wait: hipMemset runs on the null stream, which the handle's non-blocking stream does not synchronise
+  // with -- an upload or a kernel queued right after the allocation could otherwise be overtaken by the fill
+  HipBackend* b = (HipBackend*)h->be;
+  hipStream_t s = b ? b->stream : nullptr;
+  if (hipMemsetAsync(p, 0, bytes, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { (void)hipFree(p); return nullptr; }
   return p;
 }
 static void be_free(ur5_sim* h, void* p) { (void)hipSetDevice(h->device); (void)hipFree(p); }
