@@ -332,9 +332,9 @@ def main():
         if os.path.exists(tp):
             with open(tp) as f:
                 tj = json.load(f)
-            traffic = tj["hbm_bytes_per_env_step"] * steps_local / args.steps
-            traffic_src = (f"from profiles/ ({tj.get('source', 'hbm_traffic_latest.json')}), NOT measured in this run: (FETCH_SIZE + WRITE_SIZE) per "
-                           "env-step of the rocprofv3 PMC passes of this command x env-steps of an average timed round")
+            traffic = tj["hbm_bytes_per_env_step"] * steps_local / (args.steps * G)          # per launch, like algorithmic_bytes_per_launch below
+            traffic_src = (f"from profiles/ ({tj.get('source', 'hbm_traffic_latest.json')}), NOT measured in this run: (2 x FETCH_SIZE + WRITE_SIZE) per "
+                           "env-step of the rocprofv3 PMC passes of this command x env-steps of an average timed launch")
         out = {
             "metric": f"env-steps/sec (+ grasp-attempts/sec), {n_total} parallel UR5 scenes on {world} MI355X",
             "value": steps_all / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -357,6 +357,7 @@ def main():
                          "traffic_source": traffic_src, "kernel": "ur5_run_kernel<32>", "bytes_per_env_step": bytes_per_step,
                          "avg_launch_ms": kernel_ms / (args.steps * G), "launches_per_round": G, "launch_concurrency": G,
                          "env_steps_per_launch": steps_local / (args.steps * G),
+                         "algorithmic_bytes_per_launch": bytes_per_step * steps_local / (args.steps * G),
                          "kernel_ms_per_round": 1e3 * elapsed_local / args.steps, "env_steps_per_round": steps_local / args.steps,
                          "note": "algorithmic state bytes x env-steps of the timed rounds / their wall time on rank 0: one attempt + episode-reset "
                                  "launch per scene group and round, the groups' launches overlapping on their own HIP streams (avg_launch_ms = "

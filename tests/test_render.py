@@ -176,11 +176,6 @@ def test_camera_model_reproduces_the_reference_overlay_image(model_2f):
 def test_hip_render_reproduces_the_reference_overlay_image(model_2f):
     env = GraspEnv(file=model_2f, show_obs=False, n_envs=2, observation="render")
     depth = np.asarray(env.reset()["depth"], dtype=np.float64)[1]
-    if os.environ.get("UR5_DIAG"):
-        st = env.sim.get_state()
-        with open(os.environ["UR5_DIAG"], "a") as f:
-            f.write(f"overlay diag: nan depth {int(np.isnan(depth).sum())} nan qpos {np.isnan(st['qpos']).sum(axis=1).tolist()} nan qvel {np.isnan(st['qvel']).sum(axis=1).tolist()} "
-                    f"status {env.sim.counters()['status'].tolist()} steps {env.sim.counters()['total_steps'].tolist()} qpos1[:8] {st['qpos'][1][:8].tolist()}\n")
     assert depth[:40, 100].min() < 1.9 and depth[170:, 100].min() > 1.9
     _check_frame_against_overlay(_frame_edges(depth))
     _check_layout_against_overlay(depth)
