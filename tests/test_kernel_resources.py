@@ -1,0 +1,47 @@
+"""Static resources of the kernels in the built csrc/libur5sim.so, read from the code objects' metadata notes (no GPU needed: hipcc
+cross-compiles). Guards what DESIGN.md section 2 relies on: the wavefront-per-scene kernel fits two waves per SIMD (256 VGPRs) and its scratch
+frame stays small (round 2: 1 216 -> 456 B per lane after the callee-saved saves, the matrices that went through scratch and the spilled loop
+invariants were removed); the tile renderer has no scratch at all."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "mujoco_rl_ur5_amd", "csrc", "libur5sim.so")
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+def _kernel_notes(tmp_path):
+    if not os.path.exists(LIB) or not os.path.exists(os.path.join(LLVM, "llvm-objdump")):
+        pytest.skip("needs the built library and the ROCm LLVM tools")
+    shutil.copy(LIB, tmp_path / "lib.so")
+    subprocess.check_call([os.path.join(LLVM, "llvm-objdump"), "--offloading", "lib.so"], cwd=tmp_path, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    out = {}
+    for f in sorted(os.listdir(tmp_path)):
+        if "amdgcn" not in f:
+            continue
+        assert f.endswith("gfx950"), f                                          # one target, no fat binary for other architectures
+        txt = subprocess.check_output([os.path.join(LLVM, "llvm-readelf"), "--notes", f], cwd=tmp_path, text=True)
+        for block in txt.split(".args:")[1:]:
+            name = re.search(r"\.name:\s+(\S+)", block)
+            if not name:
+                continue
+            out[name.group(1)] = {k: int(re.search(r"\.%s:\s+(\d+)" % k, block).group(1))
+                                  for k in ("private_segment_fixed_size", "vgpr_count", "group_segment_fixed_size", "max_flat_workgroup_size")}
+    return out
+
+
+def test_kernel_registers_and_scratch(tmp_path):
+    k = _kernel_notes(tmp_path)
+    find = lambda part: next(v for n, v in k.items() if part in n)
+    small, six, many = find("ur5_run_kernelILi32ELi64E"), find("ur5_run_kernelILi44ELi64E"), find("ur5m_run_kernelILi248ELi256E")
+    assert small["vgpr_count"] <= 256 and six["vgpr_count"] <= 256              # two waves per SIMD
+    assert small["max_flat_workgroup_size"] == 64 and many["max_flat_workgroup_size"] == 256
+    assert small["private_segment_fixed_size"] <= 512, small                    # B per lane, the whole call tree (was 1 216)
+    assert six["private_segment_fixed_size"] <= 1024, six
+    assert many["private_segment_fixed_size"] <= 512 and many["vgpr_count"] == 512, many
+    assert find("ur5_render_kernel")["private_segment_fixed_size"] == 0
+    assert small["group_segment_fixed_size"] == 0                               # the scene is dynamic LDS, sized at launch
