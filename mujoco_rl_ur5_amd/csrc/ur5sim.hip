@@ -253,6 +253,7 @@ static int be_upload_model(ur5_sim* h) {
     if (g_model_hash[h->device & 63] != h->model_hash) {
       HIPCHK(hipDeviceSynchronize());
       HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(ur5_cmodel), &h->hm, sizeof(Ur5DevModel), 0, hipMemcpyHostToDevice));
+      HIPCHK(hipDeviceSynchronize());   // the copy runs on the null stream; the launches that read the model go to a non-blocking stream
       g_model_hash[h->device & 63] = h->model_hash;
     }
     g_model_owner[h->device & 63] = h;
