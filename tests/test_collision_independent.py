@@ -213,6 +213,74 @@ def test_mpr_depth_against_the_exact_minkowski_penetration(model, emul_lib):
     _check_mpr(model, _Backends(model, emul_lib), 16, 8, 1)
 
 
+def _qmul(a, b):
+    w1, x1, y1, z1 = a
+    w2, x2, y2, z2 = b
+    return np.array([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
+                     w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2])
+
+
+def test_contacts_are_covariant_under_rigid_motions(model, emul_lib):
+    """Frame invariance: moving BOTH bodies of a pair by the same random rigid motion must move the contact set with them -- same depths, points
+    and normals carried along. Holds for every pair routine (box-box clipping, MPR for cylinders, the analytic capsule and sphere cases) and
+    needs no second implementation: a handedness slip, a world-axis assumption or an un-rotated offset in any of them breaks it."""
+    from test_collision_kat import CAP
+    q0, adr = _parked(model)
+    free = sorted(adr)                                                          # geoms on free joints: spheres, boxes, cylinders, capsules
+    rng = np.random.default_rng(5)
+    centre = np.array([0.0, -0.6, 2.0])
+    be = _Backends(model, emul_lib)
+    kinds = set()
+    done = 0
+    while done < 40:
+        ga, gb = (int(g) for g in rng.choice(free, 2, replace=False))
+        qa, qb = _random_pose(rng), _random_pose(rng)
+        reach = model.geom_rbound[ga] + model.geom_rbound[gb]
+        d = rng.normal(size=3)
+        d /= np.linalg.norm(d)
+
+        def place(dist):
+            q = q0.copy()
+            q[adr[ga]:adr[ga] + 7] = [*centre, *qa]
+            q[adr[gb]:adr[gb] + 7] = [*(centre + dist * d), *qb]
+            return q
+        target, lo, hi = rng.uniform(2e-4, 2e-3), 0.0, 1.05 * reach                # the depths contacts have in the simulation
+        for _ in range(30):
+            mid = 0.5 * (lo + hi)
+            cs = be.contacts(place(mid), centre)["oracle"]
+            if cs and min(c[0] for c in cs) < -target:
+                lo = mid
+            else:
+                hi = mid
+        pb = centre + lo * d
+        q = place(lo)
+        base = be.contacts(q, centre)
+        if len(base["oracle"]) == 0:
+            continue
+        qt = _random_pose(rng)
+        T, shift = _rot(qt), rng.uniform(-0.2, 0.2, size=3)
+        move = lambda p: centre + T @ (np.asarray(p) - centre) + shift
+        q2 = q0.copy()
+        q2[adr[ga]:adr[ga] + 7] = [*move(centre), *_qmul(qt, qa)]
+        q2[adr[gb]:adr[gb] + 7] = [*move(pb), *_qmul(qt, qb)]
+        moved = be.contacts(q2, centre + shift)
+        for name in base:
+            a, b = base[name], moved[name]
+            assert len(a) == len(b), (name, ga, gb, len(a), len(b))
+            for c in a:
+                want_p, want_n = move(c[1:4]), T @ np.asarray(c[4:7])
+                best = min(b, key=lambda e: np.abs(np.asarray(e[1:4]) - want_p).sum())
+                # analytic pairs are covariant to 1e-8 in depth (rounding, the 1e-9 tie rules of the clipping code) and to the tolerance of the capsule-box
+                # segment search in point and normal; MPR (any pair with a cylinder) stops at a 1e-6 portal tolerance, which it may reach
+                # along another sequence of portals in the moved frame: depth to ~1e-7, point to ~1e-5, normal to ~5e-3 (test_many_objects.py)
+                td, tp, tn = (5e-6, 1e-4, 2e-2) if CYL in (int(model.geom_type[ga]), int(model.geom_type[gb])) else (1e-8, 1e-7, 1e-6)
+                assert abs(best[0] - c[0]) < td and np.abs(np.asarray(best[1:4]) - want_p).max() < tp and np.abs(np.asarray(best[4:7]) - want_n).max() < tn, (
+                    name, ga, gb, int(model.geom_type[ga]), int(model.geom_type[gb]), c[:7], best[:7])
+        kinds.add((int(model.geom_type[ga]), int(model.geom_type[gb])))
+        done += 1
+    assert len(kinds) >= 8, kinds                                               # most type combinations occurred
+
+
 @pytest.mark.gpu
 def test_independent_collision_checks_on_gpu(model):
     be = _Backends(model, None)
