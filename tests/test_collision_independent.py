@@ -281,6 +281,70 @@ def test_contacts_are_covariant_under_rigid_motions(model, emul_lib):
     assert len(kinds) >= 8, kinds                                               # most type combinations occurred
 
 
+def test_contact_dynamics_are_covariant_under_motions_that_keep_gravity(model, emul_lib):
+    """One forward pass of two free objects colliding in mid-air, with random velocities, before and after a half turn about the vertical plus
+    a shift: linear accelerations (world frame) must turn along, angular ones (body frame) must stay -- through contact Jacobians, friction
+    pyramids, the coupled Newton Hessian and its solve. No second implementation involved. (Only the half turn is an exact symmetry: the
+    friction pyramid's tangents are built from the world y / z axis as in MuJoCo's mju_makeFrame [3P], so other angles orient the 4-sided
+    pyramid differently; under a half turn the tangents just change sign, and the pyramid has both signs.)"""
+    q0, adr = _parked(model)
+    free = sorted(adr)
+    rng = np.random.default_rng(7)
+    centre = np.array([0.0, -0.6, 2.0])
+    be = _Backends(model, emul_lib)
+    vadr = {g: int(model.jnt_dofadr[model.body_jntadr[int(model.geom_bodyid[g])]]) for g in free}
+    done = 0
+    while done < 16:
+        ga, gb = (int(g) for g in rng.choice(free, 2, replace=False))
+        if CYL in (int(model.geom_type[ga]), int(model.geom_type[gb])):
+            continue                                                            # MPR normals are only reproducible to ~5e-3 between frames (above)
+        qa, qb = _random_pose(rng), _random_pose(rng)
+        d = rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        reach = model.geom_rbound[ga] + model.geom_rbound[gb]
+        target, lo, hi = rng.uniform(3e-4, 1.5e-3), 0.0, 1.05 * reach
+
+        def state(dist, ang=0.0, shift=np.zeros(3), vel=None):
+            qz = np.array([np.cos(ang / 2), 0, 0, np.sin(ang / 2)]) if ang != np.pi else np.array([0.0, 0.0, 0.0, 1.0])
+            Rz = _rot(qz)
+            q, v = q0.copy(), np.zeros(model.nv)
+            for g, p, quat in ((ga, centre, qa), (gb, centre + dist * d, qb)):
+                q[adr[g]:adr[g] + 7] = [*(centre + Rz @ (p - centre) + shift), *_qmul(qz, quat)]
+            if vel is not None:
+                for g, w in ((ga, vel[:6]), (gb, vel[6:])):
+                    v[vadr[g]:vadr[g] + 3] = Rz @ w[:3]
+                    v[vadr[g] + 3:vadr[g] + 6] = w[3:]
+            return q, v, Rz
+        for _ in range(30):
+            mid = 0.5 * (lo + hi)
+            cs = be.contacts(state(mid)[0], centre)["oracle"]
+            if cs and min(c[0] for c in cs) < -target:
+                lo = mid
+            else:
+                hi = mid
+        if not be.contacts(state(lo)[0], centre)["oracle"]:
+            continue
+        vel = np.concatenate([rng.normal(size=3) * 0.2, rng.normal(size=3) * 2.0, rng.normal(size=3) * 0.2, rng.normal(size=3) * 2.0])
+        ang, shift = np.pi, np.array([*rng.uniform(-0.2, 0.2, size=2), 0.0])
+        acc = {}
+        for tag, (q, v, Rz) in (("a", state(lo, 0.0, np.zeros(3), vel)), ("b", state(lo, ang, shift, vel))):
+            be.o.set_state(qpos=q, qvel=v)
+            be.o.forward()
+            acc["oracle", tag] = be.o.vec("qacc").copy()
+            be.sim.set_state(qpos=q[None], qvel=v[None], warmstart=np.zeros((1, model.nv)))
+            acc["engine", tag] = be.sim.forward_debug()["qacc"][0][:model.nv].copy()
+        Rz = state(lo, ang)[2]
+        for name in ("oracle", "engine"):
+            a, b = acc[name, "a"], acc[name, "b"]
+            scale = max(1.0, np.abs(a).max())
+            assert np.abs(a).max() > 20.0                                       # the contact does act (free fall alone is 9.81)
+            for g in (ga, gb):
+                i = vadr[g]
+                assert np.abs(Rz @ a[i:i + 3] - b[i:i + 3]).max() < 1e-7 * scale, (name, ga, gb, a[i:i + 3], b[i:i + 3])
+                assert np.abs(a[i + 3:i + 6] - b[i + 3:i + 6]).max() < 1e-7 * scale, (name, ga, gb, a[i + 3:i + 6], b[i + 3:i + 6])
+        done += 1
+
+
 @pytest.mark.gpu
 def test_independent_collision_checks_on_gpu(model):
     be = _Backends(model, None)
