@@ -284,7 +284,7 @@ def test_contacts_are_covariant_under_rigid_motions(model, emul_lib):
 def test_contact_dynamics_are_covariant_under_motions_that_keep_gravity(model, emul_lib):
     """One forward pass of two free objects colliding in mid-air, with random velocities, before and after a half turn about the vertical plus
     a shift: linear accelerations (world frame) must turn along, angular ones (body frame) must stay -- through contact Jacobians, friction
-    pyramids, the coupled Newton Hessian and its solve. No second implementation involved. (Only the half turn is an exact symmetry: the
+    pyramids, the coupled Newton Hessian and its solve -- and the contact's forces on the two bodies must cancel. No second implementation involved. (Only the half turn is an exact symmetry: the
     friction pyramid's tangents are built from the world y / z axis as in MuJoCo's mju_makeFrame [3P], so other angles orient the 4-sided
     pyramid differently; under a half turn the tangents just change sign, and the pyramid has both signs.)"""
     q0, adr = _parked(model)
@@ -293,7 +293,7 @@ def test_contact_dynamics_are_covariant_under_motions_that_keep_gravity(model, e
     centre = np.array([0.0, -0.6, 2.0])
     be = _Backends(model, emul_lib)
     vadr = {g: int(model.jnt_dofadr[model.body_jntadr[int(model.geom_bodyid[g])]]) for g in free}
-    done = 0
+    done = acting = 0
     while done < 16:
         ga, gb = (int(g) for g in rng.choice(free, 2, replace=False))
         if CYL in (int(model.geom_type[ga]), int(model.geom_type[gb])):
@@ -331,18 +331,24 @@ def test_contact_dynamics_are_covariant_under_motions_that_keep_gravity(model, e
             be.o.set_state(qpos=q, qvel=v)
             be.o.forward()
             acc["oracle", tag] = be.o.vec("qacc").copy()
+            if tag == "a":                                                      # Newton's third law: the contact's net force on the pair vanishes
+                da = acc["oracle", tag] - be.o.vec("qacc_smooth")
+                net = sum((model.body_mass[int(model.geom_bodyid[g])] + model.dof_armature[vadr[g]]) * da[vadr[g]:vadr[g] + 3] for g in (ga, gb))
+                each = max(np.abs(model.body_mass[int(model.geom_bodyid[g])] * da[vadr[g]:vadr[g] + 3]).max() for g in (ga, gb))
+                assert np.abs(net).max() < 1e-9 * max(1.0, each), (ga, gb, net, each)
+                acting += each > 0.1                                               # (a pair whose random velocities separate it feels nothing)
             be.sim.set_state(qpos=q[None], qvel=v[None], warmstart=np.zeros((1, model.nv)))
             acc["engine", tag] = be.sim.forward_debug()["qacc"][0][:model.nv].copy()
         Rz = state(lo, ang)[2]
         for name in ("oracle", "engine"):
             a, b = acc[name, "a"], acc[name, "b"]
             scale = max(1.0, np.abs(a).max())
-            assert np.abs(a).max() > 20.0                                       # the contact does act (free fall alone is 9.81)
             for g in (ga, gb):
                 i = vadr[g]
                 assert np.abs(Rz @ a[i:i + 3] - b[i:i + 3]).max() < 1e-7 * scale, (name, ga, gb, a[i:i + 3], b[i:i + 3])
                 assert np.abs(a[i + 3:i + 6] - b[i + 3:i + 6]).max() < 1e-7 * scale, (name, ga, gb, a[i + 3:i + 6], b[i + 3:i + 6])
         done += 1
+    assert acting >= 8, acting
 
 
 @pytest.mark.gpu
