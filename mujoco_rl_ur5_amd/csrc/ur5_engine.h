@@ -52,7 +52,11 @@ static const Ur5DevModel* ur5_emul_model = nullptr;
 #define UR5_LANE 0
 #define UR5_GBASE 0
 #else
+#ifdef UR5_SIMT   // test-only: a host build of THIS (device) code path, intrinsics from tests/emul/ur5_simt_shim.h (one fibre per lane)
+#include "ur5_simt_shim.h"
+#else
 #include <hip/hip_runtime.h>
+#endif
 #define UR5_FN __device__ __forceinline__
 #define UR5_BIG __device__ __forceinline__  // phase routines: the interpreter in run() calls each of them from one place
 #define UR5_CALL __device__ __noinline__    // small helpers with many call sites: kept as real functions

@@ -1,0 +1,94 @@
+"""The engine's DEVICE code path on the CPU: csrc/ur5_engine.h compiled without -DUR5_EMUL, its HIP intrinsics emulated with the semantics of one
+64-lane wavefront (tests/emul/ur5_simt_shim.h: a fibre per lane, a rendezvous per cross-lane instruction). The plain lane emulation of
+test_engine_emul.py needs LDS stand-ins for what the GPU keeps in registers; this build runs the code that ships -- DPP reductions, v_readlane
+pivots of the row factorisation, the block-parallel register Cholesky of the robot factors and of the block-diagonal Newton path, ballot
+compactions, the 8-lanes-per-pair MPR with its DPP vertex exchange -- against the oracle, without a GPU."""
+import numpy as np
+import pytest
+
+from conftest import aimed_actions
+from mujoco_rl_ur5_amd.native import BatchSim
+from oracle.oracle import Oracle
+from test_engine_emul import _random_state
+
+
+def test_forward_quantities_through_the_device_path(model_it1, simt_lib):
+    m = model_it1
+    sim = BatchSim(m, 2, lib_path=simt_lib)
+    q, v = _random_state(m, 0)
+    ctrl = np.array([0.5, -1, 0.3, 0.2, -0.1, 0.7, -0.4])
+    o = Oracle(m)
+    o.set_state(qpos=q, qvel=v)
+    o.set_ctrl(ctrl)
+    sim.set_state(qpos=q, qvel=v, warmstart=np.zeros(m.nv))
+    sim.set_ctrl(ctrl)
+    o.forward()
+    d = sim.forward_debug()
+    assert np.abs(d["Mr"][1] - o.mass_matrix()[:8, :8]).max() < 1e-12
+    assert np.abs(d["qacc_smooth"][1][:m.nv] - o.vec("qacc_smooth")).max() < 1e-8    # robot LDL^T in registers (blk_cholesky / blk_solve)
+    assert np.abs(d["qacc"][1][:m.nv] - o.vec("qacc")).max() < 1e-8
+
+
+def test_settle_and_grasp_attempts_equal_the_oracle(model_it1, simt_lib):
+    """reset_model + two whole move_and_grasp scripts (GraspingEnv.py:205-386): ~5 000 physics steps through every phase of the device code --
+    free flight, boxes on the plate (block-diagonal Newton in registers), the gripper's hulls on a box (cooperative MPR, coupled Hessian with
+    v_readlane pivots), IK, PID, the script interpreter."""
+    m = model_it1
+    n = 2
+    seeds = np.array([20, 23], dtype=np.uint64)
+    sim = BatchSim(m, n, lib_path=simt_lib)
+    sim.reset(seeds, 1, 1000.0)
+    st = sim.get_state()
+    acts = aimed_actions(st["qpos"], 4)
+    acts[1, :2] += [0.008, -0.006]                                               # off-centre: the fingers push the box before they close
+    rots = np.array([0, 4])
+    rew, ps, pr = sim.grasp_attempt(acts, rot=rots, check_mode=1)
+    s2 = sim.get_state()
+    for e in range(n):
+        o = Oracle(m)
+        o.reset(int(seeds[e]), 1, True)
+        assert np.abs(st["qpos"][e] - o.get_state()["qpos"]).max() < 1e-12       # settled state
+        r, pso, pro = o.grasp_attempt(acts[e], int(rots[e]), 1)
+        assert r == rew[e] and pso.tolist() == ps[e].tolist() and pro.tolist() == pr[e].tolist(), (e, pso, ps[e])
+        assert np.abs(s2["qpos"][e][:8] - o.qpos[:8]).max() < 1e-9 and np.abs(s2["qpos"][e][8:] - o.qpos[8:]).max() < 1e-7, e
+    assert sim.counters()["status"].max() == 0 and sim.counters()["ncon_max"].max() >= 18
+
+
+def test_six_object_scene_and_failure_exits(model_2f, simt_lib):
+    """The NV = 44 instantiation (3 boxes + 3 spheres): settle, then the reference's random agent at pixels that take the script's IK-failure exit
+    and a normal attempt."""
+    from test_gpu_parity import random_agent_attempts
+    m = model_2f
+    acts, rots = random_agent_attempts(m, 16)
+    o_codes = {}
+    for e in range(16):                                                          # pick one IK failure and one plain attempt with the oracle (fast)
+        o = Oracle(m)
+        o.reset(20 + e, 1, True)
+        r, pso, pro = o.grasp_attempt(acts[e], int(rots[e]), 0)
+        o_codes.setdefault(int(pro[3]), (e, r, pso, pro, o.qpos.copy()))
+    picks = [o_codes[k] for k in (2, 0) if k in o_codes]
+    assert len(picks) == 2, sorted(o_codes)
+    idx = [p[0] for p in picks]
+    sim = BatchSim(m, 2, lib_path=simt_lib)
+    sim.reset(20 + np.array(idx, dtype=np.uint64), 1, 1000.0)
+    rew, ps, pr = sim.grasp_attempt(acts[idx], rot=rots[idx], check_mode=0)
+    q = sim.get_state()["qpos"]
+    for k, (e, r, pso, pro, qo) in enumerate(picks):
+        assert r == rew[k] and pro.tolist() == pr[k].tolist() and pso.tolist() == ps[k].tolist(), (e, pso, ps[k])
+        assert np.abs(q[k][:8] - qo[:8]).max() < 1e-8, e
+    assert sim.counters()["status"].max() == 0
+
+
+def test_ik_and_move_ee_through_the_device_path(model_it1, simt_lib):
+    m = model_it1
+    targets = np.array([[0.0, -0.6, 1.1], [0.2, -0.45, 0.95], [0.6, 0.1, 1.2], [2.0, 2.0, 2.0]])
+    sim = BatchSim(m, len(targets), lib_path=simt_lib)
+    sim.reset(20 + np.arange(len(targets), dtype=np.uint64), 1, 0.0)
+    q5, ok = sim.ik(targets)
+    o = Oracle(m)
+    o.reset(20, 1, False)
+    for e, t in enumerate(targets):
+        oko, q5o = o.ik(t)
+        assert bool(ok[e] == 0) == oko
+        if oko:
+            assert np.abs(q5[e] - q5o).max() < 1e-10
