@@ -47,8 +47,8 @@ def build_emul(flags=(), name="libur5sim_emul.so"):
 def build_simt():
     """Test-only host build of the engine's DEVICE code path, one fibre per lane of a wavefront (tests/emul/ur5sim_simt.cpp)."""
     lib = os.path.join(os.path.dirname(EMUL_LIB), "libur5sim_simt.so")
-    srcs = [os.path.join(EMUL_DIR, f) for f in ("ur5sim_simt.cpp", "ur5sim_emul_many.cpp")]
-    deps = srcs + [os.path.join(EMUL_DIR, f) for f in ("ur5_simt_shim.h", "ur5sim_emul.cpp")] + [
+    srcs = [os.path.join(EMUL_DIR, f) for f in ("ur5sim_simt.cpp", "ur5sim_simt_many.cpp")]
+    deps = srcs + [os.path.join(EMUL_DIR, "ur5_simt_shim.h")] + [
         os.path.join(ROOT, "mujoco_rl_ur5_amd", "csrc", f) for f in ("ur5_engine.h", "ur5sim_host.h", "ur5_devmodel.h", "ur5_raster.h", "ur5_many_names.h")]
     if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(s) for s in deps):
         os.makedirs(os.path.dirname(lib), exist_ok=True)

@@ -1,6 +1,6 @@
 // ur5_simt_shim.h -- TEST-ONLY. Lets a host compiler build the DEVICE path of csrc/ur5_engine.h (everything under `#ifndef UR5_EMUL`: DPP
 // reductions, v_readlane pivots, lane shuffles, ballots, the 8-lanes-per-pair MPR, register-resident factorisations) and run it with the
-// semantics of one 64-lane wavefront: every lane is a fibre (ucontext) with its own stack and "registers", LDS is one shared array, and each
+// semantics of a workgroup of 64-lane wavefronts (one for the small-scene kernel, four for the many-object kernel): every lane is a fibre (ucontext) with its own stack and "registers", LDS is one shared array, and each
 // cross-lane operation is a rendezvous of the lanes it involves. The plain lane emulation (ur5sim_emul.cpp, -DUR5_EMUL) runs lanes one after
 // another and therefore needs LDS stand-ins for everything that lives in registers on the GPU; this build has no stand-ins.
 //
@@ -32,14 +32,14 @@
 #define __HIP_MEMORY_SCOPE_WORKGROUP 0
 
 namespace simt {
-constexpr int NL = 64, RING = 16, NCLS = 4;      // scope classes: 8, 16, 32, 64 lanes
+constexpr int NL = 256, RING = 16, NCLS = 5;     // up to 256 lanes per workgroup; scope classes: 8, 16, 32, 64 lanes, the whole workgroup
 struct Tid { unsigned x, y, z; };
 extern Tid tid, bid;
 struct Wave {
   ucontext_t sched, ctx[NL];
   char* stack[NL];
   bool done[NL];
-  int cur;
+  int cur, nl;                                   // running lane, lanes of this workgroup (64 or 256)
   uint64_t slot[NCLS][RING][NL];
   uint32_t seq[NCLS][NL];
   long idle;                                     // consecutive blocked yields (deadlock detector)
@@ -48,12 +48,12 @@ struct Wave {
 extern Wave W;
 void yield_blocked(const char* what);
 void yield_runnable();
-void run_wave(void (*body)(void*), void* arg);
+void run_workgroup(int nlanes, void (*body)(void*), void* arg);
 
 inline int cls_of(int lanes) { return lanes <= 8 ? 0 : lanes <= 16 ? 1 : lanes <= 32 ? 2 : 3; }
 // publish `v` for this lane's next operation of scope class `cls` and wait until every live lane of the aligned group has published its own
 inline uint32_t publish(int cls, uint64_t v, const char* what) {
-  const int me = W.cur, sz = 8 << cls, base = me & ~(sz - 1);
+  const int me = W.cur, sz = cls == 4 ? W.nl : 8 << cls, base = cls == 4 ? 0 : me & ~(sz - 1);
   const uint32_t k = ++W.seq[cls][me];
   W.slot[cls][k % RING][me] = v;
   for (;;) {
@@ -66,7 +66,8 @@ inline uint32_t publish(int cls, uint64_t v, const char* what) {
   return k;
 }
 inline uint64_t peek(int cls, uint32_t k, int lane) { return W.slot[cls][k % RING][lane]; }
-inline void barrier() { publish(3, 0, "barrier"); }
+inline void wave_barrier() { publish(3, 0, "wave barrier"); }
+inline void block_barrier() { publish(4, 0, "__syncthreads"); }
 }  // namespace simt
 
 #define threadIdx (simt::tid)
@@ -74,8 +75,8 @@ inline void barrier() { publish(3, 0, "barrier"); }
 
 // ---- the builtins / HIP intrinsics the engine's device path uses
 inline void __builtin_amdgcn_fence(int, const char*) {}
-inline void __builtin_amdgcn_wave_barrier() { simt::barrier(); }
-inline void __syncthreads() { simt::barrier(); }
+inline void __builtin_amdgcn_wave_barrier() { simt::wave_barrier(); }
+inline void __syncthreads() { simt::block_barrier(); }
 inline int __double2loint(double d) { uint64_t u; memcpy(&u, &d, 8); return (int)(uint32_t)u; }
 inline int __double2hiint(double d) { uint64_t u; memcpy(&u, &d, 8); return (int)(uint32_t)(u >> 32); }
 inline double __hiloint2double(int hi, int lo) { uint64_t u = ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo; double d; memcpy(&d, &u, 8); return d; }
@@ -84,29 +85,29 @@ inline double rsqrt(double x) { return 1.0 / std::sqrt(x); }
 
 // v_mov_b32 dpp: ctrl < 0x100 quad_perm, 0x140 row_mirror, 0x141 row_half_mirror, 0x142 row_bcast:15, 0x143 row_bcast:31
 inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool /*bound_ctrl*/) {
-  const int me = simt::W.cur;
+  const int me = simt::W.cur, wl = me & 63, wb = me & ~63;      // lane inside its wavefront, first lane of the wavefront
   int scope, from = -1;
   if (ctrl < 0x100) { scope = 8; from = (me & ~3) | ((ctrl >> (2 * (me & 3))) & 3); }
   else if (ctrl == 0x141) { scope = 8; from = (me & ~7) | (7 - (me & 7)); }
   else if (ctrl == 0x140) { scope = 16; from = (me & ~15) | (15 - (me & 15)); }
-  else if (ctrl == 0x142) { scope = 64; from = me >= 16 ? (me & ~15) - 1 : -1; }
-  else if (ctrl == 0x143) { scope = 64; from = me >= 32 ? 31 : -1; }
+  else if (ctrl == 0x142) { scope = 64; from = wl >= 16 ? (me & ~15) - 1 : -1; }
+  else if (ctrl == 0x143) { scope = 64; from = wl >= 32 ? wb + 31 : -1; }
   else { fprintf(stderr, "simt: dpp control 0x%x is not modelled\n", ctrl); abort(); }
   const int cls = simt::cls_of(scope);
   const uint32_t k = simt::publish(cls, (uint64_t)(uint32_t)src, "dpp");
-  const bool enabled = (row_mask >> (me >> 4) & 1) && (bank_mask >> ((me >> 2) & 3) & 1);
+  const bool enabled = (row_mask >> (wl >> 4) & 1) && (bank_mask >> ((wl >> 2) & 3) & 1);
   return enabled && from >= 0 ? (int)(uint32_t)simt::peek(cls, k, from) : old;
 }
 inline int __builtin_amdgcn_readlane(int v, int src) {
   const uint32_t k = simt::publish(3, (uint64_t)(uint32_t)v, "readlane");
-  return (int)(uint32_t)simt::peek(3, k, src & 63);
+  return (int)(uint32_t)simt::peek(3, k, (simt::W.cur & ~63) | (src & 63));
 }
 inline int* __builtin_amdgcn_permlane16_swap(int, int, bool, bool) { fprintf(stderr, "simt: permlane16_swap (GS = 32) is not modelled\n"); abort(); }
 template <class T> inline T simt_bits_get(uint64_t u) { T t; memcpy(&t, &u, sizeof(T)); return t; }
 template <class T> inline uint64_t simt_bits_put(T t) { uint64_t u = 0; memcpy(&u, &t, sizeof(T)); return u; }
 template <class T> inline T __shfl(T v, int src, int /*width*/ = 64) {
   const uint32_t k = simt::publish(3, simt_bits_put(v), "shfl");
-  return simt_bits_get<T>(simt::peek(3, k, src & 63));
+  return simt_bits_get<T>(simt::peek(3, k, (simt::W.cur & ~63) | (src & 63)));
 }
 template <class T> inline T __shfl_xor(T v, int o, int /*width*/ = 64) {
   const int cls = simt::cls_of(2 * o);
@@ -116,7 +117,8 @@ template <class T> inline T __shfl_xor(T v, int o, int /*width*/ = 64) {
 inline unsigned long long __ballot(bool p) {
   const uint32_t k = simt::publish(3, p ? 1 : 0, "ballot");
   unsigned long long m = 0;
-  for (int l = 0; l < simt::NL; l++) if (!simt::W.done[l] && simt::peek(3, k, l)) m |= 1ull << l;
+  const int wb = simt::W.cur & ~63;
+  for (int l = 0; l < 64; l++) if (!simt::W.done[wb + l] && simt::peek(3, k, wb + l)) m |= 1ull << l;
   return m;
 }
 template <class T, class U> inline T __hip_atomic_fetch_add(T* p, U v, int, int) { T o = *p; *p = o + (T)v; simt::yield_runnable(); return o; }

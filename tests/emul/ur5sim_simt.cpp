@@ -2,14 +2,15 @@
 // intrinsics supplied by ur5_simt_shim.h, every scene executed as one 64-lane wavefront of fibres (see the shim's header). Covers on the CPU
 // what the plain lane emulation cannot reach: DPP / readlane / shuffle code, ballot compactions, the cooperative MPR and the register-resident
 // factorisations of the small-scene kernel. Slow (a rendezvous per cross-lane instruction): used for single steps and short moves only.
-// Built into tests/emul/_build by tests/conftest.py; never loaded by the package. Many-object models fall through to the plain emulation.
+// Built into tests/emul/_build by tests/conftest.py; never loaded by the package. Second unit: ur5sim_simt_many.cpp (256 fibres = 4 wavefronts per scene).
 #define UR5_SIMT 1
 #include "ur5_simt_shim.h"
 #include "../../mujoco_rl_ur5_amd/csrc/ur5_engine.h"
 #include "../../mujoco_rl_ur5_amd/csrc/ur5sim_host.h"
 
-alignas(16) double ur5_smem[16384];               // "LDS": 128 KB, one scene at a time
+alignas(16) double ur5_smem[20480];               // "LDS": 160 KB, one scene at a time
 
+#ifndef UR5_SIMT_NO_RUNTIME   // (the many-object unit, ur5sim_simt_many.cpp, includes this file a second time and shares the runtime)
 // Fibre switch. glibc's swapcontext makes a signal-mask system call per switch (~0.3 us, and a step has ~10^5 of them); on x86-64 the six
 // callee-saved registers and the stack pointer are all that has to change hands.
 #if defined(__x86_64__)
@@ -39,7 +40,7 @@ void yield_blocked(const char* what) {
   W.waiting[me] = what;
   if (++W.idle > 64L * NL) {
     fprintf(stderr, "simt: deadlock -- no lane can make progress. Lanes wait at:");
-    for (int l = 0; l < NL; l++) fprintf(stderr, " %d:%s", l, W.done[l] ? "done" : (W.waiting[l] ? W.waiting[l] : "runnable"));
+    for (int l = 0; l < W.nl; l++) fprintf(stderr, " %d:%s", l, W.done[l] ? "done" : (W.waiting[l] ? W.waiting[l] : "runnable"));
     fprintf(stderr, "\n");
     abort();
   }
@@ -59,11 +60,13 @@ static void lane_main() {
   W.idle = 0;
   to_sched(W.cur);                                  // never resumed
 }
-void run_wave(void (*body)(void*), void* arg) {
+void run_workgroup(int nlanes, void (*body)(void*), void* arg) {
   g_entry = Entry{body, arg};
   memset(W.seq, 0, sizeof W.seq);
   W.idle = 0;
-  for (int l = 0; l < NL; l++) {
+  W.nl = nlanes;
+  for (int l = 0; l < NL; l++) W.done[l] = true;
+  for (int l = 0; l < nlanes; l++) {
     if (!W.stack[l]) W.stack[l] = (char*)malloc(STACK);
     W.done[l] = false; W.waiting[l] = nullptr;
 #ifdef SIMT_ASM_SWITCH
@@ -84,7 +87,7 @@ void run_wave(void (*body)(void*), void* arg) {
   }
   for (;;) {
     bool any = false;
-    for (int l = 0; l < NL; l++) {
+    for (int l = 0; l < W.nl; l++) {
       if (W.done[l]) continue;
       any = true;
       W.cur = l; tid.x = (unsigned)l;
@@ -94,6 +97,7 @@ void run_wave(void (*body)(void*), void* arg) {
   }
 }
 }  // namespace simt
+#endif   // UR5_SIMT_NO_RUNTIME
 
 static int be_open(ur5_sim*, int) { return 0; }
 static void be_close(ur5_sim*) {}
@@ -120,9 +124,12 @@ template <int NV> static void kernel_body(void* a) {
   const int slot = (int)blockIdx.x;
   const bool live = slot < P.n_env;
   const int env = (live && P.order) ? P.order[slot] : slot;
-  ur5::Engine<double, NV, 64> eng;
+  ur5::Engine<double, NV, UR5_NT> eng;
   double* r = K.rec + (size_t)(live ? env : 0) * UR5_REC_STRIDE;
   if (live) eng.load(r, P.pid_dt, P.contacts_enabled);
+#ifdef UR5_MANY
+  eng.set_hess(P.hess + (size_t)env * UR5_HESS_STRIDE);
+#endif
   eng.run(P, env, live);
   if (live) eng.save(r);
 }
@@ -133,11 +140,15 @@ template <int NV> static void run_all(ur5_sim* h, const Ur5Launch& P) {
   for (int b = 0; b < h->n; b++) {
     memset(ur5_smem, 0xFF, sizeof(ur5::Lds<double, NV>));       // a workgroup starts with whatever the previous one left in the CU's LDS
     simt::bid.x = (unsigned)b;
-    simt::run_wave(kernel_body<NV>, &K);
+    simt::run_workgroup(UR5_NT, kernel_body<NV>, &K);
   }
 }
 static int be_render(ur5_sim*, int, int, int, int, uint8_t*, float*) { return ur5host::fail(UR5_ERR_ARG, "the SIMT test build has no renderer"); }
 static int be_launch(ur5_sim* h, const Ur5Launch& P) {
+#ifdef UR5_MANY
+  run_all<UR5_MAXNV>(h, P);
+#else
   if (h->nvt == 32) run_all<32>(h, P); else run_all<UR5_MAXNV>(h, P);
+#endif
   return 0;
 }

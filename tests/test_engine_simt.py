@@ -92,3 +92,35 @@ def test_ik_and_move_ee_through_the_device_path(model_it1, simt_lib):
         assert bool(ok[e] == 0) == oko
         if oko:
             assert np.abs(q5[e] - q5o).max() < 1e-10
+
+
+# ------------------------------------------------------------------ the many-object kernel: 256 fibres = 4 wavefronts per scene
+def test_many_object_device_path(simt_lib):
+    """ur5m_run_kernel's own code -- cross-wave reductions through LDS, the envelope Cholesky with one wavefront per panel of a level, factor
+    reuse, __syncthreads between 4 waves -- against the oracle: the first contacts of the 40-object drop step by step, then contacts and
+    constrained acceleration in the dense pile 0.4 s later, then an object pushed into the forearm's collision hull (arm-collision asset)."""
+    import test_many_objects as T
+    from mujoco_rl_ur5_amd.model import load_model
+    m = load_model(T.MANY)
+    sim = BatchSim(m, 1, lib_path=simt_lib)
+    assert sim.variant == 1
+    sim.reset([20], 1, 0.0)
+    T._drop_parity(m, sim, 0, 20, 40, 1e-9)
+    sim.reset([21], 1, 0.0)
+    sim.step(200)
+    st = sim.get_state()
+    o = Oracle(m)
+    o.set_state(qpos=st["qpos"][0], qvel=st["qvel"][0], warmstart=st["warmstart"][0], pid=st["pid"][0])
+    o.forward()
+    d = sim.forward_debug()
+    oc = o.contacts()
+    assert d["ncon"][0] == len(oc) and len(oc) >= 15
+    ec = d["contacts"][0][:len(oc)]
+    for c in oc:
+        best = min(ec, key=lambda e: np.abs(e[1:4] - c[1:4]).sum())
+        assert np.abs(best[1:4] - c[1:4]).max() < 1e-9 and np.abs(best[4:7] - c[4:7]).max() < 1e-9 and abs(best[0] - c[0]) < 1e-9
+    qacc = o.vec("qacc")
+    assert np.abs(d["qacc"][0][:m.nv] - qacc).max() < 1e-6 * max(1.0, np.abs(qacc).max())
+    assert sim.counters()["status"][0] == 0
+    ma = load_model("many_objects_arm_collision")
+    T._check_arm_hull_contact(ma, BatchSim(ma, 1, lib_path=simt_lib))
