@@ -43,6 +43,7 @@ struct Wave {
   uint64_t slot[NCLS][RING][NL];
   uint32_t seq[NCLS][NL];
   long idle;                                     // consecutive blocked yields (deadlock detector)
+  long ops[8];                                   // lane 0's operation counts: 0 dpp, 1 readlane, 2 shuffle, 3 ballot, 4 wave barrier, 5 __syncthreads, 6 LDS atomic
   const char* waiting[NL];
 };
 extern Wave W;
@@ -52,6 +53,7 @@ void run_workgroup(int nlanes, void (*body)(void*), void* arg);
 
 inline int cls_of(int lanes) { return lanes <= 8 ? 0 : lanes <= 16 ? 1 : lanes <= 32 ? 2 : 3; }
 // publish `v` for this lane's next operation of scope class `cls` and wait until every live lane of the aligned group has published its own
+inline void count(int what) { if (W.cur == 0) W.ops[what]++; }
 inline uint32_t publish(int cls, uint64_t v, const char* what) {
   const int me = W.cur, sz = cls == 4 ? W.nl : 8 << cls, base = cls == 4 ? 0 : me & ~(sz - 1);
   const uint32_t k = ++W.seq[cls][me];
@@ -66,8 +68,8 @@ inline uint32_t publish(int cls, uint64_t v, const char* what) {
   return k;
 }
 inline uint64_t peek(int cls, uint32_t k, int lane) { return W.slot[cls][k % RING][lane]; }
-inline void wave_barrier() { publish(3, 0, "wave barrier"); }
-inline void block_barrier() { publish(4, 0, "__syncthreads"); }
+inline void wave_barrier() { count(4); publish(3, 0, "wave barrier"); }
+inline void block_barrier() { count(5); publish(4, 0, "__syncthreads"); }
 }  // namespace simt
 
 #define threadIdx (simt::tid)
@@ -94,11 +96,13 @@ inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask,
   else if (ctrl == 0x143) { scope = 64; from = wl >= 32 ? wb + 31 : -1; }
   else { fprintf(stderr, "simt: dpp control 0x%x is not modelled\n", ctrl); abort(); }
   const int cls = simt::cls_of(scope);
+  simt::count(0);
   const uint32_t k = simt::publish(cls, (uint64_t)(uint32_t)src, "dpp");
   const bool enabled = (row_mask >> (wl >> 4) & 1) && (bank_mask >> ((wl >> 2) & 3) & 1);
   return enabled && from >= 0 ? (int)(uint32_t)simt::peek(cls, k, from) : old;
 }
 inline int __builtin_amdgcn_readlane(int v, int src) {
+  simt::count(1);
   const uint32_t k = simt::publish(3, (uint64_t)(uint32_t)v, "readlane");
   return (int)(uint32_t)simt::peek(3, k, (simt::W.cur & ~63) | (src & 63));
 }
@@ -106,21 +110,24 @@ inline int* __builtin_amdgcn_permlane16_swap(int, int, bool, bool) { fprintf(std
 template <class T> inline T simt_bits_get(uint64_t u) { T t; memcpy(&t, &u, sizeof(T)); return t; }
 template <class T> inline uint64_t simt_bits_put(T t) { uint64_t u = 0; memcpy(&u, &t, sizeof(T)); return u; }
 template <class T> inline T __shfl(T v, int src, int /*width*/ = 64) {
+  simt::count(2);
   const uint32_t k = simt::publish(3, simt_bits_put(v), "shfl");
   return simt_bits_get<T>(simt::peek(3, k, (simt::W.cur & ~63) | (src & 63)));
 }
 template <class T> inline T __shfl_xor(T v, int o, int /*width*/ = 64) {
   const int cls = simt::cls_of(2 * o);
+  simt::count(2);
   const uint32_t k = simt::publish(cls, simt_bits_put(v), "shfl_xor");
   return simt_bits_get<T>(simt::peek(cls, k, simt::W.cur ^ o));
 }
 inline unsigned long long __ballot(bool p) {
+  simt::count(3);
   const uint32_t k = simt::publish(3, p ? 1 : 0, "ballot");
   unsigned long long m = 0;
   const int wb = simt::W.cur & ~63;
   for (int l = 0; l < 64; l++) if (!simt::W.done[wb + l] && simt::peek(3, k, wb + l)) m |= 1ull << l;
   return m;
 }
-template <class T, class U> inline T __hip_atomic_fetch_add(T* p, U v, int, int) { T o = *p; *p = o + (T)v; simt::yield_runnable(); return o; }
+template <class T, class U> inline T __hip_atomic_fetch_add(T* p, U v, int, int) { T o = *p; *p = o + (T)v; simt::count(6); simt::yield_runnable(); return o; }
 template <class T, class U> inline T __hip_atomic_fetch_max(T* p, U v, int, int) { T o = *p; if ((T)v > o) *p = (T)v; simt::yield_runnable(); return o; }
 template <class T, class U> inline T __hip_atomic_fetch_or(T* p, U v, int, int) { T o = *p; *p = o | (T)v; simt::yield_runnable(); return o; }

@@ -99,6 +99,10 @@ void run_workgroup(int nlanes, void (*body)(void*), void* arg) {
 }  // namespace simt
 #endif   // UR5_SIMT_NO_RUNTIME
 
+// lane 0's cross-lane operation counts since the library was loaded (dpp, readlane, shuffle, ballot, wave barrier, __syncthreads, LDS atomic, -)
+#ifndef UR5_SIMT_NO_RUNTIME
+extern "C" void ur5_simt_op_counts(long* out) { for (int k = 0; k < 8; k++) out[k] = simt::W.ops[k]; }
+#endif
 static int be_open(ur5_sim*, int) { return 0; }
 static void be_close(ur5_sim*) {}
 static void* be_alloc(ur5_sim*, size_t bytes) { void* p = malloc(bytes); if (p) memset(p, 0xFF, bytes); return p; }   // poisoned like the plain emulation

@@ -124,3 +124,23 @@ def test_many_object_device_path(simt_lib):
     assert sim.counters()["status"][0] == 0
     ma = load_model("many_objects_arm_collision")
     T._check_arm_hull_contact(ma, BatchSim(ma, 1, lib_path=simt_lib))
+
+
+def test_cross_lane_operation_budget_of_a_step(model_it1, simt_lib):
+    """What one physics step costs in cross-lane instructions (lane 0's counts in the SIMT build): a guard against an accidental extra barrier or
+    reduction in the hot loop, and the numbers DESIGN.md quotes. Settled 4-box scene: ~46 wave barriers, ~200 DPP moves (a 64-lane sum of a
+    double is 12 of them + 2 v_readlane), ~30 v_readlane, ~120 shuffles (the block-parallel register Cholesky), 6 ballots."""
+    import ctypes as C
+    sim = BatchSim(model_it1, 1, lib_path=simt_lib)
+
+    def counts():
+        out = (C.c_long * 8)()
+        sim.lib.ur5_simt_op_counts(out)
+        return np.array(list(out), dtype=float)
+    sim.reset([20], 1, 1000.0)
+    c0 = counts()
+    sim.step(50)
+    dpp, readlane, shuffle, ballot, wave_barrier, block_barrier, atomic, _ = (counts() - c0) / 50
+    assert 30 <= wave_barrier <= 60 and block_barrier == 0, wave_barrier
+    assert 150 <= dpp <= 260 and 20 <= readlane <= 60 and 80 <= shuffle <= 160 and ballot <= 8, (dpp, readlane, shuffle, ballot)
+    assert 10 <= atomic <= 40, atomic
