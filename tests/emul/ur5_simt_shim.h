@@ -43,10 +43,12 @@ struct Wave {
   uint64_t slot[NCLS][RING][NL];
   uint32_t seq[NCLS][NL];
   long idle;                                     // consecutive blocked yields (deadlock detector)
+  long nbar[NL];                                 // wave barriers each lane has passed in this workgroup run
   long ops[8];                                   // lane 0's operation counts: 0 dpp, 1 readlane, 2 shuffle, 3 ballot, 4 wave barrier, 5 __syncthreads, 6 LDS atomic
   const char* waiting[NL];
 };
 extern Wave W;
+extern int g_order, g_skip_barrier;
 void yield_blocked(const char* what);
 void yield_runnable();
 void run_workgroup(int nlanes, void (*body)(void*), void* arg);
@@ -68,7 +70,8 @@ inline uint32_t publish(int cls, uint64_t v, const char* what) {
   return k;
 }
 inline uint64_t peek(int cls, uint32_t k, int lane) { return W.slot[cls][k % RING][lane]; }
-inline void wave_barrier() { count(4); publish(3, 0, "wave barrier"); }
+// (g_skip_barrier = k: every lane ignores its k-th wave barrier -- a planted race for the detector's self-test)
+inline void wave_barrier() { count(4); if (++W.nbar[W.cur] == g_skip_barrier) return; publish(3, 0, "wave barrier"); }
 inline void block_barrier() { count(5); publish(4, 0, "__syncthreads"); }
 }  // namespace simt
 

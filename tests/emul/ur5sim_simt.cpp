@@ -52,6 +52,8 @@ void yield_runnable() {
   W.idle = 0;
   to_sched(me);
 }
+int g_skip_barrier = -1;
+int g_order = -1;                                   // 0 ascending, 1 descending, 2 a fresh permutation per pass (ur5_simt_set_order / UR5_SIMT_ORDER)
 struct Entry { void (*body)(void*); void* arg; };
 static Entry g_entry;
 static void lane_main() {
@@ -63,6 +65,7 @@ static void lane_main() {
 void run_workgroup(int nlanes, void (*body)(void*), void* arg) {
   g_entry = Entry{body, arg};
   memset(W.seq, 0, sizeof W.seq);
+  memset(W.nbar, 0, sizeof W.nbar);
   W.idle = 0;
   W.nl = nlanes;
   for (int l = 0; l < NL; l++) W.done[l] = true;
@@ -85,9 +88,18 @@ void run_workgroup(int nlanes, void (*body)(void*), void* arg) {
     makecontext(&W.ctx[l], lane_main, 0);
 #endif
   }
+  // Lane order of the scheduler. Results must not depend on it beyond the order in which LDS atomics land (rounding level): the engine may only
+  // rely on what the rendezvous guarantee. ur5_simt_set_order(1 | 2) (or UR5_SIMT_ORDER=reverse / =shuffle) is the race detector: a missing SYNC between a lane's LDS write and
+  // another lane's read shows up as a result that changes with the order (or as the NaN poison of the LDS image).
+  if (g_order < 0) { const char* e = getenv("UR5_SIMT_ORDER"); g_order = !e ? 0 : (e[0] == 'r' ? 1 : (e[0] == 's' ? 2 : 0)); }
+  const int mode = g_order;
+  static uint64_t rng = 0x9E3779B97F4A7C15ull;
   for (;;) {
     bool any = false;
-    for (int l = 0; l < W.nl; l++) {
+    int start = 0, stride = 1;
+    if (mode == 2) { rng = rng * 6364136223846793005ull + 1442695040888963407ull; start = (int)((rng >> 33) % (uint64_t)W.nl); stride = (int)((rng >> 20) % 16) * 2 + 1; }
+    for (int i = 0; i < W.nl; i++) {
+      const int l = mode == 1 ? W.nl - 1 - i : (mode == 2 ? (start + i * stride) % W.nl : i);      // odd stride: a permutation of 64 / 256 lanes
       if (W.done[l]) continue;
       any = true;
       W.cur = l; tid.x = (unsigned)l;
@@ -102,6 +114,8 @@ void run_workgroup(int nlanes, void (*body)(void*), void* arg) {
 // lane 0's cross-lane operation counts since the library was loaded (dpp, readlane, shuffle, ballot, wave barrier, __syncthreads, LDS atomic, -)
 #ifndef UR5_SIMT_NO_RUNTIME
 extern "C" void ur5_simt_op_counts(long* out) { for (int k = 0; k < 8; k++) out[k] = simt::W.ops[k]; }
+extern "C" void ur5_simt_set_order(int mode) { simt::g_order = mode; }
+extern "C" void ur5_simt_skip_barrier(int k) { simt::g_skip_barrier = k; }
 #endif
 static int be_open(ur5_sim*, int) { return 0; }
 static void be_close(ur5_sim*) {}

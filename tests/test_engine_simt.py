@@ -144,3 +144,63 @@ def test_cross_lane_operation_budget_of_a_step(model_it1, simt_lib):
     assert 30 <= wave_barrier <= 60 and block_barrier == 0, wave_barrier
     assert 150 <= dpp <= 260 and 20 <= readlane <= 60 and 80 <= shuffle <= 160 and ballot <= 8, (dpp, readlane, shuffle, ballot)
     assert 10 <= atomic <= 40, atomic
+
+
+def test_results_do_not_depend_on_the_lane_schedule(model_it1, simt_lib):
+    """Race detector. The fibres of a wavefront are normally scheduled in ascending lane order; here every scheduler pass uses a fresh permutation
+    (and, for the pile, descending order). The engine may only rely on what its barriers and cross-lane instructions guarantee, so the outcome must
+    stay the same up to the order in which LDS atomics land (rounding level): a missing SYNC between one lane's LDS write and another lane's
+    read would change the result with the schedule -- or surface the NaN poison the LDS image starts with."""
+    import test_many_objects as T
+    from mujoco_rl_ur5_amd.model import load_model
+    m = model_it1
+    sim = BatchSim(m, 1, lib_path=simt_lib)
+    try:
+        sim.lib.ur5_simt_set_order(2)
+        sim.reset([20], 1, 1000.0)
+        st = sim.get_state()
+        acts = aimed_actions(st["qpos"], 4)
+        rew, ps, pr = sim.grasp_attempt(acts, rot=0, check_mode=1)
+        o = Oracle(m)
+        o.reset(20, 1, True)
+        assert np.abs(st["qpos"][0] - o.get_state()["qpos"]).max() < 1e-12
+        r, pso, pro = o.grasp_attempt(acts[0], 0, 1)
+        assert r == rew[0] and pso.tolist() == ps[0].tolist() and pro.tolist() == pr[0].tolist()
+        assert np.abs(sim.get_state()["qpos"][0] - o.qpos).max() < 1e-9 and sim.counters()["status"][0] == 0
+        mm = load_model(T.MANY)
+        for order in (1, 2):
+            sim.lib.ur5_simt_set_order(order)
+            big = BatchSim(mm, 1, lib_path=simt_lib)
+            big.reset([20], 1, 0.0)
+            T._drop_parity(mm, big, 0, 20, 30, 1e-9)
+    finally:
+        sim.lib.ur5_simt_set_order(0)
+
+
+def test_the_race_detector_sees_a_planted_race(model_it1, simt_lib):
+    """Self-test of the schedule-permutation detector: with one wave barrier of the launch ignored (ur5_simt_skip_barrier) the first 30 steps of
+    a drop must stop matching the oracle -- barrier 100 is a case that ascending lane order happens to survive and a permuted order does not,
+    barrier 200 ends in the NaN poison of the LDS image -- and with no barrier skipped both orders match to rounding."""
+    m = model_it1
+    o = Oracle(m)
+    o.reset(20, 1, False)
+    o.step(30)
+    ref = o.get_state()["qpos"]
+    sim = BatchSim(m, 1, lib_path=simt_lib)
+
+    def run(skip, order):
+        sim.lib.ur5_simt_skip_barrier(skip)
+        sim.lib.ur5_simt_set_order(order)
+        sim.reset([20], 1, 0.0)
+        sim.step(30)
+        err = np.abs(sim.get_state()["qpos"][0] - ref).max()
+        return err, int(sim.counters()["status"][0])
+    try:
+        assert run(-1, 0)[0] < 1e-12 and run(-1, 2)[0] < 1e-12
+        err, status = run(100, 2)
+        assert err > 1e-10 or status != 0, (err, status)
+        err, status = run(200, 0)
+        assert not (err < 1e-9) or status != 0, (err, status)
+    finally:
+        sim.lib.ur5_simt_skip_barrier(-1)
+        sim.lib.ur5_simt_set_order(0)
