@@ -830,6 +830,11 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     } else if (s.type == UR5_GEOM_MESH) {
       real best = -1e300;
       int bi = 0;
+#if defined(UR5_MPR_DPP_COORDS) && !defined(UR5_EMUL)
+      // build option (not measured yet): the lane keeps the coordinates of its best vertex and the DPP exchange carries them along, so the
+      // winner does not have to be fetched again with a second, dependent load after the exchange
+      v3 bl;
+#endif
       if constexpr (W == 1) {
         for (int i = 0; i < s.vnum; i++) {
           const double* p = M.hullvert[s.vadr + i];
@@ -851,10 +856,23 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
           for (int k = 0; k < 4; k++) {
             const int i = base + sl + W * k;
             const real v = px[k] * d.x + py[k] * d.y + pz[k] * d.z;
+#if defined(UR5_MPR_DPP_COORDS) && !defined(UR5_EMUL)
+            if (i < s.vnum && v > best) { best = v; bi = i; bl = v3(px[k], py[k], pz[k]); }
+#else
             if (i < s.vnum && v > best) { best = v; bi = i; }
+#endif
           }
         }
       }
+#if defined(UR5_MPR_DPP_COORDS) && !defined(UR5_EMUL)
+      if constexpr (W == 8) {
+        support_exchange<0xb1>(best, bi, bl);
+        support_exchange<0x4e>(best, bi, bl);
+        support_exchange<0x141>(best, bi, bl);
+        l = bl;
+      } else l = v3(M.hullvert[s.vadr + bi]);
+    }
+#else
 #ifndef UR5_EMUL
       if constexpr (W == 8) {
         support_exchange<0xb1>(best, bi);    // quad_perm [1,0,3,2]: lane ^ 1
@@ -864,6 +882,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
 #endif
       l = v3(M.hullvert[s.vadr + bi]);
     }
+#endif
     return s.pos + mul(s.mat, l) + dir * ((real)0.5 * s.margin);
   }
 #ifndef UR5_EMUL
@@ -872,6 +891,14 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     const int oi = __builtin_amdgcn_update_dpp(0, bi, CTRL, 0xf, 0xf, false);
     const bool take = ob > best || (ob == best && oi < bi);
     best = take ? ob : best; bi = take ? oi : bi;
+  }
+  template <int CTRL> static __device__ __forceinline__ void support_exchange(real& best, int& bi, v3& bl) {
+    const real ob = (real)ur5_dpp<CTRL, 0xf>((double)best);
+    const int oi = __builtin_amdgcn_update_dpp(0, bi, CTRL, 0xf, 0xf, false);
+    const real ox = (real)ur5_dpp<CTRL, 0xf>((double)bl.x), oy = (real)ur5_dpp<CTRL, 0xf>((double)bl.y), oz = (real)ur5_dpp<CTRL, 0xf>((double)bl.z);
+    const bool take = ob > best || (ob == best && oi < bi);
+    best = take ? ob : best; bi = take ? oi : bi;
+    bl.x = take ? ox : bl.x; bl.y = take ? oy : bl.y; bl.z = take ? oz : bl.z;
   }
 #endif
   struct MV { v3 v, a, b; };
