@@ -106,7 +106,14 @@ __constant__ Ur5DevModel ur5_cmodel;
 #else
 #define SYNC() __syncthreads()
 #endif
+#if defined(UR5_OPAQUE_LANE) && !defined(UR5_SIMT)
+// build option (+1 % without step_fn in round 2, to be re-measured): the lane index through an empty volatile asm, so that the optimiser can neither hoist
+// lane-derived LDS addresses and predicates out of loops (where they end up in scratch) nor share them between phases
+__device__ __forceinline__ int ur5_lane_opaque() { int l = (int)threadIdx.x; asm volatile("" : "+v"(l)); return l; }
+#define UR5_LANE (ur5_lane_opaque() & (GS - 1))
+#else
 #define UR5_LANE ((int)threadIdx.x & (GS - 1))
+#endif
 #define UR5_GBASE ((int)threadIdx.x & ~(GS - 1))
 // Wave-wide sum / max with DPP (data-parallel primitives: the adder reads a neighbour lane's register directly) instead of
 // __shfl_xor, which goes through the LDS crossbar (ds_bpermute) six times per value: quad swaps, row mirrors, then the two
