@@ -34,7 +34,7 @@ typedef int ur5_pair_t;
 #define UR5_MAXPAIR 2560
 #define UR5_MAXCON 160
 #define UR5_MAXCAND 512
-#define UR5_MAXHV 512
+#define UR5_MAXHV 1024                             // 590 for the gripper's full hulls + 7 x 32 for the optional arm-link hulls
 #define UR5_NB 6                                   // + 2 rolling directions (condim 6)
 #ifndef UR5_NT
 #define UR5_NT 256
@@ -93,6 +93,7 @@ struct Ur5DevModel {
   int g_type[UR5_MAXG], g_kind[UR5_MAXG], g_owner[UR5_MAXG], g_condim[UR5_MAXG], g_vadr[UR5_MAXG], g_vnum[UR5_MAXG], g_dg[UR5_MAXG];
   double g_size[UR5_MAXG][3], g_pos[UR5_MAXG][3], g_mat[UR5_MAXG][9], g_rbound[UR5_MAXG], g_margin[UR5_MAXG];
   double g_friction[UR5_MAXG][3], g_solref[UR5_MAXG][2], g_solimp[UR5_MAXG][5], g_invw[UR5_MAXG][2], g_center[UR5_MAXG][3];
+  double g_boxc[UR5_MAXG][3];   // mesh geoms: centre of the hull's bounding box in the geom frame (g_size = its half extents); zero otherwise
   int dg_geom[UR5_MAXDG];
   ur5_pair_t pair_g1[UR5_MAXPAIR], pair_g2[UR5_MAXPAIR];
   double hullvert[UR5_MAXHV][3];

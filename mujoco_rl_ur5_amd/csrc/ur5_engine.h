@@ -1310,9 +1310,13 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     // conservative OBB refinement (keeps the finger/plate pair out of the narrow phase while the gripper is high above it)
     if (t2 == UR5_GEOM_BOX && dist_point_box(A.pos, B, v3(M.g_size[g2])) > r1 + margin) return true;
     if (t1 == UR5_GEOM_BOX && dist_point_box(B.pos, A, v3(M.g_size[g1])) > r2 + margin) return true;
-    // hull pairs go to MPR (expensive): first separate their oriented bounding boxes (g_size of a mesh = its extents)
+    // hull pairs go to MPR (expensive): first separate their oriented bounding boxes. g_size of a mesh = half extents of its hull's TIGHT box, whose
+    // centre g_boxc is off the geom origin (the gripper base's mesh origin is at its back end: an origin-centred box would be twice as long and reach
+    // the grasped object in every grasp). A conservative test: any separating axis it finds also makes MPR report "no contact".
     if (t2 == UR5_GEOM_MESH && (t1 == UR5_GEOM_BOX || t1 == UR5_GEOM_MESH)) {
       Sat tmp;
+      if (t1 == UR5_GEOM_MESH) A.pos = A.pos + mul(A.mat, v3(M.g_boxc[g1]));
+      B.pos = B.pos + mul(B.mat, v3(M.g_boxc[g2]));
       if (!box_sat(A, v3(M.g_size[g1]), B, v3(M.g_size[g2]), margin, tmp)) return true;
     }
     return false;

@@ -248,6 +248,7 @@ static int build_model(const void* data, size_t nbytes, int ee_body, Ur5DevModel
   // ---- geoms (collidable only)
   std::vector<int> dev_of_geom(ngeom, -1);
   int ng = 0, nhv = 0, ndg = 0;
+  std::vector<int> mesh_dev_adr;
   dev2model_geom->clear();
   for (int g = 0; g < ngeom; g++) {
     if (!geom_collide[g]) continue;
@@ -287,17 +288,25 @@ static int build_model(const void* data, size_t nbytes, int ee_body, Ur5DevModel
       D.g_dg[k] = ndg; D.dg_geom[ndg++] = k;
     }
     if (geom_type[g] == UR5_GEOM_MESH) {
+      // hull vertices are stored once per MESH (the two fingers / knuckles share theirs): the reference's full hulls, 400 / 70 / 120 vertices
+      // (UR5gripper_2_finger.xml:54-71,188-212), 590 per scene
       int mid = geom_mesh[g], n = mesh_num[mid];
-      if (nhv + n > UR5_MAXHV) return fail(UR5_ERR_MODEL, "collidable hulls exceed the vertex budget");
-      D.g_vadr[k] = nhv; D.g_vnum[k] = n;
-      double c[3] = {0, 0, 0};
+      if ((int)mesh_dev_adr.size() <= mid) mesh_dev_adr.resize(mid + 1, -1);
+      if (mesh_dev_adr[mid] < 0) {
+        if (nhv + n > UR5_MAXHV) return fail(UR5_ERR_MODEL, "collidable hulls exceed the vertex budget");
+        mesh_dev_adr[mid] = nhv;
+        for (int i = 0; i < n; i++) memcpy(D.hullvert[nhv + i], mesh_vert + 3 * (mesh_adr[mid] + i), 24);
+        nhv += n;
+      }
+      D.g_vadr[k] = mesh_dev_adr[mid]; D.g_vnum[k] = n;
+      double c[3] = {0, 0, 0}, lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
       for (int i = 0; i < n; i++) {
         const double* v = mesh_vert + 3 * (mesh_adr[mid] + i);
-        memcpy(D.hullvert[nhv + i], v, 24);
-        for (int a = 0; a < 3; a++) c[a] += v[a];
+        for (int a = 0; a < 3; a++) { c[a] += v[a]; lo[a] = v[a] < lo[a] ? v[a] : lo[a]; hi[a] = v[a] > hi[a] ? v[a] : hi[a]; }
       }
-      for (int a = 0; a < 3; a++) D.g_center[k][a] = c[a] / (n > 0 ? n : 1);
-      nhv += n;
+      // g_center: an interior point (MPR's v0). g_boxc / g_size: the hull's tight bounding box in the geom frame (broad phase only; the blob's
+      // geom_size of a mesh is the looser origin-centred max |v|)
+      for (int a = 0; a < 3; a++) { D.g_center[k][a] = c[a] / (n > 0 ? n : 1); D.g_boxc[k][a] = 0.5 * (hi[a] + lo[a]); D.g_size[k][a] = 0.5 * (hi[a] - lo[a]); }
     }
   }
   D.ngeom = ng; D.ndg = ndg;

@@ -17,8 +17,12 @@ Documented deviations from a real MuJoCo compile (see DESIGN.md "Model constants
     "success"); the double-counted ``"signed"`` / ``"legacy"`` (|volume| pyramids, MuJoCo <= 2.1 as recalled)
     variants leave a P-only steady-state error above the 0.01 rad tolerance. Kept selectable;
   * the seven UR5 arm-link meshes are not collidable (SURVEY.md H5) unless ``arm_collision=True``;
-  * collision hulls of the gripper meshes are capped at ``maxhullvert=32`` vertices (408 / 70 / 120 in the STL hulls),
-    grown farthest-point-first; the support function of a hull is a linear scan, so this bounds the MPR cost.
+  * collision hulls of the gripper meshes are the FULL hulls of the STLs (400 / 70 / 120 vertices for
+    robotiq_85_base_link_coarse / inner_knuckle_coarse / inner_finger_coarse), as in the reference
+    (``UR5gripper_2_finger.xml:54-71,188-212``): ``maxhullvert=0``. Rounds 1-2 capped them at 32 vertices; on the oracle that
+    changed 37 of 240 reward bits of the IT1 scene (``tools/hull_cap_effect.py``, ``profiles/r03_hull_cap_effect.json``).
+    A cap > 0 grows the hull farthest-point-first (MuJoCo's ``maxhullvert`` [3P, 3.x]) and stays available for experiments;
+    the ray caster's face lists stay capped (``maxvisvert``) -- they are a rendering proxy, not collision geometry.
 """
 from __future__ import annotations
 
@@ -253,7 +257,7 @@ def hull_planes(verts):
     return eq[np.sort(idx)]
 
 
-def compile_mjcf(path, *, objects=None, arm_collision=False, mesh_inertia="dedup", maxhullvert=32, maxvisvert=48):
+def compile_mjcf(path, *, objects=None, arm_collision=False, mesh_inertia="dedup", maxhullvert=0, maxvisvert=48, maxarmhullvert=32, maxgripvisvert=32):
     """Compile an MJCF file.
 
     ``objects``: optional list of dicts replacing every free object of the scene (used for the
@@ -482,8 +486,12 @@ def compile_mjcf(path, *, objects=None, arm_collision=False, mesh_inertia="dedup
             name = g["mesh"]
             if name not in mesh_cache:
                 tris = load_stl(meshes[name])
-                # collision hulls are capped at maxhullvert vertices; an arm mesh that does not collide keeps its full hull (mass / inertia do not use it)
-                hull = convex_hull_vertices(tris, maxhullvert if (arm_collision or name not in _ARM_MESHES) else 0)
+                # gripper meshes collide with their full hulls (maxhullvert = 0). The seven arm-link hulls (1.7k-2.8k vertices; they only ever touch an
+                # object when the arm crashes into the bin) are capped at maxarmhullvert when they collide at all.
+                if name in _ARM_MESHES:
+                    hull = convex_hull_vertices(tris, maxarmhullvert if arm_collision else 0)
+                else:
+                    hull = convex_hull_vertices(tris, maxhullvert)
                 if mesh_inertia == "legacy":
                     mi = mesh_inertia_legacy(tris, density)
                 elif mesh_inertia == "signed":
@@ -498,7 +506,7 @@ def compile_mjcf(path, *, objects=None, arm_collision=False, mesh_inertia="dedup
                 mesh_vert.append(hull)
                 mesh_names.append(name)
                 # faces of the (capped) hull for the ray caster: the collision hull where one exists, else <= maxvisvert vertices
-                vis = hull if name not in _ARM_MESHES else convex_hull_vertices(tris, maxvisvert)
+                vis = convex_hull_vertices(tris, maxgripvisvert if name not in _ARM_MESHES else maxvisvert)
                 pl = hull_planes(vis)
                 vis_adr.append(sum(vis_num)); vis_num.append(len(pl)); vis_plane.append(pl)
             mid, (mass, com, inert) = mesh_cache[name]

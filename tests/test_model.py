@@ -91,6 +91,21 @@ def test_shipped_assets_are_current():
     assert set(KNOWN_MODELS) >= {"/UR5+gripper/UR5gripper_2_finger.xml", "/UR5+gripper/UR5gripper_2_finger_many_objects.xml"}
 
 
+def test_gripper_collision_hulls_are_the_reference_s_full_hulls():
+    """UR5gripper_2_finger.xml:54-71,188-212 collides the whole convex hulls of the three gripper meshes (400 / 70 / 120 hull vertices). Rounds
+    1-2 shipped 32-vertex approximations, which changed 37 of 240 reward bits on the oracle (profiles/r03_hull_cap_effect.json, made by
+    tools/hull_cap_effect.py: every cap below the full hull changes rewards, the full hull is the zero line)."""
+    import json
+    for spec in KNOWN_MODELS:
+        m = load_model(spec)
+        num = dict(zip(m.names["mesh"], m.mesh_vertnum.tolist()))
+        assert (num["robotiq_85_base_link_coarse"], num["inner_knuckle_coarse"], num["inner_finger_coarse"]) == (400, 70, 120), (spec, num)
+    rep = json.load(open(os.path.join(os.path.dirname(__file__), "..", "profiles", "r03_hull_cap_effect.json")))
+    assert rep["attempts"] >= 200
+    for scene, rows in rep["scenes"].items():
+        assert rows["0"]["reward_bits_differ"] == 0 and rows["32"]["reward_bits_differ"] > 0, scene
+
+
 def test_urdf_chain_matches_mjcf(model_2f):
     """ikpy builds its chain from ur5_gripper.urdf:61-234 [3P]; the engine uses the MJCF tree. Golden origins were extracted
     from the URDF by tools/gen_golden.py; both chains must give the same ee_link pose."""
