@@ -7,9 +7,12 @@ transition always in the batch) -- for N scenes per rank at once. Observations a
 simulating GPU, the network runs there (PyTorch-ROCm / MIOpen), actions go back to the engine as a device tensor, rewards come back
 as one; per round only the 16-byte outcome records cross ranks (``sharding.gather_outcomes``, RCCL all_gather).
 
-Differences that follow from batching, all deliberate: epsilon decays per transition (``steps_done`` advances by N per round); one
-optimiser step per round on 12 sampled transitions (the reference learns once per env step); colour jitter (torchvision's
-ColorJitter, :120-126) and the depth noise run on the device (``color_jitter`` below).
+Differences that follow from batching, all deliberate: epsilon decays per transition (``steps_done`` advances by N per round); colour
+jitter (torchvision's ColorJitter, :120-126) and the depth noise run on the device (``color_jitter`` below). Learning cadence: the reference
+pushes ONE transition and takes ONE optimiser step per env step (:551-556). ``Learner.push_and_learn`` keeps that order for a round's N
+transitions -- push k, step, push k, step ... -- with ``transitions_per_update = k`` (default 1 = the reference's update-to-data ratio of 1)
+and at most ``max_updates_per_round`` steps per round (default 64: a round of 4096 scenes then learns from every 64th push); the round's
+output states the ratio it ran at (``update_to_data``).
 """
 from __future__ import annotations
 
@@ -55,12 +58,11 @@ def _hsv_to_rgb(img):
     f = h * 6.0 - i
     i = i.to(torch.int32) % 6
     p, q, t = (v * (1.0 - s)).clamp(0, 1), (v * (1.0 - s * f)).clamp(0, 1), (v * (1.0 - s * (1.0 - f))).clamp(0, 1)
-    mask = i.unsqueeze(1) == torch.arange(6, device=img.device).view(1, -1, 1, 1)
-    a1 = torch.stack((v, q, p, p, t, v), dim=1)
-    a2 = torch.stack((t, v, v, q, p, p), dim=1)
-    a3 = torch.stack((p, p, t, v, v, q), dim=1)
-    a4 = torch.stack((a1, a2, a3), dim=1)                     # [N, 3, 6, H, W]
-    return (a4 * mask.unsqueeze(1).to(img.dtype)).sum(dim=2)
+    i = i.long().unsqueeze(1)                                   # [N, 1, H, W]: one gather per channel instead of a 6-way one-hot product
+    a1 = torch.stack((v, q, p, p, t, v), dim=1).gather(1, i)
+    a2 = torch.stack((t, v, v, q, p, p), dim=1).gather(1, i)
+    a3 = torch.stack((p, p, t, v, v, q), dim=1).gather(1, i)
+    return torch.cat((a1, a2, a3), dim=1)
 
 
 def color_jitter(rgb, generator=None, brightness=0.5, contrast=0.5, saturation=0.5, hue=0.5):
@@ -76,27 +78,78 @@ def color_jitter(rgb, generator=None, brightness=0.5, contrast=0.5, saturation=0
     fs = (1 - saturation + 2 * saturation * u[:, 2]).view(n, 1, 1, 1)
     fh = (-hue + 2 * hue * u[:, 3]).view(n, 1, 1)
     order = torch.argsort(torch.rand((n, 4), device=dev, generator=generator), dim=1)    # a random permutation of the 4 ops per image
-    out = rgb
-    for pos in range(4):
-        op = order[:, pos].view(n, 1, 1, 1)
-        bright = (out * fb).clamp(0, 1)
-        contr = (fc * out + (1 - fc) * _gray(out).mean(dim=(1, 2, 3), keepdim=True)).clamp(0, 1)
-        satur = (fs * out + (1 - fs) * _gray(out)).clamp(0, 1)
-        hsv = _rgb_to_hsv(out)
-        hsv = torch.stack((torch.remainder(hsv[:, 0] + fh, 1.0), hsv[:, 1], hsv[:, 2]), dim=1)
-        huesh = _hsv_to_rgb(hsv)
-        out = torch.where(op == 0, bright, torch.where(op == 1, contr, torch.where(op == 2, satur, huesh)))
+    out = rgb.clone()
+    for pos in range(4):                                       # each operation runs ONCE per position, on the images whose order selects it there
+        for op in range(4):
+            idx = (order[:, pos] == op).nonzero(as_tuple=True)[0]
+            if idx.numel() == 0:
+                continue
+            x = out.index_select(0, idx)
+            if op == 0:
+                y = (x * fb[idx]).clamp(0, 1)
+            elif op == 1:
+                y = (fc[idx] * x + (1 - fc[idx]) * _gray(x).mean(dim=(1, 2, 3), keepdim=True)).clamp(0, 1)
+            elif op == 2:
+                y = (fs[idx] * x + (1 - fs[idx]) * _gray(x)).clamp(0, 1)
+            else:
+                hsv = _rgb_to_hsv(x)
+                y = _hsv_to_rgb(torch.stack((torch.remainder(hsv[:, 0] + fh[idx], 1.0), hsv[:, 1], hsv[:, 2]), dim=1))
+            out.index_copy_(0, idx, y)
     return out
+
+
+class Learner:
+    """Replay buffer + optimiser step of ``Grasp_Agent`` (Grasping_Agent_multidiscrete.py:140-156, 388-446, 551-556) without the environment:
+    what ``tests/test_qnet.py`` replays against a transition stream run through the reference's own ``Modules.ReplayBuffer`` and network."""
+
+    def __init__(self, policy_net, height, width, device, learning_rate=LEARNING_RATE, mem_size=MEMORY_SIZE, batch_size=BATCH_SIZE,
+                 transitions_per_update=1, max_updates_per_round=64):
+        self.policy_net, self.device, self.batch_size = policy_net, torch.device(device), int(batch_size)
+        self.memory = ReplayBuffer(mem_size, height, width, device=self.device)                          # :140-142
+        self.optimizer = torch.optim.Adam(self.policy_net.parameters(), lr=learning_rate, weight_decay=0.00002)   # :153-156
+        self.transitions_per_update, self.max_updates_per_round = max(1, int(transitions_per_update)), max(1, int(max_updates_per_round))
+        self.last_loss, self.updates_done = None, 0
+
+    def learn(self):
+        """:388-446 with GAMMA = 0: one optimiser step on BATCH_SIZE transitions (the newest always included)."""
+        if len(self.memory) < 2 * self.batch_size:                                                        # :396-398
+            return None
+        state, action, reward = self.memory.sample(self.batch_size)
+        self.policy_net.train()
+        q_pred = self.policy_net(state).reshape(self.batch_size, -1).gather(1, action)                   # :424-426
+        loss = F.binary_cross_entropy(q_pred, reward.float())                                            # :439
+        loss.backward()
+        self.optimizer.step()
+        self.optimizer.zero_grad()
+        self.last_loss = float(loss.detach())
+        self.updates_done += 1
+        return self.last_loss
+
+    def push_and_learn(self, state, action, reward, learn=True):
+        """A round's N transitions in the reference's order (:551-556: push, then learn): the transitions go into the ring in chunks of
+        ``k`` consecutive scenes, an optimiser step after each chunk (its newest transition is in the batch). k = transitions_per_update,
+        raised so that a round takes at most max_updates_per_round steps. Returns (losses, update_to_data ratio of this round)."""
+        n = state.shape[0]
+        k = max(self.transitions_per_update, -(-n // self.max_updates_per_round))
+        losses = []
+        for i0 in range(0, n, k):
+            self.memory.push(state[i0:i0 + k], action[i0:i0 + k], reward[i0:i0 + k])
+            if learn:
+                loss = self.learn()
+                if loss is not None:
+                    losses.append(loss)
+        return losses, (len(losses) / n if n else 0.0)
 
 
 class BatchedGraspAgent:
     def __init__(self, env: GraspEnv = None, n_envs=1, device=None, learning_rate=LEARNING_RATE, mem_size=MEMORY_SIZE, eps_start=EPS_START,
-                 eps_end=EPS_END, eps_decay=EPS_DECAY, seed=20, load_path=None, first_scene_id=0, **env_kwargs):
+                 eps_end=EPS_END, eps_decay=EPS_DECAY, seed=20, load_path=None, first_scene_id=0, n_total=None, transitions_per_update=1,
+                 max_updates_per_round=64, **env_kwargs):
         torch.manual_seed(seed)                                                        # :76-79
         np.random.seed(seed)
         self.device = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
         self.env = env if env is not None else GraspEnv(n_envs=n_envs, show_obs=False, observation="render", first_scene_id=first_scene_id,
-                                                        **env_kwargs)
+                                                        n_total=n_total, **env_kwargs)
         self.N, self.H, self.W = self.env.n_envs, self.env.IMAGE_HEIGHT, self.env.IMAGE_WIDTH
         self.n_actions_1, self.n_actions_2 = int(self.env.action_space.nvec[0]), int(self.env.action_space.nvec[1])   # :97-100
         self.output = self.n_actions_1 * self.n_actions_2
@@ -106,8 +159,9 @@ class BatchedGraspAgent:
             self.policy_net.load_state_dict(checkpoint["model_state_dict"])
         self.depth_threshold = float(np.round(self.env.model.cam_pos0[self.env.model.camera_name2id("top_down")][2]
                                               - self.env.TABLE_HEIGHT + 0.01, decimals=3))   # :131-136
-        self.memory = ReplayBuffer(mem_size, self.H, self.W, device=self.device)       # :140-142
-        self.optimizer = torch.optim.Adam(self.policy_net.parameters(), lr=learning_rate, weight_decay=0.00002)   # :153-156
+        self.learner = Learner(self.policy_net, self.H, self.W, self.device, learning_rate, mem_size, BATCH_SIZE, transitions_per_update,
+                               max_updates_per_round)                                  # :140-156
+        self.memory, self.optimizer = self.learner.memory, self.learner.optimizer
         self.eps_start, self.eps_end, self.eps_decay = eps_start, eps_end, eps_decay
         self.steps_done, self.eps_threshold = 0, eps_start
         self.first_scene_id = self.env.first_scene_id if env is not None else first_scene_id   # one source of truth: the env's scene range
@@ -160,17 +214,8 @@ class BatchedGraspAgent:
 
     # ------------------------------------------------------------------ learning
     def learn(self):
-        """:388-446 with GAMMA = 0: one optimiser step on BATCH_SIZE transitions (the newest always included)."""
-        if len(self.memory) < 2 * BATCH_SIZE:                                                            # :396-398
-            return None
-        state, action, reward = self.memory.sample(BATCH_SIZE)
-        self.policy_net.train()
-        q_pred = self.policy_net(state).reshape(BATCH_SIZE, -1).gather(1, action)                        # :424-426
-        loss = F.binary_cross_entropy(q_pred, reward.float())                                            # :439
-        loss.backward()
-        self.optimizer.step()
-        self.optimizer.zero_grad()
-        self.last_loss = float(loss.detach())
+        """One optimiser step (:388-446), see ``Learner.learn``."""
+        self.last_loss = self.learner.learn()
         return self.last_loss
 
     # ------------------------------------------------------------------ one round of the episode loop (:540-560)
@@ -181,9 +226,10 @@ class BatchedGraspAgent:
         action, greedy = self.epsilon_greedy(state, obs)
         env_action = self.transform_action(action)
         reward, skipped = self.env.step_device(env_action, obs["depth"], self.device)
-        self.memory.push(state, action, reward)                                                          # :551-554
+        losses, utd = self.learner.push_and_learn(state, action, reward, learn=learn)                    # :551-556
+        self.last_loss = losses[-1] if losses else None
         ids = self.first_scene_id + torch.arange(self.N, dtype=torch.int32, device=self.device)
         rec = torch.stack([ids, env_action[:, 0].int(), env_action[:, 1].int(), reward.int()], dim=1)
         outcomes = sharding.gather_outcomes(rec)
-        loss = self.learn() if learn else None
-        return {"reward": reward, "skipped": skipped, "greedy": greedy, "loss": loss, "outcomes": outcomes, "epsilon": self.eps_threshold}
+        return {"reward": reward, "skipped": skipped, "greedy": greedy, "loss": self.last_loss if learn else None, "losses": losses,
+                "update_to_data": utd, "outcomes": outcomes, "epsilon": self.eps_threshold}

@@ -62,7 +62,7 @@ enum { UR5_KIND_STATIC = 0, UR5_KIND_ROBOT = 1, UR5_KIND_OBJECT = 2 };
 
 // status bits (per env, sticky until reset)
 #define UR5_ST_CONTACT_OVERFLOW 1
-#define UR5_ST_NAN 2
+#define UR5_ST_NAN 2                                 // a step produced a non-finite (or > 1e10) state: the scene went back to qpos0 (mj_resetData [3P]) and is flagged
 #define UR5_ST_ROW_OVERFLOW 4
 #define UR5_ST_CAND_OVERFLOW 8                       // more broad-phase survivors than UR5_MAXCAND: pairs were dropped
 
@@ -89,6 +89,7 @@ struct Ur5DevModel {
   double obj_arm[UR5_MAXOBJ][2], obj_damp[UR5_MAXOBJ][2];     // [lin, rot]
   double obj_invweight[UR5_MAXOBJ][2];                         // dof_invweight0 lin / rot
   double obj_lo[UR5_MAXOBJ][3], obj_hi[UR5_MAXOBJ][3];
+  double obj_qpos0[UR5_MAXOBJ][7];                             // the object's 7 qpos0 entries (mj_resetData of a blown-up scene)
   // ---- geoms
   int g_type[UR5_MAXG], g_kind[UR5_MAXG], g_owner[UR5_MAXG], g_condim[UR5_MAXG], g_vadr[UR5_MAXG], g_vnum[UR5_MAXG], g_dg[UR5_MAXG];
   double g_size[UR5_MAXG][3], g_pos[UR5_MAXG][3], g_mat[UR5_MAXG][9], g_rbound[UR5_MAXG], g_margin[UR5_MAXG];

@@ -173,8 +173,11 @@ template <int W, class T> __device__ __forceinline__ T ur5_wave_max(T v) {   // 
 #define PROF(id) ((void)0)
 #endif
 enum { PF_KIN = 0, PF_CRB, PF_VEL, PF_BROAD, PF_NARROW, PF_ROWS, PF_NEWTON_INIT, PF_IMAGES, PF_LINESEARCH, PF_GRADG, PF_HASM, PF_CHOL, PF_SOLVE,
-       PF_INTEGRATE, PF_PID, PF_IK, PF_CORECLK, PF_REALCLK, PF_X0, PF_X1, PF_X2, PF_X3, PF_X4, PF_X5, PF_X6, PF_X7, PF_COUNT };   // the last two: start / end of the scene's wave in 100 MHz ticks (s_memrealtime)
+       PF_INTEGRATE, PF_PID, PF_IK, PF_CORECLK, PF_REALCLK, PF_X0, PF_X1, PF_X2, PF_X3, PF_X4, PF_X5, PF_X6, PF_X7, PF_COUNT };   // PF_X7: MPR pairs (count, not cycles)   // the last two: start / end of the scene's wave in 100 MHz ticks (s_memrealtime)
 
+#ifndef UR5_SUP_K
+#define UR5_SUP_K 4   // hull vertices per lane and trip of the cooperative support scan
+#endif
 #ifndef UR5_INL_POW
 #define UR5_INL_POW 1
 #endif
@@ -350,7 +353,7 @@ template <class real, int NV_> struct Lds {
 #if defined(UR5_PROFILE) && !defined(UR5_EMUL)
   double prof[PF_COUNT];
 #endif
-  int status, solver_iters, ncon_max;
+  int status, solver_iters, ncon_max, badstate;
   real pid_dt;
   int contacts_enabled, last_steps, total_steps;
 };
@@ -429,7 +432,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
   UR5_FN void load(const double* rec, real dt, int con) {
     PAR(i, UR5_REC_STRIDE) S.rec[i] = (real)rec[i];
     if (UR5_LANE == 0) { S.pid_dt = dt; S.contacts_enabled = con; S.last_steps = 0; S.total_steps = 0; }
-    if (UR5_LANE == 0) { S.status = 0; S.solver_iters = 0; S.ncon_max = 0; S.ncon = 0; S.nsr = 0; }
+    if (UR5_LANE == 0) { S.status = 0; S.solver_iters = 0; S.ncon_max = 0; S.ncon = 0; S.nsr = 0; S.badstate = 0; }
 #ifdef UR5_MANY
     if (UR5_LANE == 0) { S.nskip = 0; S.act_changed = 1; }
 #endif
@@ -849,18 +852,18 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
           if (v > best) { best = v; bi = i; }
         }
       } else {
-        // 4 vertices per lane and trip, all 12 loads issued before the first use (the hulls live in constant memory: one L1 / L2 round trip
-        // per trip instead of one per vertex)
-        for (int base = 0; base < s.vnum; base += 4 * W) {
-          real px[4], py[4], pz[4];
+        // UR5_SUP_K vertices per lane and trip, all their loads issued before the first use (the hulls live in constant memory: one L1 / L2 round
+        // trip per trip instead of one per vertex)
+        for (int base = 0; base < s.vnum; base += UR5_SUP_K * W) {
+          real px[UR5_SUP_K], py[UR5_SUP_K], pz[UR5_SUP_K];
 #pragma unroll
-          for (int k = 0; k < 4; k++) {
+          for (int k = 0; k < UR5_SUP_K; k++) {
             const int i = base + sl + W * k;
             const double* p = M.hullvert[s.vadr + (i < s.vnum ? i : s.vnum - 1)];
             px[k] = (real)p[0]; py[k] = (real)p[1]; pz[k] = (real)p[2];
           }
 #pragma unroll
-          for (int k = 0; k < 4; k++) {
+          for (int k = 0; k < UR5_SUP_K; k++) {
             const int i = base + sl + W * k;
             const real v = px[k] * d.x + py[k] * d.y + pz[k] * d.z;
 #if defined(UR5_MPR_DPP_COORDS) && !defined(UR5_EMUL)
@@ -1353,6 +1356,9 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
           real depth;
           v3 nrm, pos;
           const bool hit = mpr<8>(sa, sb, &depth, &nrm, &pos, sl);
+#if defined(UR5_PROFILE)
+          if (sl == 0) UR5_ATOMIC_ADD(&S.prof[PF_X7], 1.0 + 1e-9 * (double)((sa.type == UR5_GEOM_MESH ? sa.vnum : 0) + (sb.type == UR5_GEOM_MESH ? sb.vnum : 0)));   // pairs + 1e-9 x hull vertices per support call
+#endif
           const real dist = margin - depth;
           if (hit && dist < margin && sl == 0) emit(sink, pos, nrm, dist);
         }
@@ -2852,6 +2858,24 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     PROF_T0();
     integrate(fr); PROF(PF_INTEGRATE);
     if (UR5_LANE == 0) S.total_steps++;
+    guard_state();
+  }
+  // mj_step's state guard [3P]: mj_checkPos / mj_checkVel / mj_checkAcc -> mjWARN_BAD* + mj_resetData when an entry is NaN or beyond mjMAXVAL = 1e10:
+  // the scene returns to qpos0 with zero velocity / warm start / controls / time (the PID state is the controller's and persists) and stays flagged
+  // (UR5_ST_NAN, sticky until the next reset). Same rule, same place as oracle Sim::step().
+  UR5_FN void guard_state() {
+    bool bad = false;
+    PAR(i, M.nq + M.nv) { const real v = S.rec[i < M.nq ? UR5_REC_QPOS + i : UR5_REC_QVEL + (i - M.nq)]; if (!(fabs(v) <= (real)1e10)) bad = true; }
+    if (bad) S.badstate = 1;   // benign race: every writer stores the same value
+    SYNC();
+    if (S.badstate) {
+      SYNC();
+      PAR(i, M.nq) qpos()[i] = i < M.nrd ? (real)M.rd_qpos0[i] : (real)M.obj_qpos0[(i - M.nrd) / 7][(i - M.nrd) % 7];
+      PAR(i, M.nv) { qvel()[i] = 0; warm()[i] = 0; }
+      PAR(a, M.nu) ctrl()[a] = 0;
+      if (UR5_LANE == 0) { S.rec[UR5_REC_MISC + 2] = 0; S.status |= UR5_ST_NAN; S.badstate = 0; }
+      SYNC();
+    }
   }
   // In the wavefront-per-scene kernel the step is a real function: the script interpreter, the IK and the PID around it then have their own
   // register allocation, and nothing lane-derived (LDS addresses, lane predicates) that the step uses can be hoisted out of the script's
@@ -3099,7 +3123,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
               result = grasped ? 1 : 0;
               if (P.reset_seeds && P.reset_seeds[env] != 0) {
                 SYNC();
-                if (UR5_LANE == 0) ur5_reset_record(M, P.qpos0, S.rec, P.reset_seeds[env]);
+                if (UR5_LANE == 0) { ur5_reset_record(M, P.qpos0, S.rec, P.reset_seeds[env]); S.status = 0; }   // status bits are sticky until a reset: ur5_reset / ur5_reset_dev clear them too
                 SYNC();
                 pr.mask = mask_all(); pr.tol = (real)1e-7; pr.max_steps = 10; pr.repeat = P.reset_chunks;   // :473 stay(1000)
                 if (pr.repeat <= 0) pr.done = true;
@@ -3311,7 +3335,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
                   result = grasped ? 1 : 0;
                   if (P.reset_seeds && P.reset_seeds[env] != 0) {
                     SYNC();
-                    if (UR5_LANE == 0) ur5_reset_record(M, P.qpos0, S.rec, P.reset_seeds[env]);
+                    if (UR5_LANE == 0) { ur5_reset_record(M, P.qpos0, S.rec, P.reset_seeds[env]); S.status = 0; }   // status bits are sticky until a reset: ur5_reset / ur5_reset_dev clear them too
                     SYNC();
                     pr.mask = mask_all(); pr.tol = (real)1e-7; pr.max_steps = 10; pr.repeat = P.reset_chunks;   // :473 stay(1000)
                     if (pr.repeat <= 0) pr.done = true;

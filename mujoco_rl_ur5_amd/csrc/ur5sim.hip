@@ -28,10 +28,12 @@
 template <int NV, int GS>
 __global__ void UR5_KERNEL_ATTR(GS) ur5_run_kernel(double* __restrict__ rec, Ur5Launch P) {
   const int slot = blockIdx.x * (UR5_NT / GS) + (int)threadIdx.x / GS;
-  const bool live = slot < P.n_env;                // a half-filled last workgroup: the lanes of the missing scene idle
+  const bool present = slot < P.n_env;             // a half-filled last workgroup: the lanes of the missing scene idle
   // workgroups are dispatched in blockIdx order: a caller that knows which scenes have the most work ahead of them (an episode reset to
   // settle first, a box to carry) lists those first, so that the short ones fill the tail of the launch
-  const int env = (live && P.order) ? P.order[slot] : slot;
+  const int env = (present && P.order) ? P.order[slot] : slot;
+  // a stay of zero chunks (the unflagged scenes of ur5_reset_dev) touches nothing: the record, last_movement_steps included, stays as it is
+  const bool live = present && !(P.op == UR5_OP_STAY && P.max_steps[env] <= 0);
   ur5::Engine<double, NV, GS> eng;
   double* r = rec + (size_t)(live ? env : 0) * UR5_REC_STRIDE;
   if (live) eng.load(r, P.pid_dt, P.contacts_enabled);
@@ -143,9 +145,9 @@ static int be_event_pair(ur5_sim* h, HipBackend* b, hipEvent_t* e0, hipEvent_t* 
     b->ev.push_back(e);
   }
   *e0 = b->ev[2 * b->pending]; *e1 = b->ev[2 * b->pending + 1];
-  b->pending++;
-  return 0;
+  return 0;   // the pair counts (be_event_commit) only once BOTH events have been recorded: an error in between must not leave a half-recorded pair pending
 }
+static void be_event_commit(HipBackend* b) { b->pending++; }
 #define HIPCHK(call)                                                                                  \
   do {                                                                                                \
     hipError_t e_ = (call);                                                                           \
@@ -210,6 +212,12 @@ static int be_d2h(ur5_sim* h, void* dst, const void* src, size_t bytes) {
   HIPCHK(hipStreamSynchronize(b->stream));
   return 0;
 }
+static int be_d2d_async(ur5_sim* h, void* dst, const void* src, size_t bytes) {
+  HipBackend* b = (HipBackend*)h->be;
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, b->stream));
+  return 0;
+}
 static int be_upload_model(ur5_sim* h);
 static int be_launch(ur5_sim* h, const Ur5Launch& P) {
   HipBackend* b = (HipBackend*)h->be;
@@ -237,6 +245,7 @@ static int be_launch(ur5_sim* h, const Ur5Launch& P) {
 #endif
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(ev1, b->stream));
+  be_event_commit(b);
   return 0;
 }
 static int be_reset_dev(ur5_sim* h, const uint64_t* seeds_dev, const uint8_t* mask_dev, int chunks, int* max_steps_dev) {
@@ -265,18 +274,19 @@ static int be_render(ur5_sim* h, int cam, int W, int Hh, int mode, uint8_t* rgb_
   HIPCHK(hipSetDevice(h->device));
   int rc = be_upload_model(h);
   if (rc) return rc;
-  hipEvent_t ev0, ev1;
-  if (be_event_pair(h, b, &ev0, &ev1)) return ur5host::fail(UR5_ERR_DEVICE, "hipEventCreate failed");
-  HIPCHK(hipEventRecord(ev0, b->stream));
   if (!h->d_gpose) {
     h->d_gpose = be_alloc(h, (size_t)h->n * UR5_R_MAXG * sizeof(Ur5GeomPose));
     if (!h->d_gpose) return ur5host::fail(UR5_ERR_DEVICE, "device allocation failed (render geom poses)");
   }
+  hipEvent_t ev0, ev1;
+  if (be_event_pair(h, b, &ev0, &ev1)) return ur5host::fail(UR5_ERR_DEVICE, "hipEventCreate failed");
+  HIPCHK(hipEventRecord(ev0, b->stream));
   hipLaunchKernelGGL(ur5_render_pose_kernel, dim3(h->n), dim3(64), 0, b->stream, h->d_rm, h->d_rec, h->n, cam, W, Hh, (Ur5GeomPose*)h->d_gpose);
   dim3 grid(((W + 15) / 16) * ((Hh + 15) / 16), h->n), block(256);
   hipLaunchKernelGGL(ur5_render_kernel, grid, block, 0, b->stream, h->d_rm, (const Ur5GeomPose*)h->d_gpose, cam, W, Hh, mode, rgb_dev, depth_dev);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(ev1, b->stream));
+  be_event_commit(b);
   return 0;
 }
 static int be_sync(ur5_sim* h) {

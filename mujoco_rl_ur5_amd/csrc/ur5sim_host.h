@@ -235,6 +235,7 @@ static int build_model(const void* data, size_t nbytes, int ee_body, Ur5DevModel
       memcpy(D.obj_pos0[k], body_pos + 3 * b, 24);
     }
     int d0 = nrd + 6 * k;
+    memcpy(D.obj_qpos0[k], qpos0 + nrd + 7 * k, 56);
     D.obj_mass[k] = body_mass[b];
     for (int a = 0; a < 3; a++) D.obj_inertia[k][a] = bi[a];
     D.obj_arm[k][0] = dof_arm[d0]; D.obj_arm[k][1] = dof_arm[d0 + 3];
@@ -422,7 +423,8 @@ struct ur5_sim {
   unsigned* d_mask = nullptr;
   double *d_target = nullptr, *d_tol = nullptr, *d_debug = nullptr, *d_hess = nullptr, *d_qpos0 = nullptr;
   void* d_gpose = nullptr;        // render: per-scene geom poses + screen boxes (HIP backend)
-  const int* d_order = nullptr;   // caller-owned dispatch order of the scripted launches (ur5_set_order_dev), NULL = scene order
+  const int* d_order = nullptr;   // dispatch order of the scripted launches (ur5_set_order_dev), NULL = scene order; points at d_order_buf
+  int* d_order_buf = nullptr;     // handle-owned copy: the caller's tensor may be freed or rewritten once ur5_set_order_dev has returned
   uint64_t model_hash = 0;        // of hm: handles with equal models share the device's constant-memory copy
   double kernel_ms_total = 0;   // engine-kernel time of every launch since ur5_create (HIP events on the handle's stream)
   int *d_max = nullptr, *d_result = nullptr, *d_steps = nullptr, *d_ps = nullptr, *d_pr = nullptr;
@@ -438,6 +440,7 @@ static void* be_alloc(ur5_sim* h, size_t bytes);
 static void be_free(ur5_sim* h, void* p);
 static int be_h2d(ur5_sim* h, void* dst, const void* src, size_t bytes);
 static int be_d2h(ur5_sim* h, void* dst, const void* src, size_t bytes);
+static int be_d2d_async(ur5_sim* h, void* dst, const void* src, size_t bytes);   // device-to-device on the handle's stream, stream-ordered, no host wait
 static int be_launch(ur5_sim* h, const Ur5Launch& P);
 static int be_sync(ur5_sim* h);
 static int be_set_stream(ur5_sim* h, void* stream, int external);
@@ -567,7 +570,7 @@ int ur5_create(const void* blob, size_t nbytes, int n_env, int device_id, const 
 void ur5_destroy(ur5_sim* h) {
   UR5_FWD_VOID(destroy, (h));
   if (!h) return;
-  void* ptrs[] = {h->dm, h->d_rec, h->d_mask, h->d_target, h->d_tol, h->d_max, h->d_result, h->d_steps, h->d_ps, h->d_pr, h->d_debug, h->d_rm, h->d_rgb, h->d_depth, h->d_hess, h->d_qpos0, h->d_gpose};
+  void* ptrs[] = {h->dm, h->d_rec, h->d_mask, h->d_target, h->d_tol, h->d_max, h->d_result, h->d_steps, h->d_ps, h->d_pr, h->d_debug, h->d_rm, h->d_rgb, h->d_depth, h->d_hess, h->d_qpos0, h->d_gpose, h->d_order_buf};
   for (void* p : ptrs) if (p) be_free(h, p);
   be_close(h);
   delete h;
@@ -810,7 +813,16 @@ int ur5_render(ur5_sim* h, int camera_id, int width, int height, int depth_mode,
   return rc;
 }
 int ur5_set_order_dev(ur5_sim* h, const int* order_dev) {
-  UR5_FWD(set_order_dev, (h, order_dev)); h->d_order = order_dev; return 0; }
+  UR5_FWD(set_order_dev, (h, order_dev));
+  if (!order_dev) { h->d_order = nullptr; return 0; }
+  if (!h->d_order_buf) h->d_order_buf = (int*)be_alloc(h, (size_t)h->n * 4);
+  if (!h->d_order_buf) return ur5host::fail(UR5_ERR_DEVICE, "device allocation failed (dispatch order)");
+  // copied on the handle's stream: later launches read the copy, so the caller's buffer only has to stay valid until work queued so far has run
+  int rc = be_d2d_async(h, h->d_order_buf, order_dev, (size_t)h->n * 4);
+  if (rc) return rc;
+  h->d_order = h->d_order_buf;
+  return 0;
+}
 int ur5_sync(ur5_sim* h) {
   UR5_FWD(sync, (h)); return be_sync(h); }
 int ur5_set_stream(ur5_sim* h, void* hip_stream, int external) {

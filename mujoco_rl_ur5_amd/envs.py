@@ -73,7 +73,25 @@ class GraspEnv(object):
         # multi-rank runs: this handle simulates scenes [first_scene_id, first_scene_id + n_envs) of n_total; seeds are keyed by the
         # GLOBAL scene id (sharding.global_seeds), so a scene's trajectory does not depend on how the batch is sharded
         self.first_scene_id = int(first_scene_id)
-        self.n_total = int(n_total) if n_total is not None else self.first_scene_id + self.n_envs
+        if n_total is None:
+            # the episode stride of the seeds must be the GLOBAL scene count on every rank (else rank 0's episode 1 re-simulates rank 1's episode 0)
+            world = 1
+            try:
+                import torch.distributed as dist
+                if dist.is_available() and dist.is_initialized():
+                    world = dist.get_world_size()
+            except ImportError:
+                pass
+            if world > 1 and self.first_scene_id == dist.get_rank() * self.n_envs:
+                n_total = world * self.n_envs                                # this rank's contiguous shard (sharding.shard_range)
+            elif self.first_scene_id == 0:
+                n_total = self.n_envs                                        # a stand-alone handle
+            else:
+                raise ValueError("first_scene_id > 0 needs n_total (the global scene count): seeds are keyed by global scene id and episode, "
+                                 "and a per-rank stride would make ranks re-simulate each other's episodes")
+        self.n_total = int(n_total)
+        if self.first_scene_id + self.n_envs > self.n_total:
+            raise ValueError("scene range [first_scene_id, first_scene_id + n_envs) exceeds n_total")
         self.device_id = int(device_id)
         self._episode = 0
         self.last_phase_steps = None
@@ -127,13 +145,18 @@ class GraspEnv(object):
         self.controller.last_movement_steps = self._one(ps[:, 11])
         return rew.astype(np.int64)
 
+    def episode_seeds(self, episode):
+        """Seeds of this handle's scenes for ``episode``: base + global scene id + episode * n_total (== sharding.global_seeds for the rank that
+        owns this scene range), so a scene's trajectory does not depend on how the batch is sharded."""
+        return (np.uint64(self.base_seed) + np.arange(self.first_scene_id, self.first_scene_id + self.n_envs, dtype=np.uint64)
+                + np.uint64(episode * self.n_total))
+
     def reset(self):
         """MujocoEnv.reset() [3P] -> reset_model() (GraspingEnv.py:409-477)."""
         return self.reset_model()
 
     def reset_model(self, show_obs=True):                                    # :409-477
-        seeds = (np.uint64(self.base_seed) + np.arange(self.first_scene_id, self.first_scene_id + self.n_envs, dtype=np.uint64)
-                 + np.uint64(self._episode * self.n_total))                   # == sharding.global_seeds for this rank's range
+        seeds = self.episode_seeds(self._episode)
         self._episode += 1
         self.sim.reset(seeds, mode=1, settle_ms=1000.0 + (5000.0 if self.demo_mode else 0.0))   # :473-475
         self.current_observation = self.get_observation(show=self.show_observations)

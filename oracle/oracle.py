@@ -36,7 +36,7 @@ def lib():
         for f in ("ur5o_nq", "ur5o_nv", "ur5o_nu", "ur5o_ncon", "ur5o_nefc", "ur5o_solver_iter_last", "ur5o_last_steps"):
             getattr(L, f).argtypes = [vp]
             getattr(L, f).restype = C.c_int
-        for f in ("ur5o_total_steps", "ur5o_solver_iters"):
+        for f in ("ur5o_total_steps", "ur5o_solver_iters", "ur5o_bad_state_resets"):
             getattr(L, f).argtypes = [vp]
             getattr(L, f).restype = C.c_long
         L.ur5o_set_options.argtypes = [vp, C.c_int, C.c_double, C.c_int]
@@ -194,6 +194,11 @@ class Oracle:
     @property
     def total_steps(self):
         return lib().ur5o_total_steps(self._h)
+
+    @property
+    def bad_state_resets(self):
+        """How often a step produced a non-finite / > 1e10 state and the scene went back to qpos0 (mj_resetData [3P])."""
+        return lib().ur5o_bad_state_resets(self._h)
 
     @property
     def solver_iters(self):

@@ -1380,11 +1380,29 @@ struct Sim {
     }
     time += h;
   }
+  // mj_step [3P] guards the state: mj_checkPos / mj_checkVel / mj_checkAcc raise mjWARN_BADQPOS / BADQVEL / BADQACC when an entry is NaN or larger than
+  // mjMAXVAL = 1e10 and call mj_resetData -- the scene silently returns to qpos0 with zero velocity, warm start, controls and time (the controller's
+  // PID objects live in Python and keep their state). Here the test runs once per step, on the state the step produced (an internal blow-up is
+  // caught in the step it happens in; MuJoCo tests the incoming state and the acceleration), and the scene is flagged (bad_state_resets).
+  long bad_state_resets = 0;
+  bool state_is_bad() const {
+    for (double v : qpos) if (!(std::fabs(v) <= 1e10)) return true;
+    for (double v : qvel) if (!(std::fabs(v) <= 1e10)) return true;
+    return false;
+  }
+  void reset_data() {
+    qpos.assign(M.qpos0, M.qpos0 + nq);
+    std::fill(qvel.begin(), qvel.end(), 0.0);
+    std::fill(qacc_warmstart.begin(), qacc_warmstart.end(), 0.0);
+    std::fill(ctrl.begin(), ctrl.end(), 0.0);
+    time = 0;
+  }
   void step() {  // sim.step(), MujocoController.py:379
     forward();
     qacc_warmstart = qacc;
     integrate();
     total_steps++;
+    if (state_is_bad()) { reset_data(); bad_state_resets++; }
   }
 
   // ------------------------------------------------------------------ controller layer
@@ -1852,6 +1870,7 @@ int ur5o_grasp_attempt(void* h, const double* xyz, int rot, int check_mode, doub
   return ((Sim*)h)->grasp_attempt(xyz, rot, check_mode, table_height, phase_steps, phase_result);
 }
 long ur5o_total_steps(void* h) { return ((Sim*)h)->total_steps; }
+long ur5o_bad_state_resets(void* h) { return ((Sim*)h)->bad_state_resets; }
 long ur5o_solver_iters(void* h) { return ((Sim*)h)->solver_iter_total; }
 int ur5o_last_steps(void* h) { return ((Sim*)h)->last_steps; }
 // introspection

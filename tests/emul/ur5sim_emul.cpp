@@ -16,6 +16,7 @@ static void* be_alloc(ur5_sim*, size_t bytes) { void* p = malloc(bytes); if (p) 
 static void be_free(ur5_sim*, void* p) { free(p); }
 static int be_h2d(ur5_sim*, void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); return 0; }
 static int be_d2h(ur5_sim*, void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); return 0; }
+static int be_d2d_async(ur5_sim*, void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); return 0; }
 static int be_sync(ur5_sim*) { return 0; }
 static int be_set_stream(ur5_sim*, void*, int) { return 0; }
 static int be_reset_dev(ur5_sim* h, const uint64_t* seeds, const uint8_t* mask, int chunks, int* max_steps) {
@@ -32,6 +33,7 @@ template <int NV> static void run_all(ur5_sim* h, const Ur5Launch& P) {
   L* lds = new L();
   for (int i = 0; i < h->n; i++) {
     const int e = P.order ? P.order[i] : i;
+    if (P.op == UR5_OP_STAY && P.max_steps[e] <= 0) continue;   // as in ur5_run_kernel: a stay of zero chunks touches nothing
     memset((void*)lds, 0xFF, sizeof(L));
     ur5_emul_lds = lds;
     ur5_emul_model = h->dm;

@@ -123,6 +123,7 @@ static void* be_alloc(ur5_sim*, size_t bytes) { void* p = malloc(bytes); if (p) 
 static void be_free(ur5_sim*, void* p) { free(p); }
 static int be_h2d(ur5_sim*, void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); return 0; }
 static int be_d2h(ur5_sim*, void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); return 0; }
+static int be_d2d_async(ur5_sim*, void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); return 0; }
 static int be_sync(ur5_sim*) { return 0; }
 static int be_set_stream(ur5_sim*, void*, int) { return 0; }
 static int be_reset_dev(ur5_sim* h, const uint64_t* seeds, const uint8_t* mask, int chunks, int* max_steps) {
@@ -140,8 +141,9 @@ template <int NV> static void kernel_body(void* a) {
   const KernelArgs<NV>& K = *(const KernelArgs<NV>*)a;
   const Ur5Launch& P = *K.P;
   const int slot = (int)blockIdx.x;
-  const bool live = slot < P.n_env;
-  const int env = (live && P.order) ? P.order[slot] : slot;
+  const bool present = slot < P.n_env;
+  const int env = (present && P.order) ? P.order[slot] : slot;
+  const bool live = present && !(P.op == UR5_OP_STAY && P.max_steps[env] <= 0);
   ur5::Engine<double, NV, UR5_NT> eng;
   double* r = K.rec + (size_t)(live ? env : 0) * UR5_REC_STRIDE;
   if (live) eng.load(r, P.pid_dt, P.contacts_enabled);

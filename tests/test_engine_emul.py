@@ -138,16 +138,31 @@ def test_two_finger_six_object_scene_runs(model_2f, emul_lib):
     assert np.abs(np.linalg.norm(quats, axis=1) - 1).max() < 1e-12
 
 
-def test_non_finite_state_is_flagged(model_it1, emul_lib):
-    """A NaN must never come back looking like a result: status bit 2 (include/ur5sim.h) is set for that scene only."""
+def test_non_finite_state_resets_the_scene_like_mj_resetdata_and_flags_it(model_it1, emul_lib):
+    """mj_step's state guard [3P] (mj_checkPos / mj_checkVel / mj_checkAcc -> mjWARN_BAD* + mj_resetData): a scene whose step produces a NaN (or
+    a value beyond 1e10) goes back to qpos0 with zero velocity / warm start / controls / time and keeps running; it is flagged (status bit 2,
+    include/ur5sim.h), its neighbours are untouched, and the oracle does the same thing in the same step."""
     sim = BatchSim(model_it1, 2, lib_path=emul_lib)
     sim.reset([20, 21], 1, 0.0)
     st = sim.get_state()
+    o = Oracle(model_it1)
+    o.set_state(qpos=st["qpos"][1], qvel=st["qvel"][1], warmstart=st["warmstart"][1], pid=st["pid"][1])
     st["qvel"][1, 3] = np.nan
     sim.set_state(qvel=st["qvel"])
-    sim.step(2)
-    c = sim.counters()
-    assert c["status"][0] == 0 and c["status"][1] & 2
+    o.set_state(qvel=st["qvel"][1])
+    sim.step(1)
+    o.step(1)
+    c, s1 = sim.counters(), sim.get_state()
+    assert c["status"][0] == 0 and c["status"][1] & 2 and o.bad_state_resets == 1
+    assert np.array_equal(s1["qpos"][1], model_it1.qpos0) and not s1["qvel"][1].any() and not s1["warmstart"][1].any() and not sim.get_ctrl()[1].any()
+    assert np.array_equal(o.get_state()["qpos"], model_it1.qpos0) and np.isfinite(s1["qpos"][0]).all()
+    sim.step(20)                                                   # the scene keeps running from qpos0, like the oracle's
+    o.step(20)
+    s2 = sim.get_state()
+    assert np.isfinite(s2["qpos"]).all() and np.abs(s2["qpos"][1] - o.get_state()["qpos"]).max() < 1e-9 and o.bad_state_resets == 1
+    assert sim.counters()["status"][1] & 2                        # sticky until the next reset
+    sim.reset([20, 21], 1, 0.0)
+    assert sim.counters()["status"][1] == 0
 
 
 def test_random_agent_attempts_take_the_same_exits_as_the_oracle(model_it1, emul_lib):

@@ -96,9 +96,12 @@ def test_reset_dev_matches_host_reset_and_leaves_unflagged_scenes_alone(model_it
     a, b = BatchSim(model_it1, n, lib_path=emul_lib), BatchSim(model_it1, n, lib_path=emul_lib)
     seeds = (20 + np.arange(n)).astype(np.uint64)
     a.reset(seeds + np.uint64(100), 1, 40.0)                      # the controller's PID state persists across resets: same history
-    a.reset(seeds, 1, 40.0)
     b.reset(seeds + np.uint64(100), 1, 40.0)
-    before = b.get_state()
+    b.move_group(1 << 6, [0.1], 0.05, 30)                         # so that last_movement_steps is not 0 before the reset
+    a.move_group(1 << 6, [0.1], 0.05, 30)
+    a.reset(seeds, 1, 40.0)
+    before, cb = b.get_state(), b.counters()
+    assert cb["last_steps"][1] > 0
     mask = np.array([1, 0, 1, 1], dtype=np.uint8)
     b.reset_dev(seeds.ctypes.data, mask.ctypes.data, 40.0)        # emulation build: "device" pointers are host pointers
     b.sync()
@@ -106,6 +109,8 @@ def test_reset_dev_matches_host_reset_and_leaves_unflagged_scenes_alone(model_it
     for k in ("qpos", "qvel", "warmstart"):
         assert np.array_equal(sa[k][mask == 1], sb[k][mask == 1]), k
         assert np.array_equal(before[k][1], sb[k][1]), k
+    ca = b.counters()                                             # an unflagged scene keeps its whole record, counters included
+    assert ca["last_steps"][1] == cb["last_steps"][1] and ca["total_steps"][1] == cb["total_steps"][1]
 
 
 def test_host_step_skip_uses_the_kernel_early_out(model_it1, emul_lib):
@@ -138,15 +143,24 @@ def test_attempt_plus_reset_in_one_launch_equals_two_calls(model_it1, emul_lib):
         sim = BatchSim(model_it1, n, lib_path=emul_lib)
         sim.reset(seeds0, 1, 60.0)
         rew = np.zeros(n, dtype=np.int32)
+        st = sim.get_state()
+        st["qvel"][0, 2] = np.nan                                 # scene 0 blows up in its first step: flagged (status bit 2), then reset by its new seed
+        st["qvel"][1, 2] = np.nan                                 # scene 1 too, but it is not reset: its flag must survive the launch
+        sim.set_state(qvel=st["qvel"])
         if fused:
-            sim.set_order_dev(order.ctypes.data)
+            tmp = order.copy()
+            sim.set_order_dev(tmp.ctypes.data)
+            tmp[:] = -7                                           # the handle keeps its own copy: the caller's buffer may die after the call
+            del tmp
             sim.grasp_attempt_reset_dev(act.ctypes.data, rew.ctypes.data, new_seeds.ctypes.data, check_mode=1, settle_ms=60.0)
         else:
             sim.grasp_attempt_dev(act.ctypes.data, rew.ctypes.data, check_mode=1)
             mask = (new_seeds != 0).astype(np.uint8)
             sim.reset_dev(new_seeds.ctypes.data, mask.ctypes.data, 60.0)
         sim.sync()
-        out.append((rew.copy(), sim.get_state(), sim.counters()["total_steps"].copy()))
+        out.append((rew.copy(), sim.get_state(), sim.counters()["total_steps"].copy(), sim.counters()["status"].copy()))
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][2], out[1][2])
+    # status bits are sticky until a reset -- the fused reset (script state 19) clears them exactly like ur5_reset_dev
+    assert out[0][3].tolist() == out[1][3].tolist() == [0, 2, 0]
     for k in out[0][1]:
         assert np.array_equal(out[0][1][k], out[1][1][k]), k

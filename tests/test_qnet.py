@@ -112,3 +112,57 @@ def test_learn_step_equals_the_reference_on_gpu():
     g, loss, q, s, a = _learn_step("cuda")
     assert abs(loss - g["loss"]) < 1e-3 and np.allclose(q, g["q_pred"], atol=1e-3)
     assert abs(s - g["after_sum"]) < 1e-2 * abs(g["after_sum"]) and abs(a - g["after_abs_sum"]) < 1e-2 * g["after_abs_sum"]
+
+
+def _learn_sequence(device, per_round):
+    """The golden stream of tools/gen_golden_qnet.py ("learn_sequence": the REFERENCE's ReplayBuffer + network, one push and one learn() per
+    transition, Grasping_Agent_multidiscrete.py:551-556) fed to Learner.push_and_learn in rounds of `per_round` transitions."""
+    from mujoco_rl_ur5_amd.agent import Learner
+    g = GOLD["learn_sequence"]
+    n, hs = g["n"], g["size"]
+    torch.manual_seed(0)
+    net = qnet.MULTIDISCRETE_RESNET(6).train().to(device)
+    gen = torch.Generator().manual_seed(4)
+    rgb = torch.randint(0, 256, (n, 3, hs, hs), generator=gen).float() / 255.0
+    dep = torch.rand(n, 1, hs, hs, generator=gen)
+    states = torch.cat((rgb, dep), dim=1).to(device)
+    actions = torch.randint(0, 6 * hs * hs, (n, 1), generator=gen).to(device)
+    rewards = torch.randint(0, 2, (n, 1), generator=gen).to(device)
+    lr = Learner(net, hs, hs, device, mem_size=g["mem"], transitions_per_update=1, max_updates_per_round=10 ** 6)
+    losses, ratios = [], []
+    for i0 in range(0, n, per_round):
+        ls, utd = lr.push_and_learn(states[i0:i0 + per_round], actions[i0:i0 + per_round], rewards[i0:i0 + per_round])
+        losses += ls
+        ratios.append(utd)
+    net.eval()
+    with torch.no_grad():
+        y = net(states[:2])
+    return g, losses, ratios, float(y.double().sum()), float(y.double().abs().sum())
+
+
+@pytest.mark.parametrize("per_round", [1, 6, 36])
+def test_batched_push_and_learn_reproduces_the_reference_s_cadence(per_round):
+    """N pushes + N optimiser steps of a batched round == N sequential push / learn() pairs of the reference (update-to-data ratio 1), whatever
+    the round size: same sampled batches (python `random` seeded 20, newest transition always in), same losses, same weights afterwards."""
+    g, losses, ratios, s, a = _learn_sequence("cpu", per_round)
+    assert len(losses) == len(g["losses"]) == g["n"] - 23 and np.allclose(losses, g["losses"], rtol=2e-4, atol=1e-6)
+    assert abs(s - g["after_sum"]) < 1e-3 * abs(g["after_sum"]) and abs(a - g["after_abs_sum"]) < 1e-3 * g["after_abs_sum"]
+    # every transition pushed once the buffer holds 2 * BATCH_SIZE was followed by a step (13 of the 36; the last rounds run at ratio 1)
+    assert ratios[-1] == (1.0 if per_round < 36 else 13 / 36)
+
+
+def test_update_cap_spreads_the_steps_over_the_round():
+    from mujoco_rl_ur5_amd.agent import Learner
+    net = qnet.MULTIDISCRETE_RESNET(6)
+    lr = Learner(net, 8, 8, "cpu", mem_size=64, max_updates_per_round=4)
+    x = torch.rand(40, 4, 8, 8)
+    ls, utd = lr.push_and_learn(x, torch.zeros(40, 1, dtype=torch.long), torch.zeros(40, 1))
+    # 40 transitions, at most 4 steps: chunks of 10; the first two chunks are below 2 * BATCH_SIZE stored transitions (:396-398)
+    assert len(ls) == 2 and utd == 2 / 40 and len(lr.memory) == 40 and lr.updates_done == 2
+
+
+@pytest.mark.gpu
+def test_batched_push_and_learn_reproduces_the_reference_s_cadence_on_gpu():
+    g, losses, ratios, s, a = _learn_sequence("cuda", 12)
+    assert len(losses) == len(g["losses"]) and np.allclose(losses, g["losses"], rtol=2e-2, atol=1e-3)
+    assert abs(s - g["after_sum"]) < 3e-2 * abs(g["after_sum"]) and abs(a - g["after_abs_sum"]) < 3e-2 * g["after_abs_sum"]

@@ -16,6 +16,33 @@ def test_shard_ranges_and_seeds():
     assert np.array_equal(s, 20 + np.arange(16, dtype=np.uint64))
 
 
+def test_graspenv_shards_reproduce_the_unsharded_env_over_two_episodes(emul_lib, model_it1):
+    """Seeds are keyed by GLOBAL scene id and episode with the GLOBAL scene count as episode stride (sharding.global_seeds): two GraspEnv shards
+    (first_scene_id 0 / 2 of n_total 4) reset to exactly the scenes of one 4-scene env, episode after episode; a per-rank stride (round-2
+    default: first_scene_id + n_envs) made rank 0's episode 1 equal rank 1's episode 0."""
+    from mujoco_rl_ur5_amd.envs import GraspEnv
+    from mujoco_rl_ur5_amd.agent import BatchedGraspAgent
+    kw = dict(file=model_it1, show_obs=False, observation="flat", _lib_path=emul_lib)
+    full = GraspEnv(n_envs=4, **kw)
+    parts = [GraspEnv(n_envs=2, first_scene_id=2 * r, n_total=4, **kw) for r in range(2)]
+    seen = []
+    for ep in range(2):
+        full.reset()
+        q = full.sim.get_state()["qpos"]
+        for r, p in enumerate(parts):
+            p.reset()
+            assert np.array_equal(p.sim.get_state()["qpos"], q[2 * r:2 * r + 2]), (ep, r)
+            assert np.array_equal(p.episode_seeds(ep), sharding.global_seeds(20, 4, r, 2, episode=ep))
+        seen.append(q[:, 8:10].copy())
+    assert not np.array_equal(seen[0][2:], seen[1][:2])                       # episode 1 of scenes 0-1 is not episode 0 of scenes 2-3
+    with pytest.raises(ValueError):
+        GraspEnv(n_envs=2, first_scene_id=2, **kw)                            # a shard must be told the global scene count
+    with pytest.raises(ValueError):
+        GraspEnv(n_envs=2, first_scene_id=3, n_total=4, **kw)
+    import inspect
+    assert "n_total" in inspect.signature(BatchedGraspAgent.__init__).parameters
+
+
 def _worker(rank, world, port, emul_lib, out):
     import torch.distributed as dist
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -68,6 +68,36 @@ with torch.no_grad():
     y2 = net(state[:2])
 out["learn_step"] = {"loss": float(loss), "q_pred": [float(v) for v in q_pred.detach().reshape(-1)],
                      "after_sum": float(y2.double().sum()), "after_abs_sum": float(y2.double().abs().sum())}
+# the reference's learning CADENCE on a fixed transition stream (Grasping_Agent_multidiscrete.py:551-556: memory.push of ONE transition, then learn()):
+# the reference's own ReplayBuffer (python `random` seeded with 20 in its constructor, the newest transition always in the batch) and network;
+# learn() starts once 2 * BATCH_SIZE transitions are stored (:396-398). rgb values are multiples of 1/255 (what ToTensor of a uint8 image gives).
+torch.manual_seed(0)
+net = R.MULTIDISCRETE_RESNET(6).train()
+opt = torch.optim.Adam(net.parameters(), lr=0.001, weight_decay=0.00002)
+g = torch.Generator().manual_seed(4)
+NSEQ, HS = 36, 24
+rgb = torch.randint(0, 256, (NSEQ, 3, HS, HS), generator=g).float() / 255.0
+dep = torch.rand(NSEQ, 1, HS, HS, generator=g)
+states = torch.cat((rgb, dep), dim=1)
+actions = torch.randint(0, 6 * HS * HS, (NSEQ, 1), generator=g)
+rewards = torch.randint(0, 2, (NSEQ, 1), generator=g)
+buf = R.ReplayBuffer(30, simple=True)            # smaller than the stream: the ring wraps
+seq_losses = []
+for i in range(NSEQ):
+    buf.push(states[i:i + 1], actions[i:i + 1], rewards[i:i + 1])
+    if len(buf) < 24:
+        continue
+    batch = R.simple_Transition(*zip(*buf.sample(12)))
+    q_pred = net(torch.cat(batch.state)).view(12, -1).gather(1, torch.cat(batch.action))
+    loss = F.binary_cross_entropy(q_pred, torch.cat(batch.reward).float())
+    loss.backward()
+    opt.step()
+    opt.zero_grad()
+    seq_losses.append(float(loss))
+net.eval()
+with torch.no_grad():
+    y3 = net(states[:2])
+out["learn_sequence"] = {"n": NSEQ, "size": HS, "mem": 30, "losses": seq_losses, "after_sum": float(y3.double().sum()), "after_abs_sum": float(y3.double().abs().sum())}
 with open(os.path.join(ROOT, "tests", "golden", "qnet_reference.json"), "w") as f:
     json.dump(out, f, indent=1)
 print({k: (v.get("n_params"), v.get("out_shape")) for k, v in out.items() if "keys" in v})

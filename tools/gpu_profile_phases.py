@@ -36,8 +36,10 @@ rew, ps, pr = sim.grasp_attempt(acts, rot=0, check_mode=0, table_height=0.89 if 
 c1 = sim.counters(); p = read(); steps = (c1["total_steps"] - c0["total_steps"]).astype(float)
 print("grasp: kernel %.1f ms, mean %d steps/env, success %.2f" % (sim.last_launch_ms(), steps.mean(), rew.mean()))
 for k, nm in enumerate(NAMES): print("  %-12s %10.0f" % (nm, (p[:, k] / steps).mean()))
-print("  sub-intervals x0..x7 (cycles/step): %s" % (p[:, 18:26] / steps[:, None]).mean(0).round(0).tolist())
-print("  %-12s %10.0f  (%s; kernel %.2f ms)" % ("sum", (p[:, :16].sum(1) / steps).mean() + (p[:, 18:26].sum(1) / steps).mean(), life(p), sim.last_launch_ms()))
+print("  sub-intervals x0..x6 (cycles/step): %s" % (p[:, 18:25] / steps[:, None]).mean(0).round(0).tolist())
+npairs = np.floor(p[:, 25]); nverts = (p[:, 25] - npairs) * 1e9     # profile build: S.prof[PF_X7] += 1 + 1e-9 * (hull vertices of the pair) per cooperative MPR pair
+if not MANY: print("  cooperative MPR: %.3f pairs per step, %.1f hull vertices per pair (one support call scans that many)" % ((npairs / steps).mean(), nverts.sum() / max(npairs.sum(), 1)))
+print("  %-12s %10.0f  (%s; kernel %.2f ms)" % ("sum", (p[:, :16].sum(1) / steps).mean() + (p[:, 18:25].sum(1) / steps).mean(), life(p), sim.last_launch_ms()))
 lt = (p[:, 17] - p[:, 16]) / 1e5
 print("  lifetime percentiles (ms) 10/50/90/99/max: %s; steps 10/50/90/max: %s; us per step 10/50/90/max: %s" % (
     np.percentile(lt, [10, 50, 90, 99, 100]).round(1).tolist(), np.percentile(steps, [10, 50, 90, 100]).tolist(),
