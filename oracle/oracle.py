@@ -40,6 +40,8 @@ def lib():
             getattr(L, f).argtypes = [vp]
             getattr(L, f).restype = C.c_long
         L.ur5o_set_options.argtypes = [vp, C.c_int, C.c_double, C.c_int]
+        L.ur5o_set_solver_limits.argtypes = [vp, C.c_int, C.c_double]
+        L.ur5o_primal_cost.argtypes = [vp, dp, dp, dp]
         L.ur5o_get_state.argtypes = [vp, dp, dp, dp, dp]
         L.ur5o_set_state.argtypes = [vp, dp, dp, dp, dp]
         L.ur5o_set_ctrl.argtypes = [vp, dp]
@@ -111,6 +113,17 @@ class Oracle:
     def set_options(self, contacts_enabled=1, pid_dt=0.0, solver=0):
         """solver: 0 = Newton (default), 1 = PGS."""
         lib().ur5o_set_options(self._h, contacts_enabled, pid_dt, solver)
+
+    def set_solver_limits(self, iterations=0, tolerance=-1.0):
+        """Override the model's solver iteration cap / tolerance (0 / negative: the model's own)."""
+        lib().ur5o_set_solver_limits(self._h, int(iterations), float(tolerance))
+
+    def primal_cost(self, qacc):
+        """(cost, |gradient|) of the constraint QP of the last forward() at the acceleration `qacc`."""
+        x = np.ascontiguousarray(qacc, dtype=np.float64)
+        c, g = C.c_double(0), C.c_double(0)
+        lib().ur5o_primal_cost(self._h, _dp(x), C.byref(c), C.byref(g))
+        return c.value, g.value
 
     def get_state(self):
         qpos, qvel, warm, pid = np.zeros(self.nq), np.zeros(self.nv), np.zeros(self.nv), np.zeros((self.nu, 4))

@@ -1224,7 +1224,7 @@ struct Sim {
     double cost = std::min(cw, cs);
     double scale = 1.0 / (M.meaninertia * std::max(1, nv));
     newton_direction();
-    for (int it = 0; it < M.iterations; it++) {
+    for (int it = 0; it < solver_iterations(); it++) {
       // exact line search on phi(alpha) = cost(qacc + alpha * search)
       matvecM(nsearch, nMv);
       for (size_t i = 0; i < ne; i++) {
@@ -1276,13 +1276,18 @@ struct Sim {
       double gn = 0;
       for (int i = 0; i < nv; i++) gn += ngrad[i] * ngrad[i];
       double gradient = scale * std::sqrt(gn);
-      if (improvement < M.tolerance || gradient < M.tolerance) break;
+      if (improvement < solver_tolerance() || gradient < solver_tolerance()) break;
     }
     for (size_t i = 0; i < ne; i++) rows[i].force = (!rows[i].unilateral || njar[i] < 0) ? -rows[i].D * njar[i] : 0.0;
     solver_iter_total += solver_iter_last;
   }
 
   int solver = 0;  // 0 = Newton (reference default [3P]), 1 = PGS (kept for comparison; north_star names it)
+  // test hook (ur5o_set_solver_limits): run a solver past the model's iteration cap / tolerance, e.g. PGS to convergence for the solver cross-check
+  int iter_override = 0;
+  double tol_override = -1;
+  int solver_iterations() const { return iter_override > 0 ? iter_override : M.iterations; }
+  double solver_tolerance() const { return tol_override >= 0 ? tol_override : M.tolerance; }
   void solve_constraints() {
     qacc = qacc_smooth;
     solver_iter_last = 0;
@@ -1306,7 +1311,7 @@ struct Sim {
     if (cost > 0) { for (auto& r : rows) r.force = 0; }
     else { for (int d = 0; d < nv; d++) qacc[d] += dq[d]; }
     double scale = 1.0 / (M.meaninertia * std::max(1, nv));
-    for (int it = 0; it < M.iterations; it++) {
+    for (int it = 0; it < solver_iterations(); it++) {
       double improvement = 0;
       for (int ri : order) {
         Row& r = rows[ri];
@@ -1322,7 +1327,7 @@ struct Sim {
         }
       }
       solver_iter_last = it + 1;
-      if (improvement * scale < M.tolerance) break;
+      if (improvement * scale < solver_tolerance()) break;
     }
     solver_iter_total += solver_iter_last;
   }
@@ -1746,6 +1751,23 @@ void ur5o_set_options(void* h, int contacts_enabled, double pid_dt, int solver) 
   s->solver = solver;
   if (pid_dt > 0) s->pid_dt = pid_dt;
 }
+// test hook: the primal objective of the constraint QP (what both solvers minimise) at an arbitrary acceleration, and the norm of its gradient there,
+// for the rows of the last forward() -- the solver cross-check compares solutions by their cost, which is the convergence measure of a convex problem
+void ur5o_primal_cost(void* h, const double* qacc, double* cost, double* gradnorm) {
+  Sim* s = (Sim*)h;
+  std::vector<double> x(qacc, qacc + s->nv), Ma(s->nv), g(s->nv);
+  s->matvecM(x, Ma);
+  *cost = s->primal_cost(x, Ma);
+  for (int i = 0; i < s->nv; i++) g[i] = Ma[i] - s->qfrc_smooth[i];
+  for (const Row& r : s->rows) {
+    double jar = s->row_jar(r, x);
+    if (!r.unilateral || jar < 0) for (size_t k = 0; k < r.idx.size(); k++) g[r.idx[k]] += r.D * jar * r.J[k];
+  }
+  double n = 0;
+  for (double v : g) n += v * v;
+  *gradnorm = std::sqrt(n);
+}
+void ur5o_set_solver_limits(void* h, int iterations, double tolerance) { ((Sim*)h)->iter_override = iterations; ((Sim*)h)->tol_override = tolerance; }
 void ur5o_get_state(void* h, double* qpos, double* qvel, double* warm, double* pidstate) {
   Sim* s = (Sim*)h;
   if (qpos) memcpy(qpos, s->qpos.data(), 8 * s->nq);

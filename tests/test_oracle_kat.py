@@ -230,3 +230,31 @@ def test_depth_statistics_match_the_references_mean_and_std(model_2f):
         ds.append(o.render(cam, 200, 200, 0)[1])
     d = np.array(ds, dtype=np.float64)
     assert abs(d.mean() - ref["mean"][3]) < 0.004 and abs(d.std() - ref["std"][3]) < 0.004, (d.mean(), d.std(), ref)
+
+
+def test_newton_is_at_the_optimum_of_multi_contact_grasp_states_and_pgs_converges_towards_it():
+    """Solver cross-check on the states that decide the reward bit (fingers closed on a box, lifting, carrying; 11-19 contacts, ~100 rows): the
+    constraint QP is strictly convex, so a zero gradient identifies THE solution -- Newton's has |grad| <= 1e-9 --, and projected Gauss-Seidel, which
+    shares only the row construction, stays above Newton's cost and approaches it as its sweeps grow (tools/solver_crosscheck.py runs 72 states up
+    to 1e6 sweeps: profiles/r03_solver_crosscheck.json)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("solver_crosscheck", os.path.join(os.path.dirname(__file__), "..", "tools", "solver_crosscheck.py"))
+    sc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sc)
+    m, states = sc.grasp_states("it1_4box", 21, 3)
+    assert len(states) == 3
+    for tag, qpos, qvel, warm, pid, ctrl in states:
+        def solve(solver, iters, tol):
+            o = Oracle(m)
+            o.set_options(1, 0.0, solver)
+            o.set_solver_limits(iters, tol)
+            o.set_state(qpos=qpos, qvel=qvel, warmstart=warm, pid=pid)
+            o.set_ctrl(ctrl)
+            o.forward()
+            x = o.vec("qacc")
+            return x, *o.primal_cost(x), len(o.contacts())
+        xn, cn, gn, ncon = solve(0, 0, -1.0)
+        assert ncon >= 8 and gn <= 1e-9 * max(1.0, abs(cn)), (tag, ncon, gn)
+        x1, c1, _, _ = solve(1, 100, 0.0)
+        x2, c2, _, _ = solve(1, 20000, 0.0)
+        assert c1 >= c2 - 1e-6 >= cn - 2e-6 and np.abs(x2 - xn).max() <= np.abs(x1 - xn).max() + 1e-9, (tag, c1 - cn, c2 - cn)
