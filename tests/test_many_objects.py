@@ -5,6 +5,9 @@ Parity horizon: piles of cylinders / capsules resting on single MPR contacts are
 its 1e-6 tolerance (a 1e-14 state difference can flip a portal step and move a normal by 5e-3), so trajectories are compared
 over the first contacts of the drop (tens of steps, 1e-9) and statistically afterwards.
 """
+import os
+import sys
+
 import numpy as np
 import pytest
 
@@ -290,20 +293,25 @@ def test_settled_pile_forward_parity_on_gpu(model_many):
 @pytest.mark.gpu
 def test_pile_grasp_bits_against_the_oracle_on_gpu(model_many):
     """Grasp attempts on settled piles: the HIP kernel and the oracle start from the SAME settled state (the kernel's), run one full
-    move_and_grasp script each, and must agree on the reward bit and the script's result codes. 12 scenes here (oracle threads in
-    parallel); tools/gpu_many_agreement.py runs the >= 128-scene statistic kept under profiles/."""
+    move_and_grasp script each, and must agree on the reward bit and the script's result codes. The 12 scenes are the ones of a 96-pile pool
+    whose best box (tools/pile_aim.py: level top face, sides parallel to the fingers) scores lowest, so that the statistic HAS positives -- with
+    the round-2 rule (any object, rotation e % 6) 2 % of the attempts succeeded and all-zeros on both sides passed. tools/gpu_many_agreement.py
+    runs the 256-of-3072-scene statistic kept under profiles/ (28 % positives, 97 % agreement, 96 % of the oracle's positives reproduced)."""
     from concurrent.futures import ThreadPoolExecutor
-    n = 12
-    sim = BatchSim(model_many, n)
-    sim.reset(500 + np.arange(n, dtype=np.uint64), 1, 1000.0)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    from pile_aim import pick_box
+    pool, n = 96, 12
+    sim = BatchSim(model_many, pool)
+    sim.reset(500 + np.arange(pool, dtype=np.uint64), 1, 1000.0)
     st = sim.get_state()
     ctrl = sim.get_ctrl()
-    xpos = sim.body_xpos()[:, 8:48]
-    acts, rots = np.zeros((n, 3)), np.arange(n) % 6
-    for e in range(n):
-        inbin = np.where((np.abs(xpos[e][:, 0]) < 0.2) & (np.abs(xpos[e][:, 1] + 0.6) < 0.13) & (xpos[e][:, 2] > 0.85))[0]
-        k = inbin[e % len(inbin)]
-        acts[e] = [xpos[e][k, 0], xpos[e][k, 1], xpos[e][k, 2] + 0.02]
+    picks = [pick_box(model_many, st["qpos"][e]) for e in range(pool)]
+    sel = sorted([e for e in range(pool) if picks[e] is not None], key=lambda e: picks[e][3])[:n]
+    assert len(sel) == n and picks[sel[-1]][3] < 25
+    acts, rots = np.zeros((pool, 3)), np.zeros(pool, dtype=np.int64)
+    acts[:] = [0.0, -0.6, 1.0]
+    for e in sel:
+        acts[e], rots[e] = picks[e][1], picks[e][2]
     rew, ps, pr = sim.grasp_attempt(acts, rot=rots, check_mode=0)
     assert sim.counters()["status"].max() == 0
 
@@ -314,10 +322,12 @@ def test_pile_grasp_bits_against_the_oracle_on_gpu(model_many):
         r, pso, pro = o.grasp_attempt(acts[e], int(rots[e]), 0)
         return r, pro
     with ThreadPoolExecutor(max_workers=n) as ex:
-        res = list(ex.map(one, range(n)))
-    bits = sum(int(r == rew[e]) for e, (r, _) in enumerate(res))
-    codes = sum(int(pro.tolist() == pr[e].tolist()) for e, (_, pro) in enumerate(res))
-    assert bits >= n - 1 and codes >= n - 2, (bits, codes, rew.tolist(), [r for r, _ in res])   # piles are chaotic: one flip tolerated
+        res = list(ex.map(one, sel))
+    orew = [r for r, _ in res]
+    bits = sum(int(r == rew[e]) for e, (r, _) in zip(sel, res))
+    codes = sum(int(pro.tolist() == pr[e].tolist()) for e, (_, pro) in zip(sel, res))
+    assert sum(orew) >= 2, orew                                               # a statistic with positives
+    assert bits >= n - 1 and codes >= n - 2, (bits, codes, rew[sel].tolist(), orew)   # piles are chaotic: one flip tolerated
 
 
 # ------------------------------------------------------------------ arm-link collision hulls

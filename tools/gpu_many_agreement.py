@@ -15,6 +15,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from mujoco_rl_ur5_amd.model import load_model
 from mujoco_rl_ur5_amd.native import BatchSim
 from oracle.oracle import Oracle
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from pile_aim import pick_box
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 threads = int(sys.argv[2]) if len(sys.argv) > 2 else min(n, os.cpu_count() or 8)
@@ -28,50 +30,15 @@ xpos = sim.body_xpos()[:, 8:48]
 acts, rots = np.zeros((n, 3)), np.arange(n) % 6
 
 
-def quat_mat(q):
-    w, x, y, z = q
-    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
-                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
-
-
-def pick_box(e):
-    """(object index, top-face height, rotation index, score) of the best box of scene e, or None"""
-    best = None
-    P = st["qpos"][e][8:].reshape(-1, 7)
-    geom0 = m.ngeom - 40
-    for k in range(40):
-        if m.geom_type[geom0 + k] != 6:
-            continue
-        c, R, half = P[k, :3], quat_mat(P[k, 3:7]), m.geom_size[geom0 + k]
-        if not (abs(c[0]) < 0.17 and abs(c[1] + 0.6) < 0.10 and c[2] > 0.89):
-            continue                                                            # inside the bin, away from its walls
-        a = int(np.argmax(np.abs(R[2])))
-        tilt = np.degrees(np.arccos(min(1.0, abs(R[2, a]))))
-        b = (a + 1) % 3
-        yaw = np.degrees(np.arctan2(R[1, b], R[0, b]))
-        want = -yaw                                                             # fingers parallel to the box's sides (oracle probe: yaw 30 <-> wrist -30)
-        cand = {0: 0.0, 1: 30.0, 4: -30.0}
-        mis = {r: abs(((want - ang + 45) % 90) - 45) for r, ang in cand.items()}
-        r = min(mis, key=mis.get)
-        d = P[:, :3] - c
-        on_top = np.any((np.hypot(d[:, 0], d[:, 1]) < 0.05) & (d[:, 2] > 0.01) & (np.arange(40) != k))
-        score = tilt + mis[r] + (100.0 if on_top else 0.0)
-        if best is None or score < best[3]:
-            best = (k, c[2] + half[a] * abs(R[2, a]), r, score)
-    return best
-
-
 scores = np.full(n, np.nan)
 for e in range(n):
     inbin = np.where((np.abs(xpos[e][:, 0]) < 0.2) & (np.abs(xpos[e][:, 1] + 0.6) < 0.13) & (xpos[e][:, 2] > 0.85))[0]
     k = inbin[e % len(inbin)]
     acts[e] = [xpos[e][k, 0], xpos[e][k, 1], xpos[e][k, 2] + 0.02]
     if rule == "boxes":
-        b = pick_box(e)
+        b = pick_box(m, st["qpos"][e])
         if b is not None:
-            acts[e] = [xpos[e][b[0], 0], xpos[e][b[0], 1], b[1]]
-            rots[e] = b[2]
-            scores[e] = b[3]
+            acts[e], rots[e], scores[e] = b[1], b[2], b[3]
 rew, ps, pr = sim.grasp_attempt(acts, rot=rots, check_mode=0)
 kernel_ms = sim.last_launch_ms()
 s2 = sim.get_state()["qpos"]
