@@ -45,17 +45,31 @@ BASE_SEED = 20  # Grasping_Agent_multidiscrete.py:64
 
 
 class It1Rounds:
-    """Device-side driver of the stationary IT1 workload for one rank: flags / seeds of the scenes that reset, action records."""
+    """Device-side driver of the stationary workloads for one rank: flags / seeds of the scenes that reset, action records.
+    kind "it1" (headline, BASELINE configs[1]): physics only, fixed z = 0.91, IT1 closing check (check_mode 1).
+    kind "it4" (configs[2]): every round renders the 200x200 RGB-D observation; the grasp height is the rendered depth under the aimed pixel
+    (GraspEnv.step, GraspingEnv.py:100-104); in-tree script (check_mode 0). kind "many" (configs[3]): the same on 40-object piles, aimed by the
+    box rule of tools/pile_aim.py evaluated on the device (the box with the most level top face whose sides are parallel to the fingers)."""
 
-    def __init__(self, torch, model, sim, dev, lo, n_local, n_total, rule):
+    def __init__(self, torch, model, sim, dev, lo, n_local, n_total, rule, kind="it1"):
         from mujoco_rl_ur5_amd.controller import MJ_Controller
-        self.torch, self.sim, self.rule, self.n, self.n_total = torch, sim, rule, n_local, n_total
+        self.torch, self.sim, self.rule, self.n, self.n_total, self.kind = torch, sim, rule, n_local, n_total, kind
         self.gid = torch.arange(lo, lo + n_local, dtype=torch.int64, device=dev)
-        self.state = sim.state_tensor(dev)                                        # [n, 192] f64, aliases the engine's records
-        # objects: 3 slides + ball each (UR5gripper_2_finger.xml:233-239): world position = body_pos + slide offsets
+        self.state = sim.state_tensor(dev)                                        # [n, stride] f64, aliases the engine's records
+        # objects: 3 slides + ball each (UR5gripper_2_finger.xml:233-239): world position = body_pos + slide offsets; free joints hold world coordinates
         self.nobj = (model.nq - 8) // 7
         obj_bodies = [int(model.jnt_bodyid[list(model.jnt_qposadr).index(8 + 7 * k)]) for k in range(self.nobj)]
-        self.pos0 = torch.from_numpy(np.asarray(model.body_pos)[obj_bodies].copy()).to(dev)   # [nobj, 3]
+        free = int(model.jnt_type[list(model.jnt_qposadr).index(8)]) == 0
+        self.pos0 = torch.from_numpy(np.zeros((self.nobj, 3)) if free else np.asarray(model.body_pos)[obj_bodies].copy()).to(dev)   # [nobj, 3]
+        self.cam_id = model.camera_name2id("top_down")
+        self.cam_z = float(model.cam_pos0[self.cam_id][2])
+        if kind != "it1":
+            self.img = torch.zeros((n_local, 200, 200, 3), dtype=torch.uint8, device=dev)
+            self.dep = torch.zeros((n_local, 200, 200), dtype=torch.float32, device=dev)
+        if kind == "many":
+            g0 = model.ngeom - self.nobj
+            self.box_idx = torch.tensor([k for k in range(self.nobj) if int(model.geom_type[g0 + k]) == 6], dtype=torch.int64, device=dev)
+            self.box_half = torch.from_numpy(np.asarray(model.geom_size)[g0:g0 + self.nobj][self.box_idx.cpu().numpy()].copy()).to(dev)   # [nb, 3]
         # pinhole of the top-down camera at table height (MujocoController.py:742-806): world (x, y) <-> pixel is affine at fixed z
         ctl = MJ_Controller(model, sim, None)
         z_t = 0.91
@@ -81,12 +95,19 @@ class It1Rounds:
         seeds = BASE_SEED + self.gid + self.n_total * (k // EP)                  # == sharding.global_seeds(20, n_total, ..., episode)
         return self.torch.where((k % EP) == 0, seeds, self.torch.zeros_like(seeds))
 
-    def launch(self, r, reward_row, check_mode=1):
-        """One round on the engine's stream: action records from the current state, longest-expected-first dispatch order, ONE launch of
-        attempt (+ episode reset). Returns (action records [n, 8], aimed pixel [n])."""
+    def launch(self, r, reward_row, check_mode=None):
+        """One round on the engine's stream: (observation,) action records from the current state, longest-expected-first dispatch order, ONE
+        launch of attempt (+ episode reset). Returns (action records [n, 8], aimed pixel [n])."""
         torch = self.torch
+        if check_mode is None:
+            check_mode = 1 if self.kind == "it1" else 0
         seeds = self.reset_seeds(r)
+        if self.kind != "it1":
+            self.sim.render_dev(self.img.data_ptr(), self.dep.data_ptr(), self.cam_id, 200, 200, 0)   # get_observation (GraspingEnv.py:390-406), metric depth
         act, pixel, any_on = self.actions(r)
+        if self.kind != "it1":                                                   # top-down camera: world z of what the aimed pixel shows (GraspingEnv.py:100-104)
+            px = pixel.long()
+            act[:, 2] = self.cam_z - self.dep[torch.arange(self.n, device=px.device), px // 200, px % 200].double()
         est = torch.where(any_on, 2300, 1300) + torch.where(seeds != 0, 500, 0)   # expected physics steps of the scene in this launch
         order = torch.argsort(est, descending=True, stable=True).to(torch.int32)
         self.sim.set_order_dev(order.data_ptr())
@@ -101,7 +122,11 @@ class It1Rounds:
         torch = self.torch
         a = torch.zeros((self.n, 8), dtype=torch.float64, device=self.gid.device)
         a[:, 2] = 0.91
-        if self.rule == "aimed":
+        if self.rule == "aimed" and self.kind == "many":
+            xy, rot, any_on = self.pile_box_actions(r)
+            a[:, :2] = xy
+            a[:, 3] = rot.double()
+        elif self.rule == "aimed":
             q = self.state[:, 8:8 + 7 * self.nobj].view(self.n, self.nobj, 7)[:, :, :3] + self.pos0      # [n, nobj, 3] world
             on = (q[:, :, 0].abs() <= 0.27) & ((q[:, :, 1] + 0.6).abs() <= 0.19) & (q[:, :, 2] >= 0.905) & (q[:, :, 2] <= 1.0)
             j = (self.gid + r) % EP
@@ -124,93 +149,214 @@ class It1Rounds:
         return a, (py * 200 + px).to(torch.int32), any_on
 
 
-def cpu_baseline(model, budget_s=12.0, many=False):
+    def pile_box_actions(self, r):
+        """tools/pile_aim.py pick_box for every scene at once, on the device: (xy [n, 2], rotation index [n], a box was found [n]). Scenes without a box
+        in the bin aim at their highest object in the bin (rotation cycling), an empty bin gets an attempt at its centre."""
+        torch = self.torch
+        n, dev = self.n, self.gid.device
+        P = self.state[:, 8:8 + 7 * self.nobj].view(n, self.nobj, 7)
+        c = P[:, :, :3]                                                          # [n, nobj, 3] world (free joints)
+        q = P[:, self.box_idx, 3:7]
+        w, x, y, z = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+        R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y), 2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                         2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], dim=-1).view(n, -1, 3, 3)
+        cb = c[:, self.box_idx]                                                  # [n, nb, 3]
+        cosv, a_ax = R[:, :, 2, :].abs().max(dim=-1)                             # the box axis nearest to the vertical
+        tilt = torch.rad2deg(torch.acos(cosv.clamp(max=1.0)))
+        b_ax = ((a_ax + 1) % 3)[..., None, None].expand(-1, -1, 3, 1)
+        bcol = torch.gather(R, 3, b_ax)[..., 0]                                  # world direction of the next axis: [n, nb, 3]
+        want = -torch.rad2deg(torch.atan2(bcol[..., 1], bcol[..., 0]))           # fingers parallel to the box's sides: wrist angle = -yaw (mod 90)
+        ang = torch.tensor([0.0, 30.0, -30.0], dtype=torch.float64, device=dev)  # rotation indices 0 / 1 / 4 (GraspingEnv.py:40)
+        mis = (torch.remainder(want[..., None] - ang + 45.0, 90.0) - 45.0).abs() # [n, nb, 3]
+        mis_min, which = mis.min(dim=-1)
+        d = c[:, None, :, :] - cb[:, :, None, :]                                 # [n, nb, nobj, 3]
+        other = torch.arange(self.nobj, device=dev)[None, None, :] != self.box_idx[None, :, None]
+        on_top = ((torch.hypot(d[..., 0], d[..., 1]) < 0.05) & (d[..., 2] > 0.01) & other).any(dim=-1)
+        inbin = (cb[..., 0].abs() < 0.17) & ((cb[..., 1] + 0.6).abs() < 0.10) & (cb[..., 2] > 0.89)
+        score = tilt + mis_min + 100.0 * on_top.double() + 1e6 * (~inbin).double()
+        best_score, best = score.min(dim=1)
+        e = torch.arange(n, device=dev)
+        found = best_score < 1e5
+        rot_box = torch.tensor([0, 1, 4], dtype=torch.int64, device=dev)[which[e, best]]
+        # fallback: the highest object inside the bin
+        ib = (c[..., 0].abs() < 0.2) & ((c[..., 1] + 0.6).abs() < 0.13) & (c[..., 2] > 0.85)
+        top = torch.where(ib, c[..., 2], torch.full_like(c[..., 2], -1.0)).argmax(dim=1)
+        any_obj = ib.any(dim=1)
+        centre = torch.tensor([0.0, -0.6], dtype=torch.float64, device=dev)
+        xy_fb = torch.where(any_obj[:, None], c[e, top, :2], centre)
+        xy = torch.where(found[:, None], cb[e, best, :2], xy_fb)
+        rot = torch.where(found, rot_box, (self.gid // EP + r) % 6)
+        return xy, rot, found | any_obj
+
+
+def cpu_baseline(model, budget_s=12.0, kind="it1"):
     """The fp64 oracle (a port: the reference's own MuJoCo binary cannot exist here) on the host cores, SAME workload as the timed GPU
-    rounds: whole episodes of reset + 1000 ms settle + EP aimed grasp attempts (oracle/ur5_oracle.cpp ur5o_batch mode 2, bench_aim),
-    one scene per native thread on every core (SURVEY.md section 8d ii), plus the single-core rate."""
+    rounds: whole episodes of reset + 1000 ms settle + EP aimed grasp attempts (oracle/ur5_oracle.cpp ur5o_batch mode 2 / 3, bench_aim; kind "it4"
+    renders the observation and takes the grasp height from its depth image, like the GPU rounds), one scene per native thread on every core
+    (SURVEY.md section 8d ii), plus the single-core rate. kind "many": one thread per scene does reset + settle + ONE rendered attempt on a
+    40-object pile (a whole episode of a pile is minutes of CPU time; the sample is bounded, its physics steps are the same kind of steps)."""
     from oracle import oracle as O
     cores = os.cpu_count() or 1
-    if many:
-        s1, a1, t1, _, _ = O.batch(model, 1, 0.3 * budget_s, 1, 100)
-        sn, an, tn, _, _ = O.batch(model, cores, 0.7 * budget_s, 1, 100)
+    if kind == "many":
+        sn, an, tn, attn, sucn = O.batch(model, cores, 1.0, 4, 1)                   # every thread finishes the one scene it started within the budget
         return dict(value=sn / tn, unit="env-steps/s", cores=cores, kind="port",
-                    sample=f"the first 100 steps of the 40-object drop of scenes 0..{an - 1} ({sn} physics steps), oracle/ur5_oracle.cpp, "
-                           f"one scene per thread on {cores} threads for {tn:.1f} s wall",
-                    single_core={"value": s1 / t1, "sample": f"{a1} scenes ({s1} steps), {t1:.1f} s on one core"})
-    s1, e1, t1, att1, _ = O.batch(model, 1, 0.3 * budget_s, 2, EP)
-    sn, en, tn, attn, sucn = O.batch(model, cores, 0.7 * budget_s, 2, EP)
+                    sample=f"{an} piles (scenes 0..{an - 1}): reset + 1000 ms settle + one rendered grasp attempt at the highest object of the bin each "
+                           f"({sn} physics steps, {attn} attempts), oracle/ur5_oracle.cpp, one scene per thread on {cores} threads, {tn:.1f} s wall",
+                    grasp_attempts_per_s=attn / tn, grasp_success_rate=sucn / max(1, attn), env_steps_per_attempt=sn / max(1, attn))
+    mode = 2 if kind == "it1" else 3
+    s1, e1, t1, att1, _ = O.batch(model, 1, 0.3 * budget_s, mode, EP)
+    sn, en, tn, attn, sucn = O.batch(model, cores, 0.7 * budget_s, mode, EP)
+    what = "aimed attempts, the timed GPU rule" if kind == "it1" else "aimed attempts with a rendered 200x200 RGB-D observation and depth-derived grasp height each, the timed GPU rule"
     return dict(value=sn / tn, unit="env-steps/s", cores=cores, kind="port",
-                sample=f"{en} whole episodes (scenes 0..{en - 1}: reset + 1000 ms settle + {EP} aimed attempts, the timed GPU rule; {sn} physics "
+                sample=f"{en} whole episodes (scenes 0..{en - 1}: reset + 1000 ms settle + {EP} {what}; {sn} physics "
                        f"steps, {attn} attempts), oracle/ur5_oracle.cpp, one scene per thread on {cores} threads for {tn:.1f} s wall",
                 grasp_attempts_per_s=attn / tn, grasp_success_rate=sucn / max(1, attn), env_steps_per_attempt=sn / max(1, attn),
                 single_core={"value": s1 / t1, "grasp_attempts_per_s": att1 / t1,
                              "sample": f"{e1} episodes ({s1} steps, {att1} attempts), {t1:.1f} s on one core"})
 
 
-def rendered_sub_result(torch, dev, local_rank, workload, n, rounds, warmup):
-    """Short N=1 measurement of the render + grasp-round shape of BASELINE.json configs[2] (it4) / configs[3] (many) so that the driver's
-    one line also times them: `rounds` timed rounds after `warmup`. Every round renders the 200x200 RGB-D observation and aims at the pixel
-    over one of the objects in the pick bin (a different one per round); the grasp height comes from the rendered depth at that pixel
-    (GraspEnv.step, GraspingEnv.py:100-104), on the device."""
+class Job:
+    """The scenes of one rank as G scene groups (one engine handle + one HIP stream each, rounds pipelined across the groups) and the timed-region
+    protocol of the driver contract: barrier + synchronize on both sides, exactly the rounds asked for in between."""
+
+    def __init__(self, torch, dist, sharding, model, kind, rule, n_local, n_total, lo, world, dev, dev_id, G, rows):
+        from mujoco_rl_ur5_amd.native import BatchSim
+        self.torch, self.dist, self.sharding, self.world, self.model, self.kind = torch, dist, sharding, world, model, kind
+        self.G = G if n_local % max(1, G) == 0 else 1
+        self.n_g, self.n_local, self.n_total = n_local // self.G, n_local, n_total
+        job = self
+
+        class Group:
+            """One scene group: engine handle, its HIP stream (torch's, so that action tensors are stream-ordered with the launches)."""
+            def __init__(self, g):
+                self.lo = lo + g * job.n_g
+                self.sim = BatchSim(model, job.n_g, device_id=dev_id)
+                self.sim.reset(BASE_SEED + np.arange(self.lo, self.lo + job.n_g, dtype=np.uint64), 1, 1000.0)   # episode 0 (GraspingEnv.py:409-477), untimed
+                self.stream = torch.cuda.Stream(device=dev) if job.G > 1 else torch.cuda.current_stream()
+                self.sim.set_stream(self.stream.cuda_stream)
+                with torch.cuda.stream(self.stream):
+                    self.wl = It1Rounds(torch, model, self.sim, dev, self.lo, job.n_g, n_total, rule, kind)
+                    self.reward = torch.zeros((rows, job.n_g), dtype=torch.int32, device=dev)
+                    self.ids = torch.arange(self.lo, self.lo + job.n_g, dtype=torch.int32, device=dev)
+        self.groups = [Group(g) for g in range(self.G)]
+        torch.cuda.synchronize()
+
+    def run_rounds(self, r0, r1, wls=None):
+        torch, gathered = self.torch, None
+        for r in range(r0, r1):
+            for k, gr in enumerate(self.groups):
+                with torch.cuda.stream(gr.stream):
+                    wl = gr.wl if wls is None else wls[k]
+                    act, pixel = wl.launch(r, gr.reward[r])                        # (observation +) attempt (+ reset_model for the scenes whose episode ends)
+                    rec = torch.stack([gr.ids, pixel, act[:, 3].to(torch.int32), gr.reward[r]], dim=1)
+                    gathered = self.sharding.gather_outcomes(rec)                  # the path's only collective: 16 B per scene per round
+        return gathered
+
+    def counters(self):
+        cs = [gr.sim.counters() for gr in self.groups]
+        return {k: np.concatenate([c[k] for c in cs]) for k in cs[0]}
+
+    def timed(self, r0, r1, wls=None):
+        torch = self.torch
+        for gr in self.groups:
+            gr.sim.sync()
+        c0, k0 = self.counters(), sum(gr.sim.kernel_ms_total() for gr in self.groups)
+        if self.world > 1:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        g = self.run_rounds(r0, r1, wls)
+        torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+        elapsed = time.perf_counter() - t0
+        for gr in self.groups:
+            gr.sim.sync()                                                          # resolves the HIP event pairs of the region's launches
+        c1, k1 = self.counters(), sum(gr.sim.kernel_ms_total() for gr in self.groups)
+        return elapsed, c0, c1, k1 - k0, g
+
+    def close(self):
+        for gr in self.groups:
+            gr.sim.close()
+
+
+def rendered_sub_result(torch, dist, sharding, dev, dev_id, workload, n, rounds, warmup, with_cpu):
+    """N = 1 measurement of BASELINE.json configs[2] (it4) / configs[3] (many) in the driver's one line, with the headline's machinery: the same
+    stationary episode structure (EP rounds, a quarter of the batch resets per round inside the attempt's launch), every round renders the
+    200x200 RGB-D observation, re-aims ON THE DEVICE from the current state, takes the grasp height from the rendered depth under the aimed pixel
+    (GraspEnv.step, GraspingEnv.py:100-104), dispatches longest-expected-first, two scene groups pipelined; `rounds` timed rounds after `warmup`."""
     from mujoco_rl_ur5_amd.model import load_model
-    from mujoco_rl_ur5_amd.native import BatchSim
     many = workload == "many"
     model = load_model("/UR5+gripper/UR5gripper_2_finger_many_objects.xml" if many else "/UR5+gripper/UR5gripper_2_finger.xml")
-    sim = BatchSim(model, n, device_id=local_rank)
-    sim.reset(BASE_SEED + np.arange(n, dtype=np.uint64), 1, 1000.0)
-    nobj = (model.nv - 8) // 6
-    xpos = sim.body_xpos()[:, 8:8 + nobj]
-    from mujoco_rl_ur5_amd.controller import MJ_Controller
-    ctl = MJ_Controller(model, sim, None)
-    acts = np.zeros((warmup + rounds, n, 8))
-    pix = np.zeros((warmup + rounds, n, 2), dtype=np.int64)
-    for r in range(warmup + rounds):
-        for e in range(n):
-            objs = xpos[e]
-            inbin = np.where((np.abs(objs[:, 0]) < 0.2) & (np.abs(objs[:, 1] + 0.6) < 0.13) & (objs[:, 2] > 0.85))[0]
-            k = inbin[(e + r) % len(inbin)] if len(inbin) else 0
-            px, py = ctl.world_2_pixel(objs[k], 200, 200)                      # the pixel over the object's centre
-            pix[r, e] = [min(max(int(px), 0), 199), min(max(int(py), 0), 199)]
-            acts[r, e, :2] = objs[k, :2]
-            acts[r, e, 3] = (e + r) % 6
-    actions = torch.from_numpy(acts).to(dev)
-    pix_t = torch.from_numpy(pix).to(dev)
-    cam_z = float(model.cam_pos0[model.camera_name2id("top_down")][2])
-    scene = torch.arange(n, device=dev)
-    img = torch.zeros((n, 200, 200, 3), dtype=torch.uint8, device=dev)
-    dep = torch.zeros((n, 200, 200), dtype=torch.float32, device=dev)
-    reward = torch.zeros((warmup + rounds, n), dtype=torch.int32, device=dev)
-    cam = model.camera_name2id("top_down")
-    sim.set_stream(torch.cuda.current_stream().cuda_stream)
+    job = Job(torch, dist, sharding, model, workload, "aimed", n, n, 0, 1, dev, dev_id, 2, warmup + rounds)
+    job.run_rounds(0, warmup)
+    dt, c0, c1, kms, _ = job.timed(warmup, warmup + rounds)
+    steps = int((c1["total_steps"] - c0["total_steps"]).sum())
+    succ = sum(float(gr.reward[warmup:warmup + rounds].sum().item()) for gr in job.groups)
+    words = model.nq + 2 * model.nv + 5 * model.nu + 8
+    out = {"workload": ("BASELINE.json configs[3] shape: 40-object piles (UR5gripper_2_finger_many_objects.xml, condim 6), per round a 200x200 RGB-D render, the "
+                        "box rule of tools/pile_aim.py on the device, depth-derived grasp height, one grasp script; episodes of 4 rounds with reset_model + 1000 ms settle" if many
+                        else "BASELINE.json configs[2] shape: IT4 (in-tree UR5gripper_2_finger.xml, 3 boxes + 3 spheres), per round a 200x200 RGB-D render, device-side "
+                        "re-aim at an object still on the plate, depth-derived grasp height, one grasp script; episodes of 4 rounds with reset_model + 1000 ms settle"),
+           "scenes": n, "rounds": rounds, "warmup": warmup, "scene_groups": job.G, "env_steps_per_s": steps / dt, "grasp_attempts_per_s": rounds * n / dt,
+           "grasp_success_rate": succ / (rounds * n), "env_steps_per_attempt": steps / (rounds * n),
+           "newton_iters_per_step": float((c1["solver_iters"] - c0["solver_iters"]).sum()) / max(1, steps),
+           "status_bits": int(np.bitwise_or.reduce(c1["status"])), "ms_per_round": 1e3 * dt / rounds, "kernel_ms_per_round_and_group": kms / (rounds * job.G),
+           "roofline_frac": steps * 2 * words * 8 / dt / 8e12, "bytes_per_env_step": 2 * words * 8,
+           "kernel": "ur5m_run_kernel<248>" if many else "ur5_run_kernel<44>"}
+    job.close()
+    if with_cpu:
+        out["cpu_baseline"] = cpu_baseline(model, 8.0, workload)
+    return out
 
-    def one(r):
-        sim.render_dev(img.data_ptr(), dep.data_ptr(), cam, 200, 200, 0)            # get_observation (GraspingEnv.py:390-406), metric depth
-        actions[r, :, 2] = cam_z - dep[scene, pix_t[r, :, 1], pix_t[r, :, 0]].double()   # top-down camera: world z of what the pixel shows
-        sim.grasp_attempt_dev(actions[r].data_ptr(), reward[r].data_ptr(), check_mode=0, table_height=0.91)
-    for r in range(warmup):
-        one(r)
-    sim.sync()
-    c0, k0 = sim.counters(), sim.kernel_ms_total()
+
+def dqn_sub_result(torch, dev, dev_id, n, rounds, warmup):
+    """BASELINE.json configs[4] shape on one GPU (the 8-GPU version shards the scenes and all-gathers the 16-byte outcome records,
+    mujoco_rl_ur5_amd/agent.py): per round render -> transform_observation (+ colour jitter) -> pixel-wise grasp-Q CNN forward for every scene
+    (Modules.py MULTIDISCRETE_RESNET, fp32) -> epsilon-greedy action -> grasp script -> replay push + optimiser steps, all device-resident."""
+    from mujoco_rl_ur5_amd.agent import BatchedGraspAgent
+    from mujoco_rl_ur5_amd.envs import GraspEnv
+    env = GraspEnv(n_envs=n, show_obs=False, observation="render", device_id=dev_id)
+    env.reset()
+    agent = BatchedGraspAgent(env=env, device=dev, max_updates_per_round=16)
+    for _ in range(warmup):
+        agent.round()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for r in range(warmup, warmup + rounds):
-        one(r)
-    sim.sync()
+    c0 = env.sim.counters()["total_steps"].sum()
+    u0, t0 = agent.learner.updates_done, time.perf_counter()
+    rew = 0.0
+    for _ in range(rounds):
+        out = agent.round()
+        rew += float(out["reward"].float().mean())
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    c1, k1 = sim.counters(), sim.kernel_ms_total()
-    steps = int((c1["total_steps"] - c0["total_steps"]).sum())
-    words = model.nq + 2 * model.nv + 5 * model.nu + 8
-    out = {"workload": "configs[3] shape: 40-object piles (UR5gripper_2_finger_many_objects.xml, condim 6), 200x200 RGB-D render + grasp script per round" if many
-           else "configs[2] shape: IT4 (in-tree UR5gripper_2_finger.xml, 3 boxes + 3 spheres), 200x200 RGB-D render + grasp script per round",
-           "scenes": n, "rounds": rounds, "warmup": warmup, "env_steps_per_s": steps / dt, "grasp_attempts_per_s": rounds * n / dt,
-           "grasp_success_rate": float(reward[warmup:].sum().item()) / (rounds * n), "env_steps_per_attempt": steps / (rounds * n),
-           "newton_iters_per_step": float((c1["solver_iters"] - c0["solver_iters"]).sum()) / max(1, steps),
-           "status_bits": int(np.bitwise_or.reduce(c1["status"])), "kernel_ms_per_round": (k1 - k0) / rounds,
-           "roofline_frac": steps * 2 * words * 8 / ((k1 - k0) * 1e-3) / 8e12,
-           "kernel": "ur5m_run_kernel<248>" if many else "ur5_run_kernel<44>"}
-    sim.close()
-    return out
+    steps = int(env.sim.counters()["total_steps"].sum() - c0)
+    res = {"workload": "BASELINE.json configs[4] shape on 1 GPU: 40-object piles, 200x200 RGB-D render, grasp-Q CNN (7.32 M parameters, fp32) forward for every scene, "
+                       "epsilon-greedy pixel + rotation, grasp script, replay push + optimiser steps (batch 12), device-resident",
+           "scenes": n, "rounds": rounds, "warmup": warmup, "grasp_attempts_per_s": rounds * n / dt, "env_steps_per_s": steps / dt, "ms_per_round": 1e3 * dt / rounds,
+           "optimiser_steps_per_round": (agent.learner.updates_done - u0) / rounds, "update_to_data": out["update_to_data"], "grasp_success_rate": rew / rounds,
+           "epsilon": out["epsilon"], "loss": out["loss"], "cnn_gflop_per_scene_forward": 42.0}
+    env.sim.close()
+    return res
+
+
+def strong_scaling_points(torch, dist, sharding, model, dev, dev_id, args):
+    """What one GPU does with its share of a STRONG-scaling run (4096 scenes in total: 2048 / 1024 / 512 per GPU at 2 / 4 / 8 GPUs), measured here on this
+    GPU alone with the headline's rounds (no data-path collective: a shard is independent). Below 2048 scenes the wave slots are no longer full (2048 per
+    chip) and a round lasts as long as its slowest scene, so the rate falls with the scene count -- DESIGN.md section 6 has the numbers and the limit."""
+    pts = []
+    for n in (2048, 1024, 512):
+        try:
+            job = Job(torch, dist, sharding, model, "it1", "aimed", n, n, 0, 1, dev, dev_id, args.groups, 16)
+            job.run_rounds(0, 4)
+            dt, c0, c1, _, _ = job.timed(4, 12)
+            steps = int((c1["total_steps"] - c0["total_steps"]).sum())
+            pts.append({"scenes_per_gpu": n, "env_steps_per_s_per_gpu": steps / dt, "ms_per_round": 1e3 * dt / 8, "rounds": 8,
+                        "corresponds_to": f"{4096 // n} GPUs x {n} scenes"})
+            job.close()
+        except Exception as exc:  # noqa: BLE001
+            pts.append({"scenes_per_gpu": n, "error": f"{type(exc).__name__}: {exc}"})
+    return pts
 
 
 def main():
@@ -232,7 +378,6 @@ def main():
     import torch.distributed as dist
     from mujoco_rl_ur5_amd import sharding
     from mujoco_rl_ur5_amd.model import load_model
-    from mujoco_rl_ur5_amd.native import BatchSim
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -250,58 +395,9 @@ def main():
     n_local = args.envs if args.envs else (4096 if args.scaling == "weak" else 4096 // world)
     n_total = n_local * world
     lo, hi = sharding.shard_range(n_total, rank, world)
-    G = args.groups if n_local % max(1, args.groups) == 0 else 1
-    n_g = n_local // G
     rounds = args.warmup + args.steps
-
-    class Group:
-        """One scene group of the rank: engine handle, its HIP stream (torch's, so that action tensors are stream-ordered with the launches)."""
-        def __init__(self, g, rule):
-            self.lo = lo + g * n_g
-            self.sim = BatchSim(model, n_g, device_id=dev_id)
-            self.sim.reset(BASE_SEED + np.arange(self.lo, self.lo + n_g, dtype=np.uint64), 1, 1000.0)   # episode 0 (GraspingEnv.py:409-477), untimed
-            self.stream = torch.cuda.Stream(device=dev) if G > 1 else torch.cuda.current_stream()
-            self.sim.set_stream(self.stream.cuda_stream)
-            with torch.cuda.stream(self.stream):
-                self.wl = It1Rounds(torch, model, self.sim, dev, self.lo, n_g, n_total, rule)
-                self.reward = torch.zeros((rounds + 8, n_g), dtype=torch.int32, device=dev)
-                self.ids = torch.arange(self.lo, self.lo + n_g, dtype=torch.int32, device=dev)
-
-    groups = [Group(g, args.rule) for g in range(G)]
-    torch.cuda.synchronize()
-
-    def run_rounds(r0, r1, wls=None):
-        gathered = None
-        for r in range(r0, r1):
-            for k, gr in enumerate(groups):
-                with torch.cuda.stream(gr.stream):
-                    wl = gr.wl if wls is None else wls[k]
-                    act, pixel = wl.launch(r, gr.reward[r])                        # attempt (+ reset_model for the scenes whose episode ends)
-                    rec = torch.stack([gr.ids, pixel, act[:, 3].to(torch.int32), gr.reward[r]], dim=1)
-                    gathered = sharding.gather_outcomes(rec)                       # the path's only collective: 16 B per scene per round
-        return gathered
-
-    def counters():
-        cs = [gr.sim.counters() for gr in groups]
-        return {k: np.concatenate([c[k] for c in cs]) for k in cs[0]}
-
-    def timed(r0, r1, wls=None):
-        for gr in groups:
-            gr.sim.sync()
-        c0, k0 = counters(), sum(gr.sim.kernel_ms_total() for gr in groups)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        g = run_rounds(r0, r1, wls)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        elapsed = time.perf_counter() - t0
-        for gr in groups:
-            gr.sim.sync()                                                          # resolves the HIP event pairs of the region's launches
-        c1, k1 = counters(), sum(gr.sim.kernel_ms_total() for gr in groups)
-        return elapsed, c0, c1, k1 - k0, g
+    job = Job(torch, dist, sharding, model, "it1", args.rule, n_local, n_total, lo, world, dev, dev_id, args.groups, rounds + 8)
+    groups, G, n_g, run_rounds, timed = job.groups, job.G, job.n_g, job.run_rounds, job.timed
 
     run_rounds(0, args.warmup)
     elapsed, c0, c1, kernel_ms, gathered = timed(args.warmup, rounds)
@@ -382,14 +478,17 @@ def main():
                                    "rule": "uniformly drawn table pixel, rotation 0, z = 0.91 (SURVEY.md section 8d config 2)"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model)
-    for gr in groups:
-        gr.sim.close()
+    if rank == 0 and world == 1 and not args.no_extras:
+        out["strong_scaling_points"] = strong_scaling_points(torch, dist, sharding, model, dev, dev_id, args)
+    job.close()
     if rank == 0 and world == 1 and not args.no_extras:
         torch.cuda.synchronize()
         # the headline line must not depend on the secondary measurements: a failure there is reported in place of the sub-result
-        for key, spec in (("it4", ("it4", 4096, 2, 1)), ("many", ("many", 2048, 1, 1))):   # many: BASELINE configs[3], 2048 piles per GPU
+        for key, fn in (("it4", lambda: rendered_sub_result(torch, dist, sharding, dev, dev_id, "it4", 4096, 4, 1, not args.no_cpu_baseline)),
+                        ("many", lambda: rendered_sub_result(torch, dist, sharding, dev, dev_id, "many", 2048, 4, 1, not args.no_cpu_baseline)),   # BASELINE configs[3]: 2048 piles per GPU
+                        ("dqn", lambda: dqn_sub_result(torch, dev, dev_id, 1024, 2, 1))):
             try:
-                out[key] = rendered_sub_result(torch, dev, dev_id, *spec)
+                out[key] = fn()
             except Exception as exc:  # noqa: BLE001
                 out[key] = {"error": f"{type(exc).__name__}: {exc}"}
     if rank == 0:

@@ -191,9 +191,7 @@ class BatchedGraspAgent:
         self.eps_threshold = self.eps_end + (self.eps_start - self.eps_end) * math.exp(-1.0 * self.steps_done / self.eps_decay)   # :241-243
         self.steps_done += self.N
         explore = torch.rand(self.N, device=self.device, generator=self._gen) <= self.eps_threshold
-        with torch.no_grad():
-            q = self.policy_net(state).reshape(self.N, -1)                                               # [N, 6*H*W]
-        greedy_action = q.argmax(dim=1)
+        greedy_action = self._q_all(state)[1]
         world = self.env.pixel_world_device(observation["depth"], self.device)                           # [N,H,W,3]
         on_table = (world[..., 2] >= self.env.TABLE_HEIGHT - 0.01).reshape(self.N, -1).float()
         on_table = torch.where(on_table.sum(dim=1, keepdim=True) > 0, on_table, torch.ones_like(on_table))
@@ -202,10 +200,20 @@ class BatchedGraspAgent:
         random_action = rot * self.n_actions_1 + pixel
         return torch.where(explore, random_action, greedy_action), ~explore
 
-    def greedy(self, state):                                                                             # :284-299
+    def _q_all(self, state, chunk=256):
+        """(max Q [N], argmax over the 6*H*W (rotation, pixel) pairs [N]) of every scene: the network runs on `chunk` scenes at a time -- its
+        first layer alone is 10 MB of activations per 200x200 scene, so thousands of scenes in one call would need tens of GB."""
+        vals, idxs = [], []
         with torch.no_grad():
-            q = self.policy_net(state).reshape(self.N, -1)
-        value, idx = q.max(dim=1)
+            for i0 in range(0, self.N, chunk):
+                q = self.policy_net(state[i0:i0 + chunk]).reshape(min(chunk, self.N - i0), -1)           # [c, 6*H*W]
+                v, i = q.max(dim=1)
+                vals.append(v)
+                idxs.append(i)
+        return torch.cat(vals), torch.cat(idxs)
+
+    def greedy(self, state):                                                                             # :284-299
+        value, idx = self._q_all(state)
         return idx, value
 
     def transform_action(self, action):

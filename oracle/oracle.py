@@ -71,6 +71,7 @@ def lib():
         L.ur5o_get_contacts.argtypes = [vp, dp]
         L.ur5o_get_rows.argtypes = [vp, dp]
         L.ur5o_render.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_ubyte), C.POINTER(C.c_float)]
+        L.ur5o_batch_camera.argtypes = [C.c_int]
         L.ur5o_batch.restype = C.c_long
         L.ur5o_batch.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_long), C.POINTER(C.c_double),
                                  C.POINTER(C.c_long), C.POINTER(C.c_long)]
@@ -81,8 +82,10 @@ def lib():
 def batch(model, nthreads, budget_s, mode=0, nsteps=100):
     """bench.py's CPU baseline: `nthreads` native threads, one scene each at a time, for `budget_s` seconds of wall time
     (mode 0 = IT1 reset + one aimed grasp attempt per scene, mode 1 = the first `nsteps` steps of the many-object drop,
-    mode 2 = bench.py's stationary IT1 workload: episodes of reset + settle + `nsteps` aimed attempts).
+    mode 2 = bench.py's stationary IT1 workload: episodes of reset + settle + `nsteps` aimed attempts, mode 3 = the same episodes with a rendered
+    observation and depth-derived grasp height per attempt (bench.py kind "it4"), mode 4 = 40-object piles: reset + settle + one rendered attempt).
     Returns (physics steps, scenes completed, wall seconds, grasp attempts, successes)."""
+    lib().ur5o_batch_camera(int(model.camera_name2id("top_down")))
     blob = model.to_blob()
     scenes, wall, att, suc = C.c_long(0), C.c_double(0), C.c_long(0), C.c_long(0)
     steps = lib().ur5o_batch(blob, len(blob), model.body_name2id("ee_link"), model.body_name2id("base_link"), int(nthreads), float(budget_s),

@@ -1840,8 +1840,28 @@ static void bench_aim(const Sim& s, int g, int j, double* xyz) {
     if (std::fabs(x) <= 0.27 && std::fabs(y + 0.6) <= 0.19 && z >= 0.905 && z <= 1.0) { xyz[0] = x; xyz[1] = y; return; }
   }
 }
+// the observation step of bench.py's rendered workloads on the CPU: render the 200x200 RGB-D image of camera `cam` (GraspEnv.get_observation), find the
+// pixel over world (x, y) at table height (the inverse of the renderer's own pixel -> ray map) and return the world height the depth image shows there
+static int g_batch_cam = 1;   // "top_down" of both scene files
+void ur5o_batch_camera(int cam) { g_batch_cam = cam; }
+static double bench_observed_height(Sim& s, double x, double y, std::vector<unsigned char>& rgb, std::vector<float>& depth) {
+  const int W = 200, H = 200, cam = g_batch_cam;
+  rgb.resize((size_t)W * H * 3); depth.resize((size_t)W * H);
+  s.render(cam, W, H, 0, rgb.data(), depth.data());
+  const double PI = 3.14159265358979323846;
+  const double f = 0.5 * H / std::tan(s.M.cam_fovy[cam] * PI / 360.0);
+  V3 o = v3(s.M.cam_pos + 3 * cam);
+  M3 Rc; for (int k = 0; k < 9; k++) Rc.m[k] = s.M.cam_mat[9 * cam + k];
+  V3 v = mulT(Rc, V3(x, y, 0.91) - o);
+  int px = (int)std::lround(W - 1 - (v.x / -v.z * f + 0.5 * W - 0.5)), py = (int)std::lround(H - 1 - (v.y / -v.z * f + 0.5 * H - 0.5));
+  px = px < 0 ? 0 : (px > W - 1 ? W - 1 : px); py = py < 0 ? 0 : (py > H - 1 ? H - 1 : py);
+  return o.z - (double)depth[(size_t)py * W + px];
+}
 // mode 0: reset + settle + ONE aimed attempt per scene (round-1 sample, kept for comparison); mode 1: reset + nsteps raw steps (many-object drop);
-// mode 2: bench.py's stationary IT1 workload -- whole episodes of reset + settle + `nsteps` aimed attempts (bench_aim) per scene.
+// mode 2: bench.py's stationary IT1 workload -- whole episodes of reset + settle + `nsteps` aimed attempts (bench_aim) per scene;
+// mode 3: the same episodes on the rendered workload (bench.py kind "it4"): every attempt renders the observation and takes its height from the depth
+// image, in-tree script (check_mode 0); mode 4: 40-object piles (kind "many"): reset + 1000 ms settle + ONE rendered attempt at the highest object of
+// the bin per scene (a whole episode of a pile is minutes of CPU time: the sample is bounded to one attempt).
 long ur5o_batch(const void* blob, size_t nbytes, int ee_body, int base_body, int nthreads, double budget_s, int mode, int nsteps,
                 long* scenes_out, double* wall_out, long* attempts_out, long* success_out) {
   std::atomic<long> steps{0}, scenes{0}, attempts{0}, success{0};
@@ -1852,6 +1872,8 @@ long ur5o_batch(const void* blob, size_t nbytes, int ee_body, int base_body, int
     Sim s;
     if (!s.init(blob, nbytes)) return;
     s.ik_ee_body = ee_body; s.ik_base_body = base_body;
+    std::vector<unsigned char> rgb;
+    std::vector<float> depth;
     while (elapsed() < budget_s) {
       int g = next.fetch_add(1);
       long before = s.total_steps;
@@ -1862,15 +1884,28 @@ long ur5o_batch(const void* blob, size_t nbytes, int ee_body, int base_body, int
         int ps[12], pr[12];
         success += s.grasp_attempt(xyz, (g / 4) % 6, 1, 0.91, ps, pr);
         attempts++;
-      } else if (mode == 2) {
+      } else if (mode == 2 || mode == 3) {
         s.reset(20 + (uint64_t)g, 1, 1);
         for (int j = 0; j < nsteps; j++) {
           double xyz[3];
           bench_aim(s, g, j, xyz);
+          if (mode == 3) xyz[2] = bench_observed_height(s, xyz[0], xyz[1], rgb, depth);
           int ps[12], pr[12];
-          success += s.grasp_attempt(xyz, (g / 4 + j) % 6, 1, 0.91, ps, pr);
+          success += s.grasp_attempt(xyz, (g / 4 + j) % 6, mode == 2 ? 1 : 0, 0.91, ps, pr);
           attempts++;
         }
+      } else if (mode == 4) {
+        s.reset(20 + (uint64_t)g, 1, 1);
+        double xyz[3] = {0, -0.6, 0.91}, top = -1;
+        for (int b = 1; b < s.M.nbody; b++) {
+          if (s.M.body_parentid[b] != 0 || s.M.body_jntnum[b] != 1 || s.M.jnt_type[s.M.body_jntadr[b]] != JNT_FREE) continue;
+          const double* q = &s.qpos[s.M.jnt_qposadr[s.M.body_jntadr[b]]];
+          if (std::fabs(q[0]) < 0.2 && std::fabs(q[1] + 0.6) < 0.13 && q[2] > 0.85 && q[2] > top) { top = q[2]; xyz[0] = q[0]; xyz[1] = q[1]; }
+        }
+        xyz[2] = bench_observed_height(s, xyz[0], xyz[1], rgb, depth);
+        int ps[12], pr[12];
+        success += s.grasp_attempt(xyz, g % 6, 0, 0.91, ps, pr);
+        attempts++;
       } else {
         s.reset(20 + (uint64_t)g, 1, 0);
         for (int i = 0; i < nsteps; i++) s.step();

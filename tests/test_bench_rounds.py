@@ -56,3 +56,54 @@ def test_rounds_stay_stationary_on_gpu(model_it1):
     assert rates.min() > 0.45 and rates.max() < 0.9, rates                         # the oracle's episode average is 0.65-0.67
     assert abs(rates[1:5].mean() - rates[5:9].mean()) < 0.1, rates                 # same mix in every window of EP rounds
     assert sim.counters()["status"].max() == 0
+
+
+def test_rendered_rounds_on_the_emulation_build(model_2f, emul_lib):
+    """kind "it4" (BASELINE configs[2]): every round renders the observation, aims at an object still on the plate and takes the grasp height from
+    the rendered depth under the aimed pixel -- the top face of a 4 / 3 / 5 cm box or the top of a sphere, never the plate."""
+    n = 2
+    sim = BatchSim(model_2f, n, lib_path=emul_lib)
+    sim.reset((20 + np.arange(n)).astype(np.uint64), 1, 1000.0)
+    wl = bench.It1Rounds(torch, model_2f, sim, torch.device("cpu"), 0, n, n, "aimed", "it4")
+    rew = torch.zeros((1, n), dtype=torch.int32)
+    act, pixel = wl.launch(0, rew[0])
+    sim.sync()
+    assert wl.dep.min() > 0.9 and wl.img.float().std() > 1.0                    # an image was rendered
+    assert ((act[:, 2] > 0.935) & (act[:, 2] < 0.975)).all(), act[:, 2]           # plate top 0.91 + an object of 3-6 cm
+    assert sim.counters()["total_steps"].min() > 1000 and sim.counters()["status"].max() == 0
+
+
+def test_device_side_pile_rule_equals_tools_pile_aim(model_it1):
+    """It1Rounds.pile_box_actions (torch, all scenes at once, what bench.py's "many" rounds run on the GPU) picks the box, wrist rotation and
+    aiming point that tools/pile_aim.py (numpy, one scene; the rule of the 256-scene agreement statistic) picks."""
+    from mujoco_rl_ur5_amd.model import load_model
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from pile_aim import pick_box
+    m = load_model("/UR5+gripper/UR5gripper_2_finger_many_objects.xml")
+    n, stride = 64, 832
+    rng = np.random.default_rng(3)
+    st = np.zeros((n, stride))
+    q = rng.normal(size=(n, 40, 4))
+    q /= np.linalg.norm(q, axis=2, keepdims=True)
+    q[::2, 10:20] = [1, 0, 0, 0]                                                   # half of the scenes: level boxes (yaw varies below)
+    yaw = rng.uniform(-np.pi, np.pi, size=(n, 10))
+    q[::2, 10:20, 0], q[::2, 10:20, 3] = np.cos(yaw[::2] / 2), np.sin(yaw[::2] / 2)
+    pos = np.stack([rng.uniform(-0.22, 0.22, (n, 40)), rng.uniform(-0.75, -0.45, (n, 40)), rng.uniform(0.9, 1.05, (n, 40))], axis=2)
+    pos[5, :, 0] = 0.5                                                             # a scene whose bin is empty
+    st[:, 8:8 + 280] = np.concatenate([pos, q], axis=2).reshape(n, 280)
+
+    class FakeSim:
+        n = 64
+
+        def state_tensor(self, dev):
+            return torch.from_numpy(st)
+    wl = bench.It1Rounds(torch, m, FakeSim(), torch.device("cpu"), 0, n, n, "aimed", "many")
+    xy, rot, found = wl.pile_box_actions(0)
+    nbox = 0
+    for e in range(n):
+        b = pick_box(m, st[e, :288])
+        if b is None:
+            continue
+        nbox += 1
+        assert found[e] and int(rot[e]) == b[2] and np.allclose(xy[e].numpy(), b[1][:2], atol=1e-12), (e, b, xy[e], rot[e])
+    assert nbox > 40 and not found[5] and np.allclose(xy[5].numpy(), [0.0, -0.6])
