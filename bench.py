@@ -196,12 +196,12 @@ def cpu_baseline(model, budget_s=12.0, kind="it1"):
     (SURVEY.md section 8d ii), plus the single-core rate. kind "many": one thread per scene does reset + settle + ONE rendered attempt on a
     40-object pile (a whole episode of a pile is minutes of CPU time; the sample is bounded, its physics steps are the same kind of steps)."""
     from oracle import oracle as O
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     if kind == "many":
-        sn, an, tn, attn, sucn = O.batch(model, cores, 1.0, 4, 1)                   # every thread finishes the one scene it started within the budget
+        sn, an, tn, attn, sucn = O.batch(model, cores, budget_s, 4, 1)              # scenes in flight when the budget ends are cut off; their steps count
         return dict(value=sn / tn, unit="env-steps/s", cores=cores, kind="port",
-                    sample=f"{an} piles (scenes 0..{an - 1}): reset + 1000 ms settle + one rendered grasp attempt at the highest object of the bin each "
-                           f"({sn} physics steps, {attn} attempts), oracle/ur5_oracle.cpp, one scene per thread on {cores} threads, {tn:.1f} s wall",
+                    sample=f"{an} piles (scenes 0..{an - 1}): reset + 1000 ms settle + one rendered grasp attempt at the highest object of the bin each, cut off "
+                           f"after {budget_s:.0f} s ({sn} physics steps, {attn} attempts completed), oracle/ur5_oracle.cpp, one scene per thread on {cores} threads, {tn:.1f} s wall",
                     grasp_attempts_per_s=attn / tn, grasp_success_rate=sucn / max(1, attn), env_steps_per_attempt=sn / max(1, attn))
     mode = 2 if kind == "it1" else 3
     s1, e1, t1, att1, _ = O.batch(model, 1, 0.3 * budget_s, mode, EP)
@@ -213,6 +213,24 @@ def cpu_baseline(model, budget_s=12.0, kind="it1"):
                 grasp_attempts_per_s=attn / tn, grasp_success_rate=sucn / max(1, attn), env_steps_per_attempt=sn / max(1, attn),
                 single_core={"value": s1 / t1, "grasp_attempts_per_s": att1 / t1,
                              "sample": f"{e1} episodes ({s1} steps, {att1} attempts), {t1:.1f} s on one core"})
+
+
+def usable_cores():
+    """Host cores this process may really use: the affinity mask, capped by the container's CPU quota (cgroup v2 cpu.max / v1 cfs quota). A GPU box
+    reports 256 hardware threads but may grant the container far fewer; oversubscribing the oracle's threads would only stretch the sample."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(math.ceil(int(q) / int(per)))))
+    except (OSError, ValueError):
+        try:
+            q, per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()), int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(math.ceil(q / per))))
+        except (OSError, ValueError):
+            pass
+    return n
 
 
 class Job:
@@ -306,7 +324,7 @@ def rendered_sub_result(torch, dist, sharding, dev, dev_id, workload, n, rounds,
            "kernel": "ur5m_run_kernel<248>" if many else "ur5_run_kernel<44>"}
     job.close()
     if with_cpu:
-        out["cpu_baseline"] = cpu_baseline(model, 8.0, workload)
+        out["cpu_baseline"] = cpu_baseline(model, 20.0 if many else 8.0, workload)
     return out
 
 
@@ -347,9 +365,9 @@ def strong_scaling_points(torch, dist, sharding, model, dev, dev_id, args):
     pts = []
     for n in (2048, 1024, 512):
         try:
-            job = Job(torch, dist, sharding, model, "it1", "aimed", n, n, 0, 1, dev, dev_id, args.groups, 16)
-            job.run_rounds(0, 4)
-            dt, c0, c1, _, _ = job.timed(4, 12)
+            job = Job(torch, dist, sharding, model, "it1", "aimed", n, n, 0, 1, dev, dev_id, args.groups, 12)
+            job.run_rounds(0, 2)
+            dt, c0, c1, _, _ = job.timed(2, 10)
             steps = int((c1["total_steps"] - c0["total_steps"]).sum())
             pts.append({"scenes_per_gpu": n, "env_steps_per_s_per_gpu": steps / dt, "ms_per_round": 1e3 * dt / 8, "rounds": 8,
                         "corresponds_to": f"{4096 // n} GPUs x {n} scenes"})
@@ -485,8 +503,8 @@ def main():
         torch.cuda.synchronize()
         # the headline line must not depend on the secondary measurements: a failure there is reported in place of the sub-result
         for key, fn in (("it4", lambda: rendered_sub_result(torch, dist, sharding, dev, dev_id, "it4", 4096, 4, 1, not args.no_cpu_baseline)),
-                        ("many", lambda: rendered_sub_result(torch, dist, sharding, dev, dev_id, "many", 2048, 4, 1, not args.no_cpu_baseline)),   # BASELINE configs[3]: 2048 piles per GPU
-                        ("dqn", lambda: dqn_sub_result(torch, dev, dev_id, 1024, 2, 1))):
+                        ("many", lambda: rendered_sub_result(torch, dist, sharding, dev, dev_id, "many", 2048, 3, 1, not args.no_cpu_baseline)),   # BASELINE configs[3]: 2048 piles per GPU
+                        ("dqn", lambda: dqn_sub_result(torch, dev, dev_id, 512, 2, 1))):
             try:
                 out[key] = fn()
             except Exception as exc:  # noqa: BLE001

@@ -1402,7 +1402,11 @@ struct Sim {
     std::fill(ctrl.begin(), ctrl.end(), 0.0);
     time = 0;
   }
+  // bench.py's CPU legs bound their sample by wall time: past the deadline a step does nothing, so the scripts of the scenes in flight run out quickly
+  // (their loops end on max_steps) and the leg returns; the steps taken before the deadline are counted
+  const std::atomic<bool>* stop_flag = nullptr;
   void step() {  // sim.step(), MujocoController.py:379
+    if (stop_flag && stop_flag->load(std::memory_order_relaxed)) return;
     forward();
     qacc_warmstart = qacc;
     integrate();
@@ -1866,12 +1870,14 @@ long ur5o_batch(const void* blob, size_t nbytes, int ee_body, int base_body, int
                 long* scenes_out, double* wall_out, long* attempts_out, long* success_out) {
   std::atomic<long> steps{0}, scenes{0}, attempts{0}, success{0};
   std::atomic<int> next{0};
+  std::atomic<bool> stop{false};
   auto t0 = std::chrono::steady_clock::now();
   auto elapsed = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
   auto work = [&]() {
     Sim s;
     if (!s.init(blob, nbytes)) return;
     s.ik_ee_body = ee_body; s.ik_base_body = base_body;
+    if (mode == 4) s.stop_flag = &stop;                            // piles: one scene outlasts the budget; cut it off
     std::vector<unsigned char> rgb;
     std::vector<float> depth;
     while (elapsed() < budget_s) {
@@ -1904,8 +1910,8 @@ long ur5o_batch(const void* blob, size_t nbytes, int ee_body, int base_body, int
         }
         xyz[2] = bench_observed_height(s, xyz[0], xyz[1], rgb, depth);
         int ps[12], pr[12];
-        success += s.grasp_attempt(xyz, g % 6, 0, 0.91, ps, pr);
-        attempts++;
+        int r = s.grasp_attempt(xyz, g % 6, 0, 0.91, ps, pr);
+        if (!stop.load()) { success += r; attempts++; }
       } else {
         s.reset(20 + (uint64_t)g, 1, 0);
         for (int i = 0; i < nsteps; i++) s.step();
@@ -1916,7 +1922,10 @@ long ur5o_batch(const void* blob, size_t nbytes, int ee_body, int base_body, int
   };
   std::vector<std::thread> th;
   for (int t = 0; t < nthreads; t++) th.emplace_back(work);
+  std::thread timer([&]() { while (elapsed() < budget_s && scenes.load() < 0x7fffffff && !stop.load()) std::this_thread::sleep_for(std::chrono::milliseconds(20)); stop = true; });
   for (auto& t : th) t.join();
+  stop = true;
+  timer.join();
   if (scenes_out) *scenes_out = scenes.load();
   if (wall_out) *wall_out = elapsed();
   if (attempts_out) *attempts_out = attempts.load();
