@@ -389,6 +389,8 @@ def main():
     ap.add_argument("--groups", type=int, default=2, help="scene groups per GPU, one engine handle + HIP stream each, rounds pipelined (1 = one handle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the uniform-rule figure and the it4 / many sub-results (N = 1 only)")
+    ap.add_argument("--sub", choices=("it4", "many", "dqn"), default=None,
+                    help="run ONLY this secondary measurement (N = 1) and print it as {name: result}: what the rocprofv3 passes of tools/gpu_evidence_extras.sh profile")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for 2 ranks on one device)")
     args = ap.parse_args()
 
@@ -409,6 +411,12 @@ def main():
     if world > 1:
         dist.init_process_group(args.backend, **({"device_id": dev} if args.backend == "nccl" else {}))
 
+    subs = {"it4": lambda cpu: rendered_sub_result(torch, dist, sharding, dev, dev_id, "it4", 4096, 4, 1, cpu),
+            "many": lambda cpu: rendered_sub_result(torch, dist, sharding, dev, dev_id, "many", 2048, 3, 1, cpu),   # BASELINE configs[3]: 2048 piles per GPU
+            "dqn": lambda cpu: dqn_sub_result(torch, dev, dev_id, 512, 2, 1)}
+    if args.sub:
+        print(json.dumps({args.sub: subs[args.sub](False)}), flush=True)
+        return
     model = load_model("it1_4box")
     n_local = args.envs if args.envs else (4096 if args.scaling == "weak" else 4096 // world)
     n_total = n_local * world
@@ -502,9 +510,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_extras:
         torch.cuda.synchronize()
         # the headline line must not depend on the secondary measurements: a failure there is reported in place of the sub-result
-        for key, fn in (("it4", lambda: rendered_sub_result(torch, dist, sharding, dev, dev_id, "it4", 4096, 4, 1, not args.no_cpu_baseline)),
-                        ("many", lambda: rendered_sub_result(torch, dist, sharding, dev, dev_id, "many", 2048, 3, 1, not args.no_cpu_baseline)),   # BASELINE configs[3]: 2048 piles per GPU
-                        ("dqn", lambda: dqn_sub_result(torch, dev, dev_id, 512, 2, 1))):
+        for key in ("it4", "many", "dqn"):
+            fn = (lambda k=key: subs[k](not args.no_cpu_baseline))
             try:
                 out[key] = fn()
             except Exception as exc:  # noqa: BLE001

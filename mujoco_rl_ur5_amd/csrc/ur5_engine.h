@@ -178,6 +178,9 @@ enum { PF_KIN = 0, PF_CRB, PF_VEL, PF_BROAD, PF_NARROW, PF_ROWS, PF_NEWTON_INIT,
 #ifndef UR5_SUP_K
 #define UR5_SUP_K 4   // hull vertices per lane and trip of the cooperative support scan
 #endif
+#ifndef UR5_MPR_W
+#define UR5_MPR_W 8   // lanes that share one hull pair in the cooperative MPR pass (8: eight pairs per wavefront in flight; 16: four pairs, half the trips per scan)
+#endif
 #ifndef UR5_INL_POW
 #define UR5_INL_POW 1
 #endif
@@ -875,19 +878,21 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
         }
       }
 #if defined(UR5_MPR_DPP_COORDS) && !defined(UR5_EMUL)
-      if constexpr (W == 8) {
+      if constexpr (W >= 8) {
         support_exchange<0xb1>(best, bi, bl);
         support_exchange<0x4e>(best, bi, bl);
         support_exchange<0x141>(best, bi, bl);
+        if constexpr (W == 16) support_exchange<0x140>(best, bi, bl);
         l = bl;
       } else l = v3(M.hullvert[s.vadr + bi]);
     }
 #else
 #ifndef UR5_EMUL
-      if constexpr (W == 8) {
+      if constexpr (W >= 8) {
         support_exchange<0xb1>(best, bi);    // quad_perm [1,0,3,2]: lane ^ 1
         support_exchange<0x4e>(best, bi);    // quad_perm [2,3,0,1]: lane ^ 2
         support_exchange<0x141>(best, bi);   // row_half_mirror: lane -> 7 - lane, the other quad of the sub-group
+        if constexpr (W == 16) support_exchange<0x140>(best, bi);   // row_mirror: lane -> 15 - lane, the other half of a 16-lane sub-group (one DPP row)
       }
 #endif
       l = v3(M.hullvert[s.vadr + bi]);
@@ -1343,8 +1348,10 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
   UR5_BIG void mpr_pass_body() {
     {
       const int nm = S.ncouple < UR5_MAXCON ? S.ncouple : UR5_MAXCON;
-      const int sub = UR5_LANE >> 3, sl = UR5_LANE & 7;
-      for (int base = 0; base < nm; base += GS / 8) {
+      constexpr int W = UR5_MPR_W;
+      static_assert(W == 8 || W == 16, "sub-groups are aligned groups of 8 or 16 lanes (DPP quad / half-row / row exchanges)");
+      const int sub = UR5_LANE / W, sl = UR5_LANE & (W - 1);
+      for (int base = 0; base < nm; base += GS / W) {
         const int idx = base + sub;
         if (idx < nm) {
           const int p = S.couple[idx];
@@ -1355,7 +1362,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
           Shape sa = make_shape(sink.g1, margin), sb = make_shape(sink.g2, margin);
           real depth;
           v3 nrm, pos;
-          const bool hit = mpr<8>(sa, sb, &depth, &nrm, &pos, sl);
+          const bool hit = mpr<W>(sa, sb, &depth, &nrm, &pos, sl);
 #if defined(UR5_PROFILE)
           if (sl == 0) UR5_ATOMIC_ADD(&S.prof[PF_X7], 1.0 + 1e-9 * (double)((sa.type == UR5_GEOM_MESH ? sa.vnum : 0) + (sb.type == UR5_GEOM_MESH ? sb.vnum : 0)));   // pairs + 1e-9 x hull vertices per support call
 #endif

@@ -101,7 +101,8 @@ class BatchSim:
             raise RuntimeError(f"ur5_create failed ({rc}): {self.lib.ur5_last_error().decode()}")
         self._h = h
         self.nq, self.nv, self.nu = model.nq, model.nv, model.nu
-        self.variant = 1 if (model.nv - 8) // 6 > _VARIANT[0][0] else 0   # which engine of libur5sim.so serves this model
+        # which engine of libur5sim.so serves this model (ur5host::count_objects): more than 6 objects, or condim 6 on a collidable geom
+        self.variant = 1 if ((model.nv - 8) // 6 > _VARIANT[0][0] or bool(np.any((np.asarray(model.geom_condim) > 4) & (np.asarray(model.geom_collide) != 0)))) else 0
 
     def close(self):
         if getattr(self, "_h", None):

@@ -46,13 +46,16 @@ def build_emul(flags=(), name="libur5sim_emul.so"):
 
 def build_simt():
     """Test-only host build of the engine's DEVICE code path, one fibre per lane of a wavefront (tests/emul/ur5sim_simt.cpp)."""
-    lib = os.path.join(os.path.dirname(EMUL_LIB), "libur5sim_simt.so")
+    # UR5_SIMT_FLAGS="-DUR5_MPR_W=16" pytest tests/test_engine_simt.py ... checks a build option of the engine on the wavefront emulation before it costs GPU time
+    extra = os.environ.get("UR5_SIMT_FLAGS", "").split()
+    tag = "".join(c if c.isalnum() else "_" for c in "".join(extra))
+    lib = os.path.join(os.path.dirname(EMUL_LIB), f"libur5sim_simt{('_' + tag) if tag else ''}.so")
     srcs = [os.path.join(EMUL_DIR, f) for f in ("ur5sim_simt.cpp", "ur5sim_simt_many.cpp")]
     deps = srcs + [os.path.join(EMUL_DIR, "ur5_simt_shim.h")] + [
         os.path.join(ROOT, "mujoco_rl_ur5_amd", "csrc", f) for f in ("ur5_engine.h", "ur5sim_host.h", "ur5_devmodel.h", "ur5_raster.h", "ur5_many_names.h")]
     if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(s) for s in deps):
         os.makedirs(os.path.dirname(lib), exist_ok=True)
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-I" + EMUL_DIR, "-o", lib] + srcs)
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-I" + EMUL_DIR, *extra, "-o", lib] + srcs)
     return lib
 
 
