@@ -1283,22 +1283,31 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       box_box(A, v3(M.g_size[g1]), B, v3(M.g_size[g2]), margin, out, sat);
       keep.sat_code = sat.code; keep.sat_flip = sat.flip; keep.sat_best = sat.best;
     } else {
-#if !defined(UR5_EMUL) && !defined(UR5_MANY)
-      {   // general convex pair: queued for the cooperative MPR pass of collision_body (8 lanes per pair)
+#ifndef UR5_EMUL
+      // general convex pair. Pairs with a mesh hull (a support call scans 70 / 120 / 400 vertices) are queued for the cooperative MPR pass of
+      // collision_body, 8 lanes per pair. Pairs of analytic shapes (the piles' cylinders) have O(1) support functions: sharing them between lanes
+      // would only reduce the pairs in flight, so the many-object kernel runs those here, one pair per lane.
+#ifdef UR5_MANY
+      const bool coop = t1 == UR5_GEOM_MESH || t2 == UR5_GEOM_MESH;
+#else
+      const bool coop = true;
+#endif
+      if (coop) {
         const int q = __hip_atomic_fetch_add(&S.ncouple, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (q < UR5_MAXCON) S.couple[q] = pair; else S.status |= UR5_ST_CAND_OVERFLOW;   // more such pairs than list slots: flagged, never silently dropped
         (void)keep;
-      }
-#else
-      if (out.mode == 0) {
-        Shape sa = make_shape(g1, margin), sb = make_shape(g2, margin);
-        real depth;
-        keep.hit = mpr(sa, sb, &depth, &keep.normal, &keep.pos);
-        keep.dist = margin - depth;
-        if (keep.hit && !(keep.dist < margin)) keep.hit = false;
-      }
-      if (keep.hit) emit(out, keep.pos, keep.normal, keep.dist);
+      } else
 #endif
+      {
+        if (out.mode == 0) {
+          Shape sa = make_shape(g1, margin), sb = make_shape(g2, margin);
+          real depth;
+          keep.hit = mpr(sa, sb, &depth, &keep.normal, &keep.pos);
+          keep.dist = margin - depth;
+          if (keep.hit && !(keep.dist < margin)) keep.hit = false;
+        }
+        if (keep.hit) emit(out, keep.pos, keep.normal, keep.dist);
+      }
     }
   }
   UR5_FN v3 geom_position(int g) const { const int dg = M.g_dg[g]; return dg < 0 ? v3(M.g_pos[g]) : v3(S.dgpos[dg]); }
@@ -1339,7 +1348,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     return k == UR5_KIND_STATIC ? -1 : (k == UR5_KIND_ROBOT ? M.g_owner[g] : M.nrd + M.g_owner[g]);
   }
 
-#if !defined(UR5_EMUL) && !defined(UR5_MANY)
+#if !defined(UR5_EMUL)
   // General convex pairs (hull against hull / box / ...): Minkowski portal refinement with 8 lanes per pair. The lanes of a sub-group run the
   // same MPR on the same pair (sub-group-uniform control flow) and share the hull scans of its support calls; GS / 8 pairs are in flight at
   // once. S.couple / S.ncouple (filled by narrow()) are free until make_constraints rebuilds them. Its own function in the 256-register
@@ -1440,7 +1449,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     }
     SYNC();
     PROF(PF_X0);   // profile builds: the one-candidate-per-lane pass (analytic pairs, box-box); PF_NARROW then is the cooperative MPR pass
-#if !defined(UR5_EMUL) && !defined(UR5_MANY)
+#if !defined(UR5_EMUL)
     if constexpr (FLAT) mpr_pass_body(); else mpr_pass_fn();
 #endif
     if (UR5_LANE == 0) {
