@@ -97,9 +97,11 @@ double ur5_last_launch_ms(ur5_sim* h);
 /* engine-kernel time (ms) of every launch since ur5_create whose events a ur5_sync has resolved: callers difference it around a region */
 double ur5_kernel_ms_total(ur5_sim* h);
 /* counters[n][6] host: total physics steps, last_movement_steps, status bits, Newton iterations, max contacts seen in a step,
-   Newton iterations that reused the previous Cholesky factor (many-object engine; 0 otherwise).
-   Status bits (sticky until ur5_reset): 1 = more contacts than slots (30 / 160), 2 = non-finite state, 4 = more equality/limit rows
-   than slots (16), 8 = more broad-phase survivors than slots (64 / 512). Any set bit means the scene's results are not trustworthy. */
+   and a variant-specific work counter: many-object engine -- Newton iterations that reused the previous Cholesky factor; wavefront-per-scene
+   engine -- physics steps whose broad phase ran from the cached pair list instead of scanning every pair (same candidates either way).
+   Status bits (sticky until ur5_reset): 1 = more contacts than slots (30 / 160), 2 = a step produced a non-finite (or > 1e10) state: the
+   scene went back to qpos0 like mj_resetData [3P] and keeps running, 4 = more equality/limit rows than slots (16), 8 = more broad-phase
+   survivors than slots (64 / 512). Any set bit means the scene's results are not trustworthy. */
 int ur5_get_counters(ur5_sim* h, int64_t* counters);
 /* world positions of the engine's bodies [n][8 + max objects][3] (max objects: 6, or 40 for many-object models):
    8 robot weld groups (dof order) then the objects */

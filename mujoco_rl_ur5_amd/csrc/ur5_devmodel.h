@@ -65,6 +65,7 @@ enum { UR5_KIND_STATIC = 0, UR5_KIND_ROBOT = 1, UR5_KIND_OBJECT = 2 };
 #define UR5_ST_NAN 2                                 // a step produced a non-finite (or > 1e10) state: the scene went back to qpos0 (mj_resetData [3P]) and is flagged
 #define UR5_ST_ROW_OVERFLOW 4
 #define UR5_ST_CAND_OVERFLOW 8                       // more broad-phase survivors than UR5_MAXCAND: pairs were dropped
+#define UR5_ST_CACHE_MISMATCH 16                     // test builds only: the broad phase's pair cache disagreed with the full scan
 
 struct Ur5DevModel {
   int nrd, nobj, nv, nq, nu, ngeom, npair, neq, ndg, iterations, ee_cbody, nrg;

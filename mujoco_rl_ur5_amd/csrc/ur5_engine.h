@@ -178,6 +178,9 @@ enum { PF_KIN = 0, PF_CRB, PF_VEL, PF_BROAD, PF_NARROW, PF_ROWS, PF_NEWTON_INIT,
 #ifndef UR5_SUP_K
 #define UR5_SUP_K 4   // hull vertices per lane and trip of the cooperative support scan
 #endif
+#ifndef UR5_SUP_DELTA
+#define UR5_SUP_DELTA 0.02   // travel (m) of a moving geom after which the broad phase's pair superset is rebuilt
+#endif
 #ifndef UR5_MPR_W
 #define UR5_MPR_W 8   // lanes that share one hull pair in the cooperative MPR pass (8: eight pairs per wavefront in flight; 16: four pairs, half the trips per scan)
 #endif
@@ -339,8 +342,16 @@ template <class real, int NV_> struct Lds {
   int ncon, nsr, ncand, ncouple;
   unsigned cplmask;              // bit k: object k takes part in a contact between two movable bodies; bit 31: one of them has a robot side
   unsigned long long bodymask;   // cbodies that carry at least one contact
-  int cA[UR5_MAXCON], cB[UR5_MAXCON], cdim[UR5_MAXCON], cg1[UR5_MAXCON], cg2[UR5_MAXCON];
+  int cA[UR5_MAXCON], cB[UR5_MAXCON], cdim[UR5_MAXCON];
+  short cg1[UR5_MAXCON], cg2[UR5_MAXCON];
   short cand[UR5_MAXCAND];
+#ifndef UR5_MANY
+  // broad-phase cache (wavefront-per-scene engine): `sup` is a SUPERSET of the pairs that can pass cull() while no moving geom has travelled more than
+  // UR5_SUP_DELTA since the list was built; `moved` bounds each moving geom's travel since then (sum of |v| h over the steps). nsup < 0: no valid list.
+  short sup[UR5_MAXCAND];
+  float moved[UR5_MAXDG];
+  int nsup;
+#endif
   int couple[UR5_MAXCON];
   real cpos[UR5_MAXCON][3], cframe[UR5_MAXCON][6], cdist[UR5_MAXCON], cfri[UR5_MAXCON][NB > 4 ? 3 : 2];   // cframe: normal, tangent 1 (tangent 2 = n x t1)
   real cD[UR5_MAXCON];
@@ -436,6 +447,9 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     PAR(i, UR5_REC_STRIDE) S.rec[i] = (real)rec[i];
     if (UR5_LANE == 0) { S.pid_dt = dt; S.contacts_enabled = con; S.last_steps = 0; S.total_steps = 0; }
     if (UR5_LANE == 0) { S.status = 0; S.solver_iters = 0; S.ncon_max = 0; S.ncon = 0; S.nsr = 0; S.badstate = 0; }
+#ifndef UR5_MANY
+    if (UR5_LANE == 0) S.nsup = -1;
+#endif
 #ifdef UR5_MANY
     if (UR5_LANE == 0) { S.nskip = 0; S.act_changed = 1; }
 #endif
@@ -1338,6 +1352,26 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     }
     return false;
   }
+  // The rotation-invariant part of cull() with `slack` added to every bound: true = the pair cannot pass cull() as long as each of its moving geoms stays
+  // within slack / 2 of where it is now, whatever its orientation becomes. (Bounding spheres about the geom origins; the point-to-box distance only against
+  // STATIC boxes -- the plate and the bins' walls, whose bounding spheres contain the whole scene.)
+  UR5_BIG bool cull_loose(int g1, int g2, real margin, real slack) const {
+    const int t1 = M.g_type[g1], t2 = M.g_type[g2];
+    const real r1 = (real)M.g_rbound[g1], r2 = (real)M.g_rbound[g2];
+    const v3 p1 = geom_position(g1), p2 = geom_position(g2);
+    if (t1 == UR5_GEOM_PLANE) { m3 A; A.load(M.g_mat[g1]); return dot(p2 - p1, A.col(2)) > r2 + margin + slack; }
+    const v3 d = p2 - p1;
+    const real rr = r1 + r2 + margin + slack;
+    if (dot(d, d) > rr * rr) return true;
+    if (t2 == UR5_GEOM_BOX && M.g_dg[g2] < 0) { GeomPose B = geom_pose(g2); if (dist_point_box(p1, B, v3(M.g_size[g2])) > r1 + margin + slack) return true; }
+    if (t1 == UR5_GEOM_BOX && M.g_dg[g1] < 0) { GeomPose A = geom_pose(g1); if (dist_point_box(p2, A, v3(M.g_size[g1])) > r2 + margin + slack) return true; }
+    return false;
+  }
+  UR5_FN void invalidate_pair_cache() {
+#ifndef UR5_MANY
+    S.nsup = -1;
+#endif
+  }
   UR5_FN static void make_frame(v3 n, real* fr) {
     v3 y = fabs(n.y) < (real)0.5 ? v3(0, 1, 0) : v3(0, 0, 1);
     y = normalized(y - n * dot(n, y));   // |y - n (n.y)| >= 0.86: never degenerate
@@ -1392,20 +1426,95 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     PROF_T0();
     // broad phase: ordered compaction of the surviving pairs
     int ncand = 0;
+#ifndef UR5_MANY
+    // Pair cache: most of the M.npair pairs are far apart for many steps in a row (a box on the pick plate and the walls of the drop bin), yet the scan
+    // below costs a step ~21 k cycles -- four trips of dependent model reads -- whatever the scene does. `sup` lists, in pair order, every pair that passes
+    // the rotation-invariant tests of cull() with 2 * UR5_SUP_DELTA of slack; while no moving geom has travelled more than UR5_SUP_DELTA since the list was
+    // built (S.moved: the sum of |velocity of the geom origin| * h over the steps, an upper bound of its displacement), any pair outside the list still
+    // fails cull(), so running cull() over the list alone gives the SAME candidate list, in the same order -- results are bit-identical.
+    bool use_cache = false;
+    {
+      const real h = (real)M.timestep;
+      bool over = false;
+      PAR(i, M.ndg) {
+        const int g = M.dg_geom[i];
+        const int b = body_of_geom(g);
+        v3 om(S.cvel[b]), vl(S.cvel[b] + 3);
+        const v3 v = vl + cross(om, v3(S.dgpos[i]) - body_ref(b));
+        const float mv = S.moved[i] + (float)(norm(v) * h * (real)1.0001 + (real)1e-9);
+        S.moved[i] = mv;
+        if (!(mv <= (float)UR5_SUP_DELTA)) over = true;
+      }
+      if (over) S.nsup = -1;   // benign race: every writer stores the same value
+      SYNC();
+      use_cache = S.nsup >= 0;
+    }
+    if (use_cache) {
+      const int nsup = S.nsup;
+      if (UR5_LANE == 0) S.rec[UR5_REC_MISC + 6] += 1;   // counters[5]: steps whose broad phase ran from the list
+#ifdef UR5_EMUL
+      for (int i = 0; i < nsup; i++) {
+        const int p = S.sup[i];
+        const int g1 = M.pair_g1[p], g2 = M.pair_g2[p];
+        const real margin = maxv((real)M.g_margin[g1], (real)M.g_margin[g2]);
+        if (!cull(g1, g2, margin)) { if (ncand < UR5_MAXCAND) S.cand[ncand] = (short)p; ncand++; }
+      }
+#else
+      for (int i0 = 0; i0 < nsup; i0 += GS) {
+        const int i = i0 + UR5_LANE;
+        bool keep = false;
+        int p = 0;
+        if (i < nsup) {
+          p = S.sup[i];
+          const int g1 = M.pair_g1[p], g2 = M.pair_g2[p];
+          const real margin = maxv((real)M.g_margin[g1], (real)M.g_margin[g2]);
+          keep = !cull(g1, g2, margin);
+        }
+        unsigned long long mask = __ballot(keep);
+        if constexpr (GS < 64) mask = (mask >> UR5_GBASE) & ((1ull << (GS & 63)) - 1ull);
+        const int slot = ncand + __popcll(mask & ((1ull << UR5_LANE) - 1ull));
+        if (keep && slot < UR5_MAXCAND) S.cand[slot] = (short)p;
+        ncand += __popcll(mask);
+      }
+#endif
+#if defined(UR5_EMUL) || defined(UR5_SIMT)
+      {   // test builds: the cached list must equal the full scan's, pair for pair
+        SYNC();
+        int nfull = 0;
+        bool same = true;
+        for (int p = 0; p < M.npair; p++) {
+          const int g1 = M.pair_g1[p], g2 = M.pair_g2[p];
+          if (!cull(g1, g2, maxv((real)M.g_margin[g1], (real)M.g_margin[g2]))) { if (nfull < UR5_MAXCAND && (nfull >= ncand || S.cand[nfull] != (short)p)) same = false; nfull++; }
+        }
+        if (!same || nfull != ncand) S.status |= UR5_ST_CACHE_MISMATCH;
+      }
+#endif
+    } else {
+    int nsup = 0;
+#endif
     for (int p0 = 0; p0 < M.npair; p0 += GS) {
 #ifdef UR5_EMUL
       for (int p = p0; p < p0 + GS && p < M.npair; p++) {
         int g1 = M.pair_g1[p], g2 = M.pair_g2[p];
         real margin = maxv((real)M.g_margin[g1], (real)M.g_margin[g2]);
         if (!cull(g1, g2, margin)) { if (ncand < UR5_MAXCAND) S.cand[ncand] = (short)p; ncand++; }
+#ifndef UR5_MANY
+        if (!cull_loose(g1, g2, margin, (real)(2 * UR5_SUP_DELTA))) { if (nsup < UR5_MAXCAND) S.sup[nsup] = (short)p; nsup++; }
+#endif
       }
 #else
       int p = p0 + UR5_LANE;
       bool keep = false;
+#ifndef UR5_MANY
+      bool loose = false;
+#endif
       if (p < M.npair) {
         int g1 = M.pair_g1[p], g2 = M.pair_g2[p];
         real margin = maxv((real)M.g_margin[g1], (real)M.g_margin[g2]);
         keep = !cull(g1, g2, margin);
+#ifndef UR5_MANY
+        loose = !cull_loose(g1, g2, margin, (real)(2 * UR5_SUP_DELTA));
+#endif
       }
       unsigned long long mask = __ballot(keep);
 #if UR5_NT == 64
@@ -1413,6 +1522,15 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       int slot = ncand + __popcll(mask & ((1ull << UR5_LANE) - 1ull));
       if (keep && slot < UR5_MAXCAND) S.cand[slot] = (short)p;
       ncand += __popcll(mask);
+#ifndef UR5_MANY
+      {
+        unsigned long long lm = __ballot(loose);
+        if constexpr (GS < 64) lm = (lm >> UR5_GBASE) & ((1ull << (GS & 63)) - 1ull);
+        const int ls = nsup + __popcll(lm & ((1ull << UR5_LANE) - 1ull));
+        if (loose && ls < UR5_MAXCAND) S.sup[ls] = (short)p;
+        nsup += __popcll(lm);
+      }
+#endif
 #else   // ordered compaction across the wavefronts of the scene
       if ((UR5_LANE & 63) == 0) S.redi[UR5_LANE >> 6] = __popcll(mask);
       SYNC();
@@ -1426,6 +1544,12 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
 #endif
 #endif
     }
+#ifndef UR5_MANY
+      // the list is valid from this step on (a list that does not fit stays invalid: every step then scans all pairs, as before)
+      PAR(i, M.ndg) S.moved[i] = 0;
+      if (UR5_LANE == 0) S.nsup = nsup <= UR5_MAXCAND ? nsup : -1;
+    }
+#endif
     if (UR5_LANE == 0) { S.ncand = ncand < UR5_MAXCAND ? ncand : UR5_MAXCAND; if (ncand > UR5_MAXCAND) S.status |= UR5_ST_CAND_OVERFLOW; }
     if (ncand > UR5_MAXCAND) ncand = UR5_MAXCAND;
     SYNC();
@@ -2889,7 +3013,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       PAR(i, M.nq) qpos()[i] = i < M.nrd ? (real)M.rd_qpos0[i] : (real)M.obj_qpos0[(i - M.nrd) / 7][(i - M.nrd) % 7];
       PAR(i, M.nv) { qvel()[i] = 0; warm()[i] = 0; }
       PAR(a, M.nu) ctrl()[a] = 0;
-      if (UR5_LANE == 0) { S.rec[UR5_REC_MISC + 2] = 0; S.status |= UR5_ST_NAN; S.badstate = 0; }
+      if (UR5_LANE == 0) { S.rec[UR5_REC_MISC + 2] = 0; S.status |= UR5_ST_NAN; S.badstate = 0; invalidate_pair_cache(); }
       SYNC();
     }
   }
@@ -3139,7 +3263,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
               result = grasped ? 1 : 0;
               if (P.reset_seeds && P.reset_seeds[env] != 0) {
                 SYNC();
-                if (UR5_LANE == 0) { ur5_reset_record(M, P.qpos0, S.rec, P.reset_seeds[env]); S.status = 0; }   // status bits are sticky until a reset: ur5_reset / ur5_reset_dev clear them too
+                if (UR5_LANE == 0) { ur5_reset_record(M, P.qpos0, S.rec, P.reset_seeds[env]); S.status = 0; invalidate_pair_cache(); }   // status bits are sticky until a reset: ur5_reset / ur5_reset_dev clear them too
                 SYNC();
                 pr.mask = mask_all(); pr.tol = (real)1e-7; pr.max_steps = 10; pr.repeat = P.reset_chunks;   // :473 stay(1000)
                 if (pr.repeat <= 0) pr.done = true;
@@ -3351,7 +3475,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
                   result = grasped ? 1 : 0;
                   if (P.reset_seeds && P.reset_seeds[env] != 0) {
                     SYNC();
-                    if (UR5_LANE == 0) { ur5_reset_record(M, P.qpos0, S.rec, P.reset_seeds[env]); S.status = 0; }   // status bits are sticky until a reset: ur5_reset / ur5_reset_dev clear them too
+                    if (UR5_LANE == 0) { ur5_reset_record(M, P.qpos0, S.rec, P.reset_seeds[env]); S.status = 0; invalidate_pair_cache(); }   // status bits are sticky until a reset: ur5_reset / ur5_reset_dev clear them too
                     SYNC();
                     pr.mask = mask_all(); pr.tol = (real)1e-7; pr.max_steps = 10; pr.repeat = P.reset_chunks;   // :473 stay(1000)
                     if (pr.repeat <= 0) pr.done = true;

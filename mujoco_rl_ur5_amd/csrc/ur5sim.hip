@@ -25,6 +25,9 @@
 #else
 #define UR5_KERNEL_ATTR(GS) __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((GS) < 64 ? 1 : UR5_WAVES_PER_EU)))
 #endif
+#if !defined(UR5_MANY) && !defined(UR5_PROFILE)   // (the per-phase cycle accounting build adds its counters to the image)
+static_assert(8 * sizeof(ur5::Lds<double, 32>) <= 160 * 1024, "the IT1 scene image must leave room for 8 scenes per CU (2 waves per SIMD): LDS is what caps residency");
+#endif
 template <int NV, int GS>
 __global__ void UR5_KERNEL_ATTR(GS) ur5_run_kernel(double* __restrict__ rec, Ur5Launch P) {
   const int slot = blockIdx.x * (UR5_NT / GS) + (int)threadIdx.x / GS;

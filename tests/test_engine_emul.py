@@ -138,6 +138,21 @@ def test_two_finger_six_object_scene_runs(model_2f, emul_lib):
     assert np.abs(np.linalg.norm(quats, axis=1) - 1).max() < 1e-12
 
 
+def test_broad_phase_pair_cache_serves_most_steps_with_the_full_scan_s_candidates(model_it1, emul_lib):
+    """The broad phase keeps a superset of the pairs that can pass cull() while no moving geom has travelled more than 2 cm (csrc/ur5_engine.h
+    collision_body); the test builds re-run the full scan next to every cached step and raise status bit 16 on any difference. A reset + settle + whole
+    grasp attempt: no mismatch, and most steps are served from the list (while the arm moves it is rebuilt every ~20 steps)."""
+    sim = BatchSim(model_it1, 2, lib_path=emul_lib)
+    sim.reset([20, 21], 1, 1000.0)
+    c0 = sim.counters()
+    assert (c0["cached_broadphase_steps"] > 0.9 * c0["total_steps"]).all(), c0           # a settling scene: one rebuild, then the list
+    st = sim.get_state()
+    rew, ps, pr = sim.grasp_attempt(np.array([[st["qpos"][e][8], -0.6 + st["qpos"][e][9], 0.91] for e in range(2)]), rot=[0, 3], check_mode=0)
+    c1 = sim.counters()
+    frac = (c1["cached_broadphase_steps"] - c0["cached_broadphase_steps"]) / (c1["total_steps"] - c0["total_steps"])
+    assert (c1["status"] == 0).all() and (frac > 0.8).all() and (frac < 1.0).all(), (c1, frac)
+
+
 def test_non_finite_state_resets_the_scene_like_mj_resetdata_and_flags_it(model_it1, emul_lib):
     """mj_step's state guard [3P] (mj_checkPos / mj_checkVel / mj_checkAcc -> mjWARN_BAD* + mj_resetData): a scene whose step produces a NaN (or
     a value beyond 1e10) goes back to qpos0 with zero velocity / warm start / controls / time and keeps running; it is flagged (status bit 2,
