@@ -76,9 +76,15 @@ static const Ur5DevModel* ur5_emul_model = nullptr;
 #define UR5_PHASE_C UR5_BIG   // solve_newton
 #define UR5_PHASE_D UR5_BIG   // kinematics
 #define UR5_PHASE_H UR5_BIG   // newton_direction
+#ifndef UR5_PHASE_E
 #define UR5_PHASE_E UR5_BIG    // crb_and_factor, velocity_stage, integrate: they share the register-resident robot factors
+#endif
+#ifndef UR5_PHASE_F
 #define UR5_PHASE_F UR5_BIG
+#endif
+#ifndef UR5_PHASE_G
 #define UR5_PHASE_G UR5_BIG
+#endif
 #ifndef UR5_PHASE_C
 #define UR5_PHASE_C UR5_BIG
 #endif
@@ -2982,6 +2988,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     SYNC();
   }
 
+  UR5_CALL void integrate_fn(const Fact& fr) { integrate(fr); }
   UR5_FN void forward(Fact& fr) {
     PROF_T0();
     kinematics(); PROF(PF_KIN);
@@ -2996,7 +3003,12 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     Fact fr;
     forward(fr);
     PROF_T0();
-    integrate(fr); PROF(PF_INTEGRATE);
+    // the six-object instantiation (NV = 44) sits at the 256-register cap inside the step: with the integration inlined its block Cholesky of the robot
+    // factors reloaded ~170 spilled values per step; as a real function (the factors travel in registers: argument promotion of the internal function)
+    // the step spills 15 / reloads 11. Same-box A/B (profiles/r03_g_ab_phase_functions.log): it4 rounds +7 %; the NV = 32 kernel loses 0.7 % that way and
+    // keeps it inlined.
+    if constexpr (!FLAT && NV_ > 32) integrate_fn(fr); else integrate(fr);
+    PROF(PF_INTEGRATE);
     if (UR5_LANE == 0) S.total_steps++;
     guard_state();
   }

@@ -41,7 +41,7 @@ def test_kernel_registers_and_scratch(tmp_path):
     assert small["vgpr_count"] <= 256 and six["vgpr_count"] <= 256              # two waves per SIMD
     assert small["max_flat_workgroup_size"] == 64 and many["max_flat_workgroup_size"] == 256
     assert small["private_segment_fixed_size"] <= 512, small                    # B per lane, the whole call tree (was 1 216)
-    assert six["private_segment_fixed_size"] <= 1024, six
+    assert six["private_segment_fixed_size"] <= 800, six                        # 824 until the integration became a real function in this instantiation
     assert many["private_segment_fixed_size"] <= 512 and many["vgpr_count"] == 512, many
     assert find("ur5_render_kernel")["private_segment_fixed_size"] == 0
     assert small["group_segment_fixed_size"] == 0                               # the scene is dynamic LDS, sized at launch
