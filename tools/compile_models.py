@@ -26,7 +26,7 @@ jobs = [("ur5_2f.ur5m", "UR5gripper_2_finger.xml", None, False),
         ("ur5_2f_it1_4box.ur5m", "UR5gripper_2_finger.xml", IT1_OBJECTS, False),
         ("ur5_2f_many.ur5m", "UR5gripper_2_finger_many_objects.xml", None, False),
         # the same pile scene WITH the seven arm-link hulls colliding, as in the reference (UR5gripper_2_finger_many_objects.xml:158-185,
-        # contype 1; hulls capped at 32 vertices like the gripper's): the many-object engine has a contact slot for every robot weld group
+        # contype 1; the arm hulls are capped at 32 vertices, the gripper's are full): the many-object engine has a contact slot for every robot weld group
         ("ur5_2f_many_armcol.ur5m", "UR5gripper_2_finger_many_objects.xml", None, True)]
 os.makedirs(ASSET_DIR, exist_ok=True)
 for out, xml, objs, arm in jobs:
