@@ -341,6 +341,10 @@ template <class real, int NV_> struct Lds {
   int nlvl;                                          // envelope groups (islands) and are processed together, one wavefront each
   real red[3 * 16];                                  // cross-wave reductions
   int redi[16];
+  // the envelope structure (island labels, block order, envelope pointers, panel levels, reach lists) is a function of the SET of coupled body pairs and of the
+  // objects' order along x: both are checked every step (gsig: one bit per pair of blocks), the structure is rebuilt only when one of them changed
+  unsigned gsig[2][((UR5_MAXOBJ + 1) * (UR5_MAXOBJ + 1) + 31) / 32];
+  int struct_valid, struct_dirty;
 #endif
   // dynamics vectors (dof space)
   real fs[NV_], as[NV_], x[NV_], Ma[NV_], grad[NV_], search[NV_], Mv[NV_], tmpv[NV_ + 4];
@@ -457,7 +461,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     if (UR5_LANE == 0) S.nsup = -1;
 #endif
 #ifdef UR5_MANY
-    if (UR5_LANE == 0) { S.nskip = 0; S.act_changed = 1; }
+    if (UR5_LANE == 0) { S.nskip = 0; S.act_changed = 1; S.struct_valid = 0; }
 #endif
 #if defined(UR5_PROFILE) && !defined(UR5_EMUL)
     if (UR5_LANE == 0) { for (int i = 0; i < PF_COUNT; i++) S.prof[i] = 0; S.prof[PF_CORECLK] = (double)wall_clock64(); }
@@ -1799,7 +1803,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       if (cp) S.couple[__popcll(mask & ((1ull << UR5_LANE) - 1ull))] = c;
       if (UR5_LANE == 0) S.ncouple = __popcll(mask);
     }
-#else
+#elif defined(UR5_EMUL) || !defined(UR5_MANY)
     if (UR5_LANE == 0) {
       int nc = 0;
       unsigned long long bm = 0;
@@ -1811,10 +1815,75 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       S.ncouple = nc;
       S.bodymask = bm;
     }
+#else
+    {   // many-object kernel: contacts between two movable bodies, compacted in contact order across the scene's wavefronts (one contact per lane)
+      static_assert(UR5_MAXCON <= UR5_NT, "one contact per lane");
+      if (UR5_LANE == 0) S.bodymask = 0;
+      SYNC();
+      const int c = UR5_LANE;
+      bool cp = false;
+      if (c < S.ncon) {
+        const int A = S.cA[c], B = S.cB[c];
+        cp = A >= 0 && B >= 0;
+        unsigned long long bm = 0;
+        if (A >= 0) bm |= 1ull << A;
+        if (B >= 0) bm |= 1ull << B;
+        if (bm) __hip_atomic_fetch_or(&S.bodymask, bm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      const unsigned long long mask = __ballot(cp);
+      if ((UR5_LANE & 63) == 0) S.redi[UR5_LANE >> 6] = __popcll(mask);
+      SYNC();
+      int base = 0, total = 0;
+#pragma unroll
+      for (int w = 0; w < UR5_NT / 64; w++) { if (w < (UR5_LANE >> 6)) base += S.redi[w]; total += S.redi[w]; }
+      if (cp) S.couple[base + __popcll(mask & ((1ull << (UR5_LANE & 63)) - 1ull))] = c;
+      if (UR5_LANE == 0) S.ncouple = total;
+    }
 #endif
     SYNC();
 #ifdef UR5_MANY
-    envelope_structure();
+    {
+      // Is last step's envelope structure still the structure of this step? It depends on the set of coupled block pairs and on the order of the objects
+      // along x inside their islands, nothing else.
+      const int nobj = M.nobj, nblk = nobj + 1;
+      constexpr int NW = ((UR5_MAXOBJ + 1) * (UR5_MAXOBJ + 1) + 31) / 32;
+      PAR(w, NW) S.gsig[1][w] = 0;
+      if (UR5_LANE == 0) S.struct_dirty = S.struct_valid ? 0 : 1;
+      SYNC();
+      PAR(q, S.ncouple) {
+        const int c = S.couple[q];
+        int ia = S.cA[c] < M.nrd ? nobj : S.cA[c] - M.nrd, ib = S.cB[c] < M.nrd ? nobj : S.cB[c] - M.nrd;
+        if (ia > ib) { const int t = ia; ia = ib; ib = t; }
+        const int bit = ia * nblk + ib;
+#ifdef UR5_EMUL
+        S.gsig[1][bit >> 5] |= 1u << (bit & 31);
+#else
+        __hip_atomic_fetch_or(&S.gsig[1][bit >> 5], 1u << (bit & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+      }
+      SYNC();
+      {
+        bool diff = false;
+        PAR(w, NW) if (S.gsig[1][w] != S.gsig[0][w]) diff = true;
+        if (S.struct_valid) {
+          PAR(r, nobj - 1) {   // the previous order must still be sorted by (island, x, index)
+            const int a = S.obj_at[r], b = S.obj_at[r + 1];
+            if (S.island[a] == S.island[b]) {
+              const real xa = S.bpos[M.nrd + a][0], xb = S.bpos[M.nrd + b][0];
+              if (!(xa < xb || (xa == xb && a < b))) diff = true;
+            }
+          }
+        }
+        if (diff) S.struct_dirty = 1;   // benign race: every writer stores the same value
+      }
+      SYNC();
+      if (S.struct_dirty) {
+        PAR(w, NW) S.gsig[0][w] = S.gsig[1][w];
+        envelope_structure();
+        if (UR5_LANE == 0) S.struct_valid = 1;
+        SYNC();
+      }
+    }
 #endif
   }
 
