@@ -329,7 +329,8 @@ template <class real, int NV_> struct Lds {
   int env_first[NV_], env_ptr[NV_ + 1];              // first stored column of a row, offset of the row
   short obj_rank[UR5_MAXOBJ], obj_at[UR5_MAXOBJ];   // sorted position of an object and back
   int island[UR5_MAXOBJ + 1];                        // island label of object k / of the robot (index nobj)
-  short blk_first[UR5_MAXOBJ + 1], blk_last[UR5_MAXOBJ + 1];   // per block (sorted position; robot = block nobj): first coupled block, last block reaching it
+  int blk_first[UR5_MAXOBJ + 1], blk_ptr[UR5_MAXOBJ + 1];      // per block (sorted position; robot = block nobj): first coupled block (atomic min), envelope offset of its first row
+  short blk_last[UR5_MAXOBJ + 1], lv[UR5_MAXOBJ + 1], reach_cnt[UR5_MAXOBJ + 1];   // last block reaching it, level of its panel (-1: none), blocks reaching it
   double henv[UR5_HENV_CAP];                         // the envelope itself when it fits (it does for settled 40-object piles)
   int env_inlds, nseq, act_changed, nskip;
   short reach_ptr[UR5_MAXOBJ + 2], reach_list[(UR5_MAXOBJ + 1) * UR5_MAXOBJ / 2];   // per panel: the blocks below it whose rows reach it
@@ -341,10 +342,7 @@ template <class real, int NV_> struct Lds {
   int nlvl;                                          // envelope groups (islands) and are processed together, one wavefront each
   real red[3 * 16];                                  // cross-wave reductions
   int redi[16];
-  // the envelope structure (island labels, block order, envelope pointers, panel levels, reach lists) is a function of the SET of coupled body pairs and of the
-  // objects' order along x: both are checked every step (gsig: one bit per pair of blocks), the structure is rebuilt only when one of them changed
-  unsigned gsig[2][((UR5_MAXOBJ + 1) * (UR5_MAXOBJ + 1) + 31) / 32];
-  int struct_valid, struct_dirty;
+
 #endif
   // dynamics vectors (dof space)
   real fs[NV_], as[NV_], x[NV_], Ma[NV_], grad[NV_], search[NV_], Mv[NV_], tmpv[NV_ + 4];
@@ -461,7 +459,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     if (UR5_LANE == 0) S.nsup = -1;
 #endif
 #ifdef UR5_MANY
-    if (UR5_LANE == 0) { S.nskip = 0; S.act_changed = 1; S.struct_valid = 0; }
+    if (UR5_LANE == 0) { S.nskip = 0; S.act_changed = 1; }
 #endif
 #if defined(UR5_PROFILE) && !defined(UR5_EMUL)
     if (UR5_LANE == 0) { for (int i = 0; i < PF_COUNT; i++) S.prof[i] = 0; S.prof[PF_CORECLK] = (double)wall_clock64(); }
@@ -1635,6 +1633,9 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
   UR5_CALL void make_constraints_fn() { make_constraints_body(); }
   UR5_FN void make_constraints() { if constexpr (FLAT) make_constraints_body(); else make_constraints_fn(); }
   UR5_PHASE_B void make_constraints_body() {
+#ifdef UR5_MANY
+    PROF_T0();   // profile builds of the many-object kernel: sub-intervals x1..x5 of `rows`
+#endif
 #if !defined(UR5_EMUL) && UR5_NT == 64
     // special rows (joint equality, violated joint / slide limits): one candidate per lane -- [0, neq) equalities, then 2 sides of
     // every robot joint, then 2 sides of every object slide -- compacted in candidate order (= the serial order below) with a ballot
@@ -1748,6 +1749,9 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       S.nsr = ns;
     }
 #endif
+#ifdef UR5_MANY
+    PROF(PF_X1);   // special rows (lane 0)
+#endif
     PAR(c, S.ncon) {
       int g1 = S.cg1[c], g2 = S.cg2[c];
       make_frame(v3(S.cframe[c]), S.cframe[c]);
@@ -1776,6 +1780,9 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       S.ceoff[c][0] += ckr;
     }
     SYNC();
+#ifdef UR5_MANY
+    PROF(PF_X2);   // contact rows
+#endif
 #if !defined(UR5_EMUL) && !defined(UR5_MANY)
     {   // contacts between two movable bodies, compacted in contact order with a ballot; body / coupling masks with LDS atomics
       static_assert(UR5_MAXCON <= 32, "one contact per lane of the smallest lane group");
@@ -1842,48 +1849,12 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
 #endif
     SYNC();
 #ifdef UR5_MANY
-    {
-      // Is last step's envelope structure still the structure of this step? It depends on the set of coupled block pairs and on the order of the objects
-      // along x inside their islands, nothing else.
-      const int nobj = M.nobj, nblk = nobj + 1;
-      constexpr int NW = ((UR5_MAXOBJ + 1) * (UR5_MAXOBJ + 1) + 31) / 32;
-      PAR(w, NW) S.gsig[1][w] = 0;
-      if (UR5_LANE == 0) S.struct_dirty = S.struct_valid ? 0 : 1;
-      SYNC();
-      PAR(q, S.ncouple) {
-        const int c = S.couple[q];
-        int ia = S.cA[c] < M.nrd ? nobj : S.cA[c] - M.nrd, ib = S.cB[c] < M.nrd ? nobj : S.cB[c] - M.nrd;
-        if (ia > ib) { const int t = ia; ia = ib; ib = t; }
-        const int bit = ia * nblk + ib;
-#ifdef UR5_EMUL
-        S.gsig[1][bit >> 5] |= 1u << (bit & 31);
-#else
-        __hip_atomic_fetch_or(&S.gsig[1][bit >> 5], 1u << (bit & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
-      }
-      SYNC();
-      {
-        bool diff = false;
-        PAR(w, NW) if (S.gsig[1][w] != S.gsig[0][w]) diff = true;
-        if (S.struct_valid) {
-          PAR(r, nobj - 1) {   // the previous order must still be sorted by (island, x, index)
-            const int a = S.obj_at[r], b = S.obj_at[r + 1];
-            if (S.island[a] == S.island[b]) {
-              const real xa = S.bpos[M.nrd + a][0], xb = S.bpos[M.nrd + b][0];
-              if (!(xa < xb || (xa == xb && a < b))) diff = true;
-            }
-          }
-        }
-        if (diff) S.struct_dirty = 1;   // benign race: every writer stores the same value
-      }
-      SYNC();
-      if (S.struct_dirty) {
-        PAR(w, NW) S.gsig[0][w] = S.gsig[1][w];
-        envelope_structure();
-        if (UR5_LANE == 0) S.struct_valid = 1;
-        SYNC();
-      }
-    }
+    PROF(PF_X3);   // couple list
+    // (Round 3 tried to keep the envelope structure across steps -- it is a function of the set of coupled body pairs and of the objects' x-order. Measured on
+    // piles: the pair set changes in > 95 % of the steps even after 2 s of settling, resting contacts sit within 1e-5 m of the margin at which they are detected
+    // and come and go every step, so the structure is rebuilt every step: 130 k of the 154 k cycles of this phase.)
+    envelope_structure();
+    PROF(PF_X5);   // envelope structure
 #endif
   }
 
@@ -2440,55 +2411,73 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       }
       S.obj_rank[k] = (short)r; S.obj_at[r] = (short)k;
     }
-    PAR(p2, nblk) S.blk_first[p2] = (short)p2;
+    // Everything below used to be four loops on lane 0 (over the coupled contacts, the 248 rows, the blocks, and levels x blocks with a scratch-memory
+    // array): 130 k cycles per step with the other 255 lanes waiting. Same lists, built by all lanes (round 3).
+    PAR(p2, nblk) S.blk_first[p2] = p2;
     SYNC();
-    if (UR5_LANE == 0) {
-      for (int q = 0; q < S.ncouple; q++) {
-        const int c = S.couple[q];
-        int pa = blk_of_body(S.cA[c]), pb = blk_of_body(S.cB[c]);
-        if (pa > pb) { int t = pa; pa = pb; pb = t; }
-        if (S.blk_first[pb] > pa) S.blk_first[pb] = (short)pa;
-      }
+    PAR(q, S.ncouple) {   // first block every block is coupled with: a minimum over the coupled contacts
+      const int c = S.couple[q];
+      int pa = blk_of_body(S.cA[c]), pb = blk_of_body(S.cB[c]);
+      if (pa > pb) { int t = pa; pa = pb; pb = t; }
+#ifdef UR5_EMUL
+      if (S.blk_first[pb] > pa) S.blk_first[pb] = pa;
+#else
+      __hip_atomic_fetch_min(&S.blk_first[pb], pa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
     }
     SYNC();
     PAR(p2, nblk) {   // blocks below p2 whose rows reach it (their envelope starts at or before it)
       int last = p2, cnt = 0;
       for (int q = p2 + 1; q < nblk; q++) if (S.blk_first[q] <= p2) { last = q; cnt++; }
-      S.blk_last[p2] = (short)last; S.reach_ptr[p2 + 1] = (short)cnt;
+      S.blk_last[p2] = (short)last; S.reach_cnt[p2] = (short)cnt;
     }
     PAR(i, nv) S.env_first[i] = 6 * S.blk_first[i < 6 * nobj ? i / 6 : nobj];
     SYNC();
-    if (UR5_LANE == 0) {
+    // envelope pointers: row i of block p starts at (stored entries of the blocks before p) + (stored entries of the block's rows before i);
+    // a row of block p at local index j stores 6 p + j - 6 blk_first[p] + 1 entries
+    PAR(p2, nblk) {
       int o = 0;
-      for (int i = 0; i < nv; i++) { S.env_ptr[i] = o; o += i - S.env_first[i] + 1; }
-      S.env_ptr[nv] = o;
-      S.env_inlds = o <= UR5_HENV_CAP;
-      int ns = 0;   // panels of the sequential sweep: only blocks that some later block reaches
-      for (int p2 = 0; p2 < nblk; p2++) if (S.blk_last[p2] != p2) S.seq[ns++] = (short)p2;
-      S.nseq = ns;
-      // Envelope groups: maximal block ranges that no row crosses (block g starts one when nothing before it is reached from g
-      // or later). Groups share no Hessian entry, so their panels are independent; inside a group the panels form a chain.
-      // level of a panel = its position in its group's chain.
-      {
-        short lv[UR5_MAXOBJ + 1];
-        int grp_end = -1, pos = 0, nl = 0;
-        for (int p2 = 0; p2 < nblk; p2++) {
-          if (p2 > grp_end) pos = 0;
-          if (S.blk_last[p2] > grp_end) grp_end = S.blk_last[p2];
-          if (S.blk_last[p2] != p2) { lv[p2] = (short)pos; pos++; if (pos > nl) nl = pos; } else lv[p2] = -1;
-        }
-        S.nlvl = nl;
-        int o = 0;
-        for (int l = 0; l < nl; l++) {
-          S.lvl_ptr[l] = (short)o;
-          for (int p2 = 0; p2 < nblk; p2++) if (lv[p2] == l) S.lvl_list[o++] = (short)p2;
-        }
-        S.lvl_ptr[nl] = (short)o;
+      for (int q = 0; q < p2; q++) { const int w = 6, f = 6 * (q - S.blk_first[q]); o += w * f + w * (w + 1) / 2; }   // sum_{j<w} (f + j + 1); only objects precede a block
+      S.blk_ptr[p2] = o;
+    }
+    // level of a panel = its position in its envelope group's chain (groups: maximal block ranges that no row crosses; they share no Hessian entry, so
+    // their panels are independent): a scan over the blocks, 41 steps on one lane, results in LDS
+    if (UR5_LANE == 0) {
+      int grp_end = -1, pos = 0, nl = 0, ns = 0;
+      for (int p2 = 0; p2 < nblk; p2++) {
+        const int bl = S.blk_last[p2];
+        if (p2 > grp_end) pos = 0;
+        if (bl > grp_end) grp_end = bl;
+        if (bl != p2) { S.lv[p2] = (short)pos; pos++; if (pos > nl) nl = pos; S.seq[ns++] = (short)p2; } else S.lv[p2] = -1;   // seq: panels of the sequential sweep
       }
-      S.reach_ptr[0] = 0;
-      for (int p2 = 0; p2 < nblk; p2++) S.reach_ptr[p2 + 1] = (short)(S.reach_ptr[p2 + 1] + S.reach_ptr[p2]);
+      S.nlvl = nl; S.nseq = ns;
     }
     SYNC();
+    PAR(i, nv) {
+      const int p2 = i < 6 * nobj ? i / 6 : nobj, j = i - 6 * p2, f = 6 * (p2 - S.blk_first[p2]);
+      S.env_ptr[i] = S.blk_ptr[p2] + j * f + j * (j + 1) / 2;
+      if (i == nv - 1) { const int tot = S.env_ptr[i] + f + j + 1; S.env_ptr[nv] = tot; S.env_inlds = tot <= UR5_HENV_CAP; }
+    }
+    PAR(l, S.nlvl + 1) {   // panels with a lower level come first: lvl_ptr[l] = their number
+      int o = 0;
+      for (int p2 = 0; p2 < nblk; p2++) { const int v = S.lv[p2]; if (v >= 0 && v < l) o++; }
+      S.lvl_ptr[l] = (short)o;
+    }
+    PAR(p2, nblk) {       // exclusive prefix of the reach counts
+      int o = 0;
+      for (int q = 0; q < p2; q++) o += S.reach_cnt[q];
+      S.reach_ptr[p2] = (short)o;
+      if (p2 == nblk - 1) S.reach_ptr[nblk] = (short)(o + S.reach_cnt[p2]);
+    }
+    SYNC();
+    PAR(p2, nblk) {       // a panel's slot inside its level: panels of the same level in block order
+      const int v = S.lv[p2];
+      if (v >= 0) {
+        int o = S.lvl_ptr[v];
+        for (int q = 0; q < p2; q++) if (S.lv[q] == v) o++;
+        S.lvl_list[o] = (short)p2;
+      }
+    }
     PAR(p2, nblk) { int o = S.reach_ptr[p2]; for (int q = p2 + 1; q <= S.blk_last[p2]; q++) if (S.blk_first[q] <= p2) S.reach_list[o++] = (short)q; }
     SYNC();
   }
@@ -2505,6 +2494,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
   UR5_FN bool blk_terminal(int p2) const { return S.blk_first[p2] != p2 && S.blk_last[p2] == p2; }
   template <bool INLDS> UR5_BIG void envelope_assemble() {
     const int tot = S.env_ptr[M.nv];
+    PROF_T0();
     double* const hb = INLDS ? S.henv : S.hess;
     PAR(idx, tot) hb[idx] = 0;
     SYNC();
@@ -2549,6 +2539,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       *hptr<INLDS>(pdof(di), pdof(dj)) = (double)v;
     }
     SYNC();
+    PROF(PF_X6);   // zeroing + diagonal blocks (the rest of H_asm is the coupling loop)
     // coupling blocks: every (contact, entry) pair in parallel, summed with float atomics
     PAR(idx, S.ncouple * 64) {
       const int c = S.couple[idx >> 6], ent = idx & 63;

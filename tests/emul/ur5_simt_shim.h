@@ -133,4 +133,5 @@ inline unsigned long long __ballot(bool p) {
 }
 template <class T, class U> inline T __hip_atomic_fetch_add(T* p, U v, int, int) { T o = *p; *p = o + (T)v; simt::count(6); simt::yield_runnable(); return o; }
 template <class T, class U> inline T __hip_atomic_fetch_max(T* p, U v, int, int) { T o = *p; if ((T)v > o) *p = (T)v; simt::yield_runnable(); return o; }
+template <class T, class U> inline T __hip_atomic_fetch_min(T* p, U v, int, int) { T o = *p; if ((T)v < o) *p = (T)v; simt::yield_runnable(); return o; }
 template <class T, class U> inline T __hip_atomic_fetch_or(T* p, U v, int, int) { T o = *p; *p = o | (T)v; simt::yield_runnable(); return o; }
