@@ -214,6 +214,17 @@ enum { RES_NONE = -1, RES_SUCCESS = 0, RES_MAX_STEPS = 1, RES_IK_FAIL = 2 };
 constexpr int NB = UR5_NB;  // base directions per contact: normal, 2 tangents, torsion (+ 2 rolling directions for condim 6)
 
 // ---------------------------------------------------------------------------------------------- small maths
+// Many-object kernel: geometry is computed WITHOUT fused multiply-adds -- the vector helpers below and (UR5_STRICT, first statement of their bodies) the
+// kinematics and collision routines. The oracle is built with -ffp-contract=off; Minkowski portal refinement turns a last-bit difference of its inputs into
+// another portal face now and then (a 5e-3 jump of a contact normal), and piles of cylinders are full of the degenerate configurations where that happens.
+// With identical arithmetic the kernel reproduces the oracle's contacts from the same state instead of its own variant of them. The wavefront-per-scene
+// kernel keeps contraction: its scenes have few such pairs, and kinematics + collision are a third of its step.
+#if defined(UR5_MANY) && !defined(UR5_EMUL) && !defined(UR5_SIMT)
+#pragma clang fp contract(off)
+#define UR5_STRICT _Pragma("clang fp contract(off)")
+#else
+#define UR5_STRICT
+#endif
 template <class T> struct V3 {
   T x, y, z;
   UR5_FN V3() : x(0), y(0), z(0) {}
@@ -292,6 +303,9 @@ template <class T> UR5_FN T minv(T a, T b) { return a < b ? a : b; }
 // index of (i, j), i >= j, in a packed symmetric 6x6 (21 entries, row-major lower)
 UR5_FN int sym6(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
 
+#if defined(UR5_MANY) && !defined(UR5_EMUL) && !defined(UR5_SIMT)
+#pragma clang fp contract(fast)
+#endif
 // ---------------------------------------------------------------------------------------------- LDS image of one scene
 template <class real, int NV_> struct Lds {
   static constexpr int NV = NV_;
@@ -495,7 +509,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
   // ------------------------------------------------------------------ kinematics (mj_kinematics + mj_comPos [3P])
   UR5_CALL void kinematics_fn() { kinematics_body(); }
   UR5_FN void kinematics() { if constexpr (FLAT) kinematics_body(); else kinematics_fn(); }
-  UR5_PHASE_D void kinematics_body() {
+  UR5_PHASE_D void kinematics_body() { UR5_STRICT;
     // ping-pong buffers of the pointer-jumping pass: ce / cde (contact images, dead until this step's constraint rows are
     // built) hold the frames, cand (broad-phase list, rebuilt later) the ancestor links
     static_assert(UR5_MAXCON * NB >= 12 * UR5_MAXRD && UR5_MAXCAND * sizeof(short) >= 2 * UR5_MAXRD * sizeof(int), "scratch aliasing");
@@ -828,20 +842,20 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
 
   // ------------------------------------------------------------------ collision
   struct GeomPose { v3 pos; m3 mat; };
-  UR5_FN GeomPose geom_pose(int g) const {
+  UR5_FN GeomPose geom_pose(int g) const { UR5_STRICT;
     GeomPose r;
     int dg = M.g_dg[g];
     if (dg < 0) { r.pos = v3(M.g_pos[g]); r.mat.load(M.g_mat[g]); }
     else { r.pos = v3(S.dgpos[dg]); r.mat.load(S.dgmat[dg]); }
     return r;
   }
-  UR5_FN static real dist_point_box(v3 p, const GeomPose& B, v3 s) {
+  UR5_FN static real dist_point_box(v3 p, const GeomPose& B, v3 s) { UR5_STRICT;
     v3 l = mulT(B.mat, p - B.pos);
     v3 d(maxv(fabs(l.x) - s.x, (real)0), maxv(fabs(l.y) - s.y, (real)0), maxv(fabs(l.z) - s.z, (real)0));
     return norm(d);
   }
   struct Shape { int type, vadr, vnum; v3 pos, size, center; m3 mat; real margin; };
-  UR5_FN Shape make_shape(int g, real margin) const {
+  UR5_FN Shape make_shape(int g, real margin) const { UR5_STRICT;
     Shape s;
     GeomPose P = geom_pose(g);
     s.type = M.g_type[g]; s.pos = P.pos; s.mat = P.mat; s.size = v3(M.g_size[g]);
@@ -853,7 +867,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
   // W = 1: the calling lane scans the hull's vertices itself. W = 8 (GPU narrow phase): the 8 lanes of an aligned sub-group work on the same
   // pair with identical arguments; lane `sl` of the sub-group takes vertices sl, sl + 8, ... and a 3-step lane exchange picks the winner --
   // larger dot product, smaller index on ties, which is exactly the vertex the serial scan (strict >) returns.
-  template <int W = 1> UR5_BIG v3 support(const Shape& s, v3 dir, int sl = 0) const {
+  template <int W = 1> UR5_BIG v3 support(const Shape& s, v3 dir, int sl = 0) const { UR5_STRICT;
     v3 d = mulT(s.mat, dir), l;
     if (s.type == UR5_GEOM_SPHERE) l = d * s.size.x;
     else if (s.type == UR5_GEOM_BOX) l = v3(d.x >= 0 ? s.size.x : -s.size.x, d.y >= 0 ? s.size.y : -s.size.y, d.z >= 0 ? s.size.z : -s.size.z);
@@ -939,13 +953,13 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
   }
 #endif
   struct MV { v3 v, a, b; };
-  template <int W = 1> UR5_FN MV msupport(const Shape& A, const Shape& B, v3 dir, int sl = 0) const {
+  template <int W = 1> UR5_FN MV msupport(const Shape& A, const Shape& B, v3 dir, int sl = 0) const { UR5_STRICT;
     MV r;
     r.a = support<W>(A, dir, sl); r.b = support<W>(B, -dir, sl); r.v = r.a - r.b;
     return r;
   }
   // Minkowski portal refinement; same scheme, tolerances and result definition as oracle mpr_penetration()
-  template <int W = 1> UR5_MPR_ATTR bool mpr(const Shape& A, const Shape& B, real* depth, v3* dir_out, v3* pos_out, int sl = 0) const {
+  template <int W = 1> UR5_MPR_ATTR bool mpr(const Shape& A, const Shape& B, real* depth, v3* dir_out, v3* pos_out, int sl = 0) const { UR5_STRICT;
     const real tol = (real)1e-6;
     const int maxit = 50;
     MV v0, v1, v2, v3_, v4;
@@ -1035,7 +1049,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
   // by more than margin; otherwise the axis of least penetration: code 0-2 face of A, 3-5 face of B, 6+3i+j edge i x edge j
   // (an edge axis must beat the best face axis by 5 % to be chosen), its signed overlap `best` and whether it points B->A.
   struct Sat { int code; bool flip; real best; };
-  UR5_FN bool box_sat(const GeomPose& A, v3 a, const GeomPose& B, v3 b, real margin, Sat& o) const {
+  UR5_FN bool box_sat(const GeomPose& A, v3 a, const GeomPose& B, v3 b, real margin, Sat& o) const { UR5_STRICT;
     v3 t = B.pos - A.pos;
     real R[3][3], Q[3][3], tA[3];
 #pragma unroll
@@ -1079,7 +1093,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
   // face) enumerated directly -- incident corners inside the reference rectangle, reference corners inside the incident
   // rectangle, edge/edge crossings -- the vertex set Sutherland-Hodgman clipping (oracle collide_box_box) produces, without
   // its run-time-indexed polygon arrays.
-  UR5_BOXBOX_ATTR void box_box(const GeomPose& A, v3 a, const GeomPose& B, v3 b, real margin, Sink& out, Sat& sat) const {
+  UR5_BOXBOX_ATTR void box_box(const GeomPose& A, v3 a, const GeomPose& B, v3 b, real margin, Sink& out, Sat& sat) const { UR5_STRICT;
     if (out.mode == 0) { if (!box_sat(A, a, B, b, margin, sat)) { sat.code = -1; return; } }
     if (sat.code < 0) return;
     const int code = sat.code;
@@ -1172,7 +1186,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
 #undef UR5_EDGE
   }
   // ---- capsule helpers (same restatements as oracle collide_plane_capsule / sphere_capsule / capsule_capsule / capsule_box)
-  UR5_FN void sphere_sphere_at(Sink& out, v3 p1, real r1, v3 p2, real r2, real margin) const {
+  UR5_FN void sphere_sphere_at(Sink& out, v3 p1, real r1, v3 p2, real r2, real margin) const { UR5_STRICT;
     v3 d = p2 - p1;
     real len = norm(d), dist = len - r1 - r2;
     if (dist >= margin) return;
@@ -1180,7 +1194,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     emit(out, p1 + n * (r1 + (real)0.5 * dist), n, dist);
   }
   // sphere (centre c, radius r) against box (B, s): signed distance; emits the contact when asked to and closer than margin
-  UR5_FN real sphere_box_at(Sink& out, v3 c, real r, const GeomPose& B, v3 s, real margin, bool do_emit) const {
+  UR5_FN real sphere_box_at(Sink& out, v3 c, real r, const GeomPose& B, v3 s, real margin, bool do_emit) const { UR5_STRICT;
     v3 cl = mulT(B.mat, c - B.pos);
     v3 p(clampv(cl.x, -s.x, s.x), clampv(cl.y, -s.y, s.y), clampv(cl.z, -s.z, s.z));
     v3 d = p - cl;
@@ -1197,7 +1211,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     if (do_emit) emit(out, c + e * ((real)0.5 * (best - r)), -e, -best - r);
     return -best - r;
   }
-  UR5_BIG void narrow(int g1, int g2, real margin, Sink& out, Single& keep, int pair = -1) {
+  UR5_BIG void narrow(int g1, int g2, real margin, Sink& out, Single& keep, int pair = -1) { UR5_STRICT;
     int t1 = M.g_type[g1], t2 = M.g_type[g2];
     GeomPose A = geom_pose(g1), B = geom_pose(g2);
     if (t1 == UR5_GEOM_PLANE) {
@@ -1334,6 +1348,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
   }
   UR5_FN v3 geom_position(int g) const { const int dg = M.g_dg[g]; return dg < 0 ? v3(M.g_pos[g]) : v3(S.dgpos[dg]); }
   UR5_BIG bool cull(int g1, int g2, real margin) const {  // true = cannot touch
+    UR5_STRICT;
     int t1 = M.g_type[g1], t2 = M.g_type[g2];
     real r1 = (real)M.g_rbound[g1], r2 = (real)M.g_rbound[g2];
     if (t1 != UR5_GEOM_PLANE) {   // bounding spheres first, from the two positions alone: most pairs end here, before any rotation matrix is fetched
@@ -1396,7 +1411,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
   // once. S.couple / S.ncouple (filled by narrow()) are free until make_constraints rebuilds them. Its own function in the 256-register
   // kernel: the portal (five Minkowski points with their witnesses) and two shapes are ~170 registers by themselves.
   UR5_CALL void mpr_pass_fn() { mpr_pass_body(); }
-  UR5_BIG void mpr_pass_body() {
+  UR5_BIG void mpr_pass_body() { UR5_STRICT;
     {
       const int nm = S.ncouple < UR5_MAXCON ? S.ncouple : UR5_MAXCON;
       constexpr int W = UR5_MPR_W;

@@ -266,17 +266,20 @@ def _forward_parity_from_engine_state(model, sim, scene, min_contacts):
     flips = 0
     for c in oc:                                                      # contact order differs (pair order vs slot claiming)
         best = min(ec, key=lambda e: np.abs(e[1:4] - c[1:4]).sum())
-        # MPR stops at a 1e-6 portal tolerance: between fused (GPU) and unfused (oracle, -ffp-contract=off) arithmetic its last portal -- hence
-        # depth, normal and contact point of cylinder / hull pairs -- may differ at that level, and now and then a rounding-level difference
-        # sends the refinement through another portal face (normal off by ~5e-3: the discontinuity described at the top of this file);
-        # analytic pairs agree to rounding. At most two such flips per scene are accepted.
-        ok = np.abs(best[1:4] - c[1:4]).max() < 2e-5 and np.abs(best[4:7] - c[4:7]).max() < 1e-4 and abs(best[0] - c[0]) < 1e-5
+        # Round 3: the many-object kernel computes kinematics and collision without fused multiply-adds, like the oracle (-ffp-contract=off): from the same
+        # state it reproduces the oracle's contacts -- measured on 24 settled piles (tools/gpu_many_forward_errors.py): 934 of 935 contacts to 3e-10 m /
+        # 4e-8 (normal) / 4e-16 m (depth), qacc to 9e-9 relative in the 23 scenes without a flip (it was 5e-3 with fused arithmetic). What is left is
+        # MPR's discontinuity itself: oracle and engine are two texts of one algorithm, and where a portal decision falls on a last-bit difference of an
+        # association order the refinement takes another face (1 contact in 935; its normal moves by ~5e-3).
+        ok = np.abs(best[1:4] - c[1:4]).max() < 1e-8 and np.abs(best[4:7] - c[4:7]).max() < 1e-6 and abs(best[0] - c[0]) < 1e-10
         if not ok:
             assert np.abs(best[1:4] - c[1:4]).max() < 2e-2 and np.abs(best[4:7] - c[4:7]).max() < 5e-2, (best, c)
             flips += 1
-    assert flips <= 2, flips
+    assert flips <= 1, flips
     qacc = o.vec("qacc")
-    assert np.abs(d["qacc"][scene][:model.nv] - qacc).max() < (5e-3 if flips == 0 else 0.5) * max(1.0, np.abs(qacc).max())
+    err = np.abs(d["qacc"][scene][:model.nv] - qacc).max() / max(1.0, np.abs(qacc).max())
+    assert err < (1e-6 if flips == 0 else 5e-2), (err, flips)
+    return flips
 
 
 @pytest.mark.gpu
@@ -286,8 +289,8 @@ def test_settled_pile_forward_parity_on_gpu(model_many):
     sim = BatchSim(model_many, 8)
     sim.reset(300 + np.arange(8, dtype=np.uint64), 1, 1000.0)
     assert sim.counters()["status"].max() == 0
-    for scene in (0, 3, 7):
-        _forward_parity_from_engine_state(model_many, sim, scene, 30)
+    flips = sum(_forward_parity_from_engine_state(model_many, sim, scene, 30) for scene in range(8))
+    assert flips <= 1, flips                                              # eight piles, ~300 contacts
 
 
 @pytest.mark.gpu
