@@ -299,7 +299,7 @@ def test_pile_grasp_bits_against_the_oracle_on_gpu(model_many):
     move_and_grasp script each, and must agree on the reward bit and the script's result codes. The 24 scenes are the ones of a 256-pile pool
     whose best box (tools/pile_aim.py: level top face, sides parallel to the fingers) scores lowest, so that the statistic HAS positives -- with
     the round-2 rule (any object, rotation e % 6) 2 % of the attempts succeeded and all-zeros on both sides passed. tools/gpu_many_agreement.py
-    runs the 256-of-3072-scene statistic kept under profiles/ (28 % positives, 97 % agreement, 96 % of the oracle's positives reproduced)."""
+    runs the 256-of-3072-scene statistic kept under profiles/ (28 % positives, 95-97 % agreement, 93-96 % of the oracle's positives reproduced)."""
     from concurrent.futures import ThreadPoolExecutor
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
     from pile_aim import pick_box
@@ -330,7 +330,7 @@ def test_pile_grasp_bits_against_the_oracle_on_gpu(model_many):
     bits = sum(int(r == rew[e]) for e, (r, _) in zip(sel, res))
     codes = sum(int(pro.tolist() == pr[e].tolist()) for e, (_, pro) in zip(sel, res))
     assert sum(orew) >= 3, orew                                               # a statistic with positives (28 % in the 256-scene run)
-    assert bits >= n - 2 and codes >= n - 4, (bits, codes, rew[sel].tolist(), orew)   # piles are chaotic: 97 % agreement per scene in the 256-scene run
+    assert bits >= n - 2 and codes >= n - 4, (bits, codes, rew[sel].tolist(), orew)   # piles are chaotic: 95-97 % agreement per scene in the 256-scene run
 
 
 # ------------------------------------------------------------------ arm-link collision hulls
