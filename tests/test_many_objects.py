@@ -290,7 +290,7 @@ def test_settled_pile_forward_parity_on_gpu(model_many):
     sim.reset(300 + np.arange(8, dtype=np.uint64), 1, 1000.0)
     assert sim.counters()["status"].max() == 0
     flips = sum(_forward_parity_from_engine_state(model_many, sim, scene, 30) for scene in range(8))
-    assert flips <= 1, flips                                              # eight piles, ~300 contacts
+    assert flips <= 2, flips                                              # eight piles, ~300 contacts at ~1 flip per 900
 
 
 @pytest.mark.gpu
