@@ -46,7 +46,8 @@ UR5_RFN F3 mulm(const float* m, F3 v) { return f3(m[0] * v.x + m[1] * v.y + m[2]
 UR5_RFN F3 mulmT(const float* m, F3 v) { return f3(m[0] * v.x + m[3] * v.y + m[6] * v.z, m[1] * v.x + m[4] * v.y + m[7] * v.z, m[2] * v.x + m[5] * v.y + m[8] * v.z); }
 
 // world poses of the engine's cbodies (robot weld groups, then objects) from a state record; out: [UR5_MAXB][12] = pos, mat
-UR5_RFN void body_poses(const Ur5DevModel& M, const double* rec, float (*out)[12]) {
+// robot weld groups: a serial chain (fp64, as the engine's kinematics); objects: independent of each other, one per caller (the pose kernel spreads them over lanes)
+UR5_RFN void robot_poses(const Ur5DevModel& M, const double* rec, float (*out)[12]) {
   double pos[UR5_MAXRD][3], quat[UR5_MAXRD][4];
   for (int d = 0; d < M.nrd; d++) {
     int p = M.rd_parent[d];
@@ -81,7 +82,9 @@ UR5_RFN void body_poses(const Ur5DevModel& M, const double* rec, float (*out)[12
     for (int k = 0; k < 4; k++) quat[d][k] = q[k];
     for (int k = 0; k < 9; k++) out[d][3 + k] = (float)m[k];
   }
-  for (int k = 0; k < M.nobj; k++) {
+}
+UR5_RFN void object_pose(const Ur5DevModel& M, const double* rec, int k, float (*out)[12]) {
+  {
     const double* qp = rec + UR5_REC_QPOS + M.nrd + 7 * k;
     double w = qp[3], x = qp[4], y = qp[5], z = qp[6];
     double nn = 1.0 / sqrt(w * w + x * x + y * y + z * z);
@@ -92,6 +95,11 @@ UR5_RFN void body_poses(const Ur5DevModel& M, const double* rec, float (*out)[12
     o[6] = (float)(2 * (x * y + w * z)); o[7] = (float)(w * w - x * x + y * y - z * z); o[8] = (float)(2 * (y * z - w * x));
     o[9] = (float)(2 * (x * z - w * y)); o[10] = (float)(2 * (y * z + w * x)); o[11] = (float)(w * w - x * x - y * y + z * z);
   }
+}
+
+UR5_RFN void body_poses(const Ur5DevModel& M, const double* rec, float (*out)[12]) {
+  robot_poses(M, rec, out);
+  for (int k = 0; k < M.nobj; k++) object_pose(M, rec, k, out);
 }
 
 // world pose of render geom g given the body poses

@@ -68,7 +68,9 @@ __global__ void __launch_bounds__(64) ur5_render_pose_kernel(const Ur5RenderMode
   __shared__ float bp[UR5_MAXB][12];
   const int scene = blockIdx.x;
   if (scene >= n) return;
-  if (threadIdx.x == 0) ur5r::body_poses(ur5_cmodel, rec + (size_t)scene * UR5_REC_STRIDE, bp);
+  const double* r = rec + (size_t)scene * UR5_REC_STRIDE;
+  if (threadIdx.x == 0) ur5r::robot_poses(ur5_cmodel, r, bp);                                            // a serial chain: one lane
+  else for (int k = (int)threadIdx.x - 1; k < ur5_cmodel.nobj; k += (int)blockDim.x - 1) ur5r::object_pose(ur5_cmodel, r, k, bp);   // the objects: the other lanes
   __syncthreads();
   for (int g = threadIdx.x; g < R->ngeom; g += blockDim.x) {
     Ur5GeomPose* o = gpose + (size_t)scene * UR5_R_MAXG + g;
