@@ -8,9 +8,12 @@ from mujoco_rl_ur5_amd.model import load_model
 from mujoco_rl_ur5_amd.native import BatchSim
 from oracle.oracle import Oracle
 
+from concurrent.futures import ThreadPoolExecutor
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 192
-m = load_model("it1_4box")
-out = {}
+spec = sys.argv[2] if len(sys.argv) > 2 else "it1_4box"           # or /UR5+gripper/UR5gripper_2_finger.xml (six objects, NV = 44 kernel)
+m = load_model(spec)
+nobj = (m.nq - 8) // 7
+out = {"model": spec}
 for mode in (0, 1):
     sim = BatchSim(m, n)
     seeds = 1000 * (mode + 1) + np.arange(n, dtype=np.uint64)
@@ -19,16 +22,20 @@ for mode in (0, 1):
     rng = np.random.default_rng(7 + mode)
     acts = np.zeros((n, 3)); rots = np.arange(n) % 6
     for e in range(n):
-        o = st[e][8:].reshape(-1, 7); k = e % 4
+        o = st[e][8:].reshape(-1, 7); k = e % nobj
         jitter = rng.uniform(-0.012, 0.012, size=2) if e % 3 == 0 else 0.0      # a third of the attempts aim slightly off
         acts[e] = [o[k, 0], -0.6 + o[k, 1], 0.91]; acts[e, :2] += jitter
     rew, ps, pr = sim.grasp_attempt(acts, rot=rots, check_mode=mode)
     s2 = sim.get_state()["qpos"]
     t0 = time.time(); agree = 0; steps_equal = 0; worst = 0.0; worst_obj = 0.0
-    for e in range(n):
+
+    def one(e):
         orc = Oracle(m); orc.reset(int(seeds[e]), 1, True)
         r, pso, pro = orc.grasp_attempt(acts[e], int(rots[e]), mode)
-        so = orc.get_state()["qpos"]
+        return r, pso, orc.get_state()["qpos"]
+    with ThreadPoolExecutor(max_workers=min(64, os.cpu_count() or 8)) as ex:
+        res = list(ex.map(one, range(n)))
+    for e, (r, pso, so) in enumerate(res):
         agree += int(r == rew[e]); steps_equal += int(pso.tolist() == ps[e].tolist())
         rel = np.abs(s2[e][:8] - so[:8]).max() / max(1.0, np.abs(so[:8]).max())
         worst = max(worst, rel)
