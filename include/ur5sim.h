@@ -83,8 +83,10 @@ int ur5_grasp_attempt_dev(ur5_sim* h, const double* action_dev, int check_mode, 
    ur5_reset_dev do, then the scene settles for settle_ms. The reward is the attempt's. Saves the separate, poorly filled settle launch. */
 int ur5_grasp_attempt_reset_dev(ur5_sim* h, const double* action_dev, int check_mode, double table_height, int* reward_dev,
                                 const uint64_t* reset_seeds_dev, double settle_ms);
-/* Dispatch order of the following grasp-attempt / settle launches: order_dev[n] int32 (HIP device pointer, caller-owned, must stay valid
-   until changed) is a permutation of the scene ids; the engine starts scenes in that order. Results do not depend on it -- only the
+/* Dispatch order of the following grasp-attempt / settle launches: order_dev[n] int32 (HIP device pointer) is a permutation of the scene
+   ids; the engine starts scenes in that order. The handle COPIES the list (device to device, on its stream, ordered with its launches): the
+   caller's buffer may be reused or freed once work queued on that stream so far has run; a caller that filled it on another stream
+   synchronises first (with ur5_set_stream on the caller's stream there is nothing to do). Results do not depend on it -- only the
    makespan does: a launch ends with its slowest scene, so callers list the scenes with the most work first. NULL = scene order. */
 int ur5_set_order_dev(ur5_sim* h, const int* order_dev);
 int ur5_sync(ur5_sim* h);
