@@ -18,6 +18,19 @@ import torch
 import torch.nn as nn
 
 
+def _conv1x1_as_gemm(conv, x):
+    """A 1x1 convolution as one batched GEMM over the channel axis (rocBLAS / hipBLASLt): [O, C] x [N, C, H*W] -> [N, O, H*W]. Same parameters as the
+    ``nn.Conv2d`` it replaces (checkpoints load unchanged). On the MI355X box MIOpen's immediate mode has no tuned solution for these layers and falls
+    back to its naive kernel (``naive_conv_ab_nonpacked_*``: 39 % of the DQN loop's GPU time, profiles/r03_m_dqn_kernel_stats.csv)."""
+    if not x.is_cuda:                    # on the host the reference's own operator (the CPU tests compare a 13-step Adam sequence with the reference to 2e-4)
+        return conv(x)
+    n, c, h, w = x.shape
+    y = torch.matmul(conv.weight.view(conv.out_channels, c), x.reshape(n, c, h * w))
+    if conv.bias is not None:
+        y = y + conv.bias.view(1, -1, 1)
+    return y.view(n, conv.out_channels, h, w)
+
+
 def _conv3x3(cin, cout):
     return nn.Conv2d(cin, cout, kernel_size=3, stride=1, padding=1, bias=False)
 
@@ -40,7 +53,7 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         out = self.bn2(self.conv2(self.relu(self.bn1(self.conv1(x)))))
-        skip = x if self.conv3 is None else self.conv3(x)
+        skip = x if self.conv3 is None else _conv1x1_as_gemm(self.conv3, x)
         return self.relu(out + skip)
 
 
@@ -74,7 +87,7 @@ class _GraspingHead(nn.Module):
             self.sigmoid = nn.Sigmoid()
 
     def forward(self, x, verbose=0):
-        x = self.C1(self.UP2(self.RB3(self.UP1(self.RB2(self.RB1(x))))))
+        x = _conv1x1_as_gemm(self.C1, self.UP2(self.RB3(self.UP1(self.RB2(self.RB1(x))))))
         x = x.squeeze()                                   # the reference squeezes in place (:230,:277): batch 1 loses its batch axis
         return self.sigmoid(x) if self.output_activation is not None else x
 
