@@ -319,7 +319,7 @@ def rendered_sub_result(torch, dist, sharding, dev, dev_id, workload, n, rounds,
            "scenes": n, "rounds": rounds, "warmup": warmup, "scene_groups": job.G, "env_steps_per_s": steps / dt, "grasp_attempts_per_s": rounds * n / dt,
            "grasp_success_rate": succ / (rounds * n), "env_steps_per_attempt": steps / (rounds * n),
            "newton_iters_per_step": float((c1["solver_iters"] - c0["solver_iters"]).sum()) / max(1, steps),
-           "status_bits": int(np.bitwise_or.reduce(c1["status"])), "ms_per_round": 1e3 * dt / rounds, "kernel_ms_per_round_and_group": kms / (rounds * job.G),
+           "status_bits": int(np.bitwise_or.reduce(c1["status"] | c1["status_ended"])), "ms_per_round": 1e3 * dt / rounds, "kernel_ms_per_round_and_group": kms / (rounds * job.G),
            "roofline_frac": steps * 2 * words * 8 / dt / 8e12, "bytes_per_env_step": 2 * words * 8,
            "kernel": "ur5m_run_kernel<248>" if many else "ur5_run_kernel<44>"}
     job.close()
@@ -389,8 +389,10 @@ def main():
     ap.add_argument("--groups", type=int, default=2, help="scene groups per GPU, one engine handle + HIP stream each, rounds pipelined (1 = one handle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the uniform-rule figure and the it4 / many sub-results (N = 1 only)")
-    ap.add_argument("--sub", choices=("it4", "many", "dqn"), default=None,
+    ap.add_argument("--sub", choices=("it4", "many", "many4096", "dqn"), default=None,
                     help="run ONLY this secondary measurement (N = 1) and print it as {name: result}: what the rocprofv3 passes of tools/gpu_evidence_extras.sh profile")
+    ap.add_argument("--sub-scenes", type=int, default=None, help="with --sub: scene count instead of the sub-result's own (same-box A/Bs of engine builds)")
+    ap.add_argument("--sub-rounds", type=int, default=None, help="with --sub: timed rounds")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for 2 ranks on one device)")
     args = ap.parse_args()
 
@@ -401,6 +403,16 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU, RCCL), exactly as the driver's launcher would
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        raise SystemExit(subprocess.call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+                                          "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:], env=env))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
@@ -412,10 +424,17 @@ def main():
         dist.init_process_group(args.backend, **({"device_id": dev} if args.backend == "nccl" else {}))
 
     subs = {"it4": lambda cpu: rendered_sub_result(torch, dist, sharding, dev, dev_id, "it4", 4096, 4, 1, cpu),
-            "many": lambda cpu: rendered_sub_result(torch, dist, sharding, dev, dev_id, "many", 2048, 3, 1, cpu),   # BASELINE configs[3]: 2048 piles per GPU
+            "many": lambda cpu: rendered_sub_result(torch, dist, sharding, dev, dev_id, "many", 2048, 2, 1, cpu),   # BASELINE configs[3]: 16384 piles on 8 GPUs = 2048 per GPU
+            "many4096": lambda cpu: rendered_sub_result(torch, dist, sharding, dev, dev_id, "many", 4096, 2, 1, False),   # north_star: "a 4096-env synthetic pile" on one GPU
             "dqn": lambda cpu: dqn_sub_result(torch, dev, dev_id, 512, 2, 1)}
     if args.sub:
-        print(json.dumps({args.sub: subs[args.sub](False)}), flush=True)
+        if args.sub in ("it4", "many", "many4096") and (args.sub_scenes or args.sub_rounds):
+            wl = "it4" if args.sub == "it4" else "many"
+            dflt = {"it4": (4096, 4), "many": (2048, 2), "many4096": (4096, 2)}[args.sub]
+            res = rendered_sub_result(torch, dist, sharding, dev, dev_id, wl, args.sub_scenes or dflt[0], args.sub_rounds or dflt[1], 1, False)
+        else:
+            res = subs[args.sub](False)
+        print(json.dumps({args.sub: res}), flush=True)
         return
     model = load_model("it1_4box")
     n_local = args.envs if args.envs else (4096 if args.scaling == "weak" else 4096 // world)
@@ -461,12 +480,12 @@ def main():
             "metric": f"env-steps/sec (+ grasp-attempts/sec), {n_total} parallel UR5 scenes on {world} MI355X",
             "value": steps_all / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64", "data": "synthetic", "scenes_total": n_total, "scenes_per_gpu": n_local,
             "grasp_attempts_per_s": attempts / elapsed, "grasp_success_rate": succ_all / attempts,
             "grasp_success_rate_per_round_rank0": [round(float(x), 4) for x in per_round.tolist()],
             "env_steps_per_attempt": steps_all / attempts,
             "newton_iters_per_step": float((c1["solver_iters"] - c0["solver_iters"]).sum()) / max(1, steps_local),
-            "status_bits": int(np.bitwise_or.reduce(c1["status"])),
+            "status_bits": int(np.bitwise_or.reduce(c1["status"] | c1["status_ended"])),   # incl. the episodes that ended inside the timed launches
             "config": {"workload": "BASELINE.json configs[1]: IT1 (UR5gripper_2_finger.xml robot + bins, 4 equal 4 cm boxes), physics only, fixed "
                                    "z = 0.91, lift + 500-step closing check; one grasp-attempt round per step, episodes of 4 rounds with reset_model "
                                    "(+ 1000 ms settle) for the quarter of the batch that starts an episode in the round",
@@ -510,12 +529,23 @@ def main():
     if rank == 0 and world == 1 and not args.no_extras:
         torch.cuda.synchronize()
         # the headline line must not depend on the secondary measurements: a failure there is reported in place of the sub-result
-        for key in ("it4", "many", "dqn"):
+        for key in ("it4", "many", "many4096", "dqn"):
             fn = (lambda k=key: subs[k](not args.no_cpu_baseline))
             try:
                 out[key] = fn()
             except Exception as exc:  # noqa: BLE001
                 out[key] = {"error": f"{type(exc).__name__}: {exc}"}
+        # the secondary results once more as top-level scalars (a driver that keeps only scalar keys of the line keeps these)
+        for key in ("it4", "many", "many4096", "dqn"):
+            for f in ("env_steps_per_s", "grasp_attempts_per_s", "roofline_frac", "grasp_success_rate", "newton_iters_per_step"):
+                if isinstance(out.get(key), dict) and f in out[key]:
+                    out[f"{key}_{f}"] = out[key][f]
+        for pt in out.get("strong_scaling_points", []):
+            if "env_steps_per_s_per_gpu" in pt:
+                out[f"strong_{pt['scenes_per_gpu']}_scenes_env_steps_per_s_per_gpu"] = pt["env_steps_per_s_per_gpu"]
+        if "cpu_baseline" in out:
+            out["cpu_env_steps_per_s"], out["cpu_cores"] = out["cpu_baseline"]["value"], out["cpu_baseline"]["cores"]
+        out["roofline_frac"] = out["roofline"]["frac"]
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

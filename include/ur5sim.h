@@ -71,7 +71,8 @@ int ur5_stay(ur5_sim* h, double ms);
 int ur5_move_ee(ur5_sim* h, const double* xyz /* [n][3] */, const double* tol, const int* max_steps, int* result, int* steps);
 /* q5[n][5] arm joint angles; result[n] = UR5_RES_SUCCESS or UR5_RES_IK_FAIL (FK(IK) further than 2 cm from the target) */
 int ur5_ik(ur5_sim* h, const double* xyz /* [n][3] */, double* q5, int* result);
-/* action[n][4] = world x, y, z, rotation index 0..5 (GraspingEnv.py:40). check_mode 0 = in-tree script, 1 = IT1.
+/* action[n][4] = world x, y, z, rotation index 0..5 (GraspingEnv.py:40). check_mode 0 = in-tree script, 1 = IT1,
+   2 = in-tree script of a demo_mode env (GraspingEnv.py:313-321: the closing check at the drop position lasts 100 steps instead of 1000).
    skip[n] (or NULL): non-zero = GraspEnv.step's rule for targets off the table (GraspingEnv.py:124-131): the scene does not move, reward 0 */
 int ur5_grasp_attempt(ur5_sim* h, const double* action, const uint8_t* skip, int check_mode, double table_height, int* reward,
                       int* phase_steps /* [n][12] or NULL */, int* phase_result /* [n][12] or NULL */);
@@ -103,7 +104,9 @@ double ur5_kernel_ms_total(ur5_sim* h);
    engine -- physics steps whose broad phase ran from the cached pair list instead of scanning every pair (same candidates either way).
    Status bits (sticky until ur5_reset): 1 = more contacts than slots (30 / 160), 2 = a step produced a non-finite (or > 1e10) state: the
    scene went back to qpos0 like mj_resetData [3P] and keeps running, 4 = more equality/limit rows than slots (16), 8 = more broad-phase
-   survivors than slots (64 / 512). Any set bit means the scene's results are not trustworthy. */
+   survivors than slots (64 / 512). Any set bit means the scene's results are not trustworthy. The status column carries the bits of the running episode
+   in bits 0-7 and, in bits 8-15, the bits of every episode that ur5_grasp_attempt_reset_dev has ended INSIDE a launch since the last ur5_reset /
+   ur5_reset_dev: the reward of an episode-ending attempt is returned by the launch that also resets the scene, and its flag must stay readable. */
 int ur5_get_counters(ur5_sim* h, int64_t* counters);
 /* world positions of the engine's bodies [n][8 + max objects][3] (max objects: 6, or 40 for many-object models):
    8 robot weld groups (dof order) then the objects */

@@ -7,7 +7,13 @@ transition always in the batch) -- for N scenes per rank at once. Observations a
 simulating GPU, the network runs there (PyTorch-ROCm / MIOpen), actions go back to the engine as a device tensor, rewards come back
 as one; per round only the 16-byte outcome records cross ranks (``sharding.gather_outcomes``, RCCL all_gather).
 
-Differences that follow from batching, all deliberate: epsilon decays per transition (``steps_done`` advances by N per round); colour
+Several ranks = ONE agent (round 4): the job's scenes shard over the ranks, every random draw is keyed by global scene id and round
+(``sharding.scene_uniform``), action selection normalises every image by itself (``qnet.per_sample_statistics``), and the gathered outcome
+records drive one logical replay ring (``qnet.ReplayBuffer.push_shared``) from which every rank takes the same optimiser steps -- so N ranks
+with n scenes each hold bit-identical weights and produce the loss sequence of one rank with N n scenes (``tests/test_sharding.py``). The
+images of a sampled batch travel to the replicas in one all-reduce per optimiser step (12 x 640 KB); gradients never do.
+
+Differences that follow from batching, all deliberate: epsilon decays per transition (``steps_done`` advances by the job's scene count per round); colour
 jitter (torchvision's ColorJitter, :120-126) and the depth noise run on the device (``color_jitter`` below). Learning cadence: the reference
 pushes ONE transition and takes ONE optimiser step per env step (:551-556). ``Learner.push_and_learn`` keeps that order for a round's N
 transitions -- push k, step, push k, step ... -- with ``transitions_per_update = k`` (default 1 = the reference's update-to-data ratio of 1)
@@ -24,7 +30,7 @@ import torch.nn.functional as F
 
 from . import sharding
 from .envs import GraspEnv
-from .qnet import MULTIDISCRETE_RESNET, ReplayBuffer
+from .qnet import MULTIDISCRETE_RESNET, ReplayBuffer, per_sample_statistics
 
 MEMORY_SIZE = 2000            # Grasping_Agent_multidiscrete.py:26-38
 BATCH_SIZE = 12
@@ -65,19 +71,20 @@ def _hsv_to_rgb(img):
     return torch.cat((a1, a2, a3), dim=1)
 
 
-def color_jitter(rgb, generator=None, brightness=0.5, contrast=0.5, saturation=0.5, hue=0.5):
+def color_jitter(rgb, generator=None, brightness=0.5, contrast=0.5, saturation=0.5, hue=0.5, u=None):
     """torchvision ``T.ColorJitter(brightness=0.5, contrast=0.5, saturation=0.5, hue=0.5)`` (Grasping_Agent_multidiscrete.py:120-126) for a
     whole batch ON THE DEVICE: rgb float [N, 3, H, W] in [0, 1]. Every image draws its own four factors -- brightness / contrast / saturation
     from U(1 - x, 1 + x), hue from U(-x, x) -- and its own order of the four operations, as torchvision's forward() does per call; the
     operations are torchvision's tensor definitions (blend with black / mean grey / grey image, hue through HSV). The reference goes through
     a uint8 PIL image between ToPILImage and ToTensor; this stays in float."""
     n, dev = rgb.shape[0], rgb.device
-    u = torch.rand((n, 4), device=dev, generator=generator)
+    if u is None:                                              # u: the 8 uniform draws of every image, given by callers that key them by scene id
+        u = torch.rand((n, 8), device=dev, generator=generator)
     fb = (1 - brightness + 2 * brightness * u[:, 0]).view(n, 1, 1, 1)
     fc = (1 - contrast + 2 * contrast * u[:, 1]).view(n, 1, 1, 1)
     fs = (1 - saturation + 2 * saturation * u[:, 2]).view(n, 1, 1, 1)
     fh = (-hue + 2 * hue * u[:, 3]).view(n, 1, 1)
-    order = torch.argsort(torch.rand((n, 4), device=dev, generator=generator), dim=1)    # a random permutation of the 4 ops per image
+    order = torch.argsort(u[:, 4:8], dim=1)                    # a random permutation of the 4 ops per image
     out = rgb.clone()
     for pos in range(4):                                       # each operation runs ONCE per position, on the images whose order selects it there
         for op in range(4):
@@ -125,15 +132,26 @@ class Learner:
         self.updates_done += 1
         return self.last_loss
 
-    def push_and_learn(self, state, action, reward, learn=True):
+    def push_and_learn(self, state, action, reward, learn=True, outcomes=None, first_scene_id=0, n_actions_1=None):
         """A round's N transitions in the reference's order (:551-556: push, then learn): the transitions go into the ring in chunks of
         ``k`` consecutive scenes, an optimiser step after each chunk (its newest transition is in the batch). k = transitions_per_update,
-        raised so that a round takes at most max_updates_per_round steps. Returns (losses, update_to_data ratio of this round)."""
-        n = state.shape[0]
+        raised so that a round takes at most max_updates_per_round steps. Returns (losses, update_to_data ratio of this round).
+
+        Multi-rank jobs pass ``outcomes`` -- the all-gathered [n_total, 4] records {scene id, pixel, rotation, reward} of the round -- and the id
+        of this rank's first scene: the round's n_total transitions then go through ONE logical ring in global scene order
+        (``ReplayBuffer.push_shared``), every rank takes the SAME optimiser steps on the same batches (``sample`` assembles a batch from the
+        ranks that hold its images), and the replicas of ``policy_net`` stay bit-identical without any gradient traffic: one learner, as in the
+        reference, fed by all the shards."""
+        shared = outcomes is not None and self.memory.shared
+        n = int(outcomes.shape[0]) if shared else state.shape[0]
         k = max(self.transitions_per_update, -(-n // self.max_updates_per_round))
         losses = []
         for i0 in range(0, n, k):
-            self.memory.push(state[i0:i0 + k], action[i0:i0 + k], reward[i0:i0 + k])
+            if shared:
+                o = outcomes[i0:i0 + k].to(self.device).long()
+                self.memory.push_shared(i0, o[:, 2] * n_actions_1 + o[:, 1], o[:, 3], state, first_scene_id)
+            else:
+                self.memory.push(state[i0:i0 + k], action[i0:i0 + k], reward[i0:i0 + k])
             if learn:
                 loss = self.learn()
                 if loss is not None:
@@ -164,9 +182,21 @@ class BatchedGraspAgent:
         self.memory, self.optimizer = self.learner.memory, self.learner.optimizer
         self.eps_start, self.eps_end, self.eps_decay = eps_start, eps_end, eps_decay
         self.steps_done, self.eps_threshold = 0, eps_start
-        self.first_scene_id = self.env.first_scene_id if env is not None else first_scene_id   # one source of truth: the env's scene range
+        self.first_scene_id = self.env.first_scene_id                                   # one source of truth: the env's scene range
+        self.n_total = self.env.n_total
         self.last_loss = None
-        self._gen = torch.Generator(device=self.device).manual_seed(seed)
+        # every random draw of the loop is keyed by (seed, GLOBAL scene id, round): a scene explores, jitters and is noised the same way however the
+        # batch is sharded (sharding.scene_uniform)
+        self.seed, self.rounds_done = int(seed), 0
+        self.gids = self.first_scene_id + torch.arange(self.N, dtype=torch.int64, device=self.device)
+        import torch.distributed as dist
+        self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        if self.world > 1:
+            if self.n_total != self.world * self.N or self.first_scene_id != dist.get_rank() * self.N:
+                raise ValueError("multi-rank agent: every rank simulates the contiguous shard sharding.shard_range(n_total, rank, world)")
+            self.memory.make_shared()                                                   # one logical replay ring for the job (qnet.ReplayBuffer.push_shared)
+            for t in list(self.policy_net.parameters()) + list(self.policy_net.buffers()):   # one set of initial weights (29 MB, once): rank 0's
+                sharding.broadcast_from_rank0(t.data)
 
     # ------------------------------------------------------------------ observation -> network input
     def transform_observation(self, observation, normalize=True, jitter_and_noise=True):
@@ -174,14 +204,15 @@ class BatchedGraspAgent:
         observation = {"rgb": uint8 [N,H,W,3], "depth": float32 [N,H,W]} device tensors -> float32 [N,4,H,W]."""
         depth = observation["depth"].to(self.device).float().clamp(max=self.depth_threshold)            # :311
         if normalize:
-            depth = depth + 0.001 * torch.randn(depth.shape, device=self.device, generator=self._gen)       # :317 (whenever normalize=True)
+            for i0 in range(0, self.N, 512):                                                             # :317 (whenever normalize=True); chunks bound the int64 temporaries
+                depth[i0:i0 + 512] += 0.001 * sharding.scene_normal(self.seed, self.gids[i0:i0 + 512], self.rounds_done, 4, self.H * self.W).view(-1, self.H, self.W)
             depth = -depth
             dmin = depth.amin(dim=(1, 2), keepdim=True)
             dmax = depth.amax(dim=(1, 2), keepdim=True)
             depth = (depth - dmin) / (dmax - dmin).clamp_min(1e-12)                                      # :319-321
         rgb = observation["rgb"].to(self.device).permute(0, 3, 1, 2).float() / 255.0                    # ToTensor (:128)
         if normalize and jitter_and_noise:
-            rgb = color_jitter(rgb, self._gen)                                                          # self.normal_rgb (:117-123, :334-335)
+            rgb = color_jitter(rgb, u=sharding.scene_uniform(self.seed, self.gids, self.rounds_done, 5, 8))   # self.normal_rgb (:117-123, :334-335)
         return torch.cat((rgb, depth.unsqueeze(1)), dim=1)
 
     # ------------------------------------------------------------------ action selection
@@ -189,22 +220,27 @@ class BatchedGraspAgent:
         """:232-282 per scene: greedy = argmax over the [6, H, W] Q maps; random = uniform over the (pixel, rotation) pairs whose pixel
         lies on the table (world z >= TABLE_HEIGHT - 0.01, :266-280). Returns (action long [N], greedy bool [N])."""
         self.eps_threshold = self.eps_end + (self.eps_start - self.eps_end) * math.exp(-1.0 * self.steps_done / self.eps_decay)   # :241-243
-        self.steps_done += self.N
-        explore = torch.rand(self.N, device=self.device, generator=self._gen) <= self.eps_threshold
+        self.steps_done += self.n_total                                                                  # epsilon decays per transition of the whole job
+        u = sharding.scene_uniform(self.seed, self.gids, self.rounds_done, 1, 3, dtype=torch.float64)    # explore?, which table pixel, which rotation
+        explore = u[:, 0] <= self.eps_threshold
         greedy_action = self._q_all(state)[1]
         world = self.env.pixel_world_device(observation["depth"], self.device)                           # [N,H,W,3]
-        on_table = (world[..., 2] >= self.env.TABLE_HEIGHT - 0.01).reshape(self.N, -1).float()
-        on_table = torch.where(on_table.sum(dim=1, keepdim=True) > 0, on_table, torch.ones_like(on_table))
-        pixel = torch.multinomial(on_table, 1, generator=self._gen).squeeze(1)
-        rot = torch.randint(0, self.n_actions_2, (self.N,), device=self.device, generator=self._gen)
+        on_table = (world[..., 2] >= self.env.TABLE_HEIGHT - 0.01).reshape(self.N, -1)
+        on_table = torch.where(on_table.any(dim=1, keepdim=True), on_table, torch.ones_like(on_table))
+        cdf = on_table.cumsum(dim=1)                                                                     # uniform over the table pixels: inverse CDF of the draw
+        want = torch.floor(u[:, 1] * cdf[:, -1].double()).long() + 1                                     # the want-th table pixel, 1-based
+        pixel = torch.searchsorted(cdf, want[:, None]).squeeze(1).clamp(max=self.n_actions_1 - 1)
+        rot = torch.floor(u[:, 2] * self.n_actions_2).long().clamp(max=self.n_actions_2 - 1)
         random_action = rot * self.n_actions_1 + pixel
         return torch.where(explore, random_action, greedy_action), ~explore
 
     def _q_all(self, state, chunk=256):
         """(max Q [N], argmax over the 6*H*W (rotation, pixel) pairs [N]) of every scene: the network runs on `chunk` scenes at a time -- its
-        first layer alone is 10 MB of activations per 200x200 scene, so thousands of scenes in one call would need tens of GB."""
+        first layer alone is 10 MB of activations per 200x200 scene, so thousands of scenes in one call would need tens of GB. Batch norm
+        uses every image's OWN statistics here (qnet.per_sample_statistics): the reference selects actions with a batch of one in training
+        mode (:232-299), and a scene's greedy action must not depend on which scenes share its chunk or its rank."""
         vals, idxs = [], []
-        with torch.no_grad():
+        with torch.no_grad(), per_sample_statistics():
             for i0 in range(0, self.N, chunk):
                 q = self.policy_net(state[i0:i0 + chunk]).reshape(min(chunk, self.N - i0), -1)           # [c, 6*H*W]
                 v, i = q.max(dim=1)
@@ -234,10 +270,11 @@ class BatchedGraspAgent:
         action, greedy = self.epsilon_greedy(state, obs)
         env_action = self.transform_action(action)
         reward, skipped = self.env.step_device(env_action, obs["depth"], self.device)
-        losses, utd = self.learner.push_and_learn(state, action, reward, learn=learn)                    # :551-556
+        rec = torch.stack([self.gids.int(), env_action[:, 0].int(), env_action[:, 1].int(), reward.int()], dim=1)
+        outcomes = sharding.gather_outcomes(rec)                                                         # the round's only collective on the rollout side: 16 B per scene
+        losses, utd = self.learner.push_and_learn(state, action, reward, learn=learn, outcomes=outcomes if self.world > 1 else None,
+                                                  first_scene_id=self.first_scene_id, n_actions_1=self.n_actions_1)   # :551-556
         self.last_loss = losses[-1] if losses else None
-        ids = self.first_scene_id + torch.arange(self.N, dtype=torch.int32, device=self.device)
-        rec = torch.stack([ids, env_action[:, 0].int(), env_action[:, 1].int(), reward.int()], dim=1)
-        outcomes = sharding.gather_outcomes(rec)
+        self.rounds_done += 1
         return {"reward": reward, "skipped": skipped, "greedy": greedy, "loss": self.last_loss if learn else None, "losses": losses,
                 "update_to_data": utd, "outcomes": outcomes, "epsilon": self.eps_threshold}

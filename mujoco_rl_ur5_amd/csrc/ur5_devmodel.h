@@ -57,7 +57,7 @@ enum { UR5_KIND_STATIC = 0, UR5_KIND_ROBOT = 1, UR5_KIND_OBJECT = 2 };
 #define UR5_REC_PIDIN (UR5_REC_TARGET + UR5_MAXNU)     // 154
 #define UR5_REC_PIDOUT (UR5_REC_PIDIN + UR5_MAXNU)     // 162
 #define UR5_REC_KP (UR5_REC_PIDOUT + UR5_MAXNU)        // 170
-#define UR5_REC_MISC (UR5_REC_KP + UR5_MAXNU)          // 178: total_steps, last_steps, time, status, solver_iters, ncon_max, -, -
+#define UR5_REC_MISC (UR5_REC_KP + UR5_MAXNU)          // 178: total_steps, last_steps, time, status, solver_iters, ncon_max, reused factors / cached broad-phase steps, status bits of episodes ended in-launch
 #define UR5_REC_STRIDE ((UR5_REC_MISC + 8 + 63) / 64 * 64)   // 192 / 832
 
 // status bits (per env, sticky until reset)
@@ -136,7 +136,7 @@ UR5_HD inline void ur5_reset_record(const Ur5DevModel& M, const double* qpos0, d
   for (int i = 0; i < M.nq; i++) r[UR5_REC_QPOS + i] = qpos0[i];
   for (int i = 0; i < M.nv; i++) { r[UR5_REC_QVEL + i] = 0; r[UR5_REC_WARM + i] = 0; }
   for (int a = 0; a < M.nu; a++) { r[UR5_REC_CTRL + a] = 0; r[UR5_REC_QPOS + M.act_dof[a]] = home[a]; r[UR5_REC_TARGET + a] = home[a]; }
-  r[UR5_REC_MISC + 2] = 0; r[UR5_REC_MISC + 3] = 0;
+  r[UR5_REC_MISC + 2] = 0; r[UR5_REC_MISC + 3] = 0; r[UR5_REC_MISC + 7] = 0;   // time, status, status bits of the episodes ended inside a launch (the fused attempt + reset restores those)
   Ur5SplitMix rng{seed};
   const double two_pi = 6.283185307179586476925286766559;
   for (int k = 0; k < M.nobj; k++) {

@@ -356,6 +356,15 @@ template <class real, int NV_> struct Lds {
   int nlvl;                                          // envelope groups (islands) and are processed together, one wavefront each
   real red[3 * 16];                                  // cross-wave reductions
   int redi[16];
+  // Fixed-order accumulation (round 4): four wavefronts share a scene, so LDS float atomics would land in an order that changes from run to
+  // run. Instead every body slot owns the list of its contact sides (2 c + side, in contact order) and every Hessian coupling block the chain of
+  // its contacts; sums run along these lists, so a scene's results do not depend on how its wavefronts are scheduled (MujocoController.py:379
+  // is one deterministic thread).
+  static constexpr int NCH = (UR5_MAXCON + 31) / 32;    // contact chunks of the list construction: one (slot, chunk) item per lane
+  short csl[UR5_MAXCON][2];                          // accumulator slot of a contact's two bodies (-1: static side)
+  short side_list[2 * UR5_MAXCON], side_cnt[NSLOT * NCH], slot_tot[NSLOT], slot_ptr[NSLOT + 1];
+  short ckey[UR5_MAXCON], cnext[UR5_MAXCON], chead[UR5_MAXCON];   // per coupled contact: block pair, next contact of the same pair; first contacts of the pairs
+  int nhead;
 
 #endif
   // dynamics vectors (dof space)
@@ -1024,7 +1033,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
   // ---- narrow phase. Contacts go to a Sink: mode 0 only counts them, mode 1 writes them to their LDS slots. Every candidate
   // pair is evaluated twice (count -> wave prefix sum -> write) so that no per-lane contact array (= scratch memory) is needed;
   // the one expensive routine, MPR, produces a single contact that is kept in registers between the two passes.
-  struct Sink { int mode, slot, n, g1, g2; };
+  struct Sink { int mode, slot, n, g1, g2, pair; };
   struct Single { bool hit; v3 pos, normal; real dist; int sat_code; bool sat_flip; real sat_best; };
   UR5_FN void emit(Sink& k, v3 pos, v3 normal, real dist) const {
     // one pass: a slot is claimed with an LDS atomic counter. Only this wavefront touches the counter, so the order is
@@ -1039,6 +1048,9 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       normal.store(S.cframe[c]);          // tangents, friction, condim, bodies: make_constraints(), one lane per contact
       S.cdist[c] = dist;
       S.cg1[c] = k.g1; S.cg2[c] = k.g2;
+#if defined(UR5_MANY) && !defined(UR5_EMUL)
+      S.cA[c] = k.pair * 8 + k.n;   // sort key of sort_contacts() (a pair emits at most 8 contacts); cA proper is written by make_constraints
+#endif
     }
     k.n++;
   }
@@ -1422,7 +1434,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
         if (idx < nm) {
           const int p = S.couple[idx];
           Sink sink;
-          sink.mode = 0; sink.slot = 0; sink.n = 0;
+          sink.mode = 0; sink.slot = 0; sink.n = 0; sink.pair = p;
           sink.g1 = M.pair_g1[p]; sink.g2 = M.pair_g2[p];
           const real margin = maxv((real)M.g_margin[sink.g1], (real)M.g_margin[sink.g2]);
           Shape sa = make_shape(sink.g1, margin), sb = make_shape(sink.g2, margin);
@@ -1589,6 +1601,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
         keep.hit = false; keep.sat_code = -1; keep.sat_flip = false; keep.sat_best = 0;
         sink.mode = 0; sink.slot = 0; sink.n = 0;
         int p = S.cand[ci];
+        sink.pair = p;
         sink.g1 = M.pair_g1[p]; sink.g2 = M.pair_g2[p];
         real margin = maxv((real)M.g_margin[sink.g1], (real)M.g_margin[sink.g2]);
         narrow(sink.g1, sink.g2, margin, sink, keep, p);
@@ -1606,8 +1619,36 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       if (n > S.ncon_max) S.ncon_max = n;
     }
     SYNC();
+#if defined(UR5_MANY) && !defined(UR5_EMUL)
+    sort_contacts();
+#endif
     PROF(PF_NARROW);
   }
+#if defined(UR5_MANY) && !defined(UR5_EMUL)
+  // Contact slots are claimed with an atomic counter by lanes of four wavefronts (and by the cooperative MPR pass after them), so the slot ORDER of a step
+  // depends on how the wavefronts were scheduled -- and every sum over contacts downstream with it. Sorting the contacts by (geom pair, number within the
+  // pair) gives the one order the lane emulation and the oracle produce anyway: pair order. One contact per lane: rank by counting, move through registers.
+  UR5_FN void sort_contacts() {
+    static_assert(UR5_MAXCON <= UR5_NT, "one contact per lane");
+    const int n = S.ncon, c = UR5_LANE;
+    int rank = 0, g1 = 0, g2 = 0;
+    real px = 0, py = 0, pz = 0, nx = 0, ny = 0, nz = 0, dist = 0;
+    if (c < n) {
+      const int key = S.cA[c];
+      for (int j = 0; j < n; j++) rank += S.cA[j] < key ? 1 : 0;
+      px = S.cpos[c][0]; py = S.cpos[c][1]; pz = S.cpos[c][2];
+      nx = S.cframe[c][0]; ny = S.cframe[c][1]; nz = S.cframe[c][2];
+      dist = S.cdist[c]; g1 = S.cg1[c]; g2 = S.cg2[c];
+    }
+    SYNC();
+    if (c < n) {
+      S.cpos[rank][0] = px; S.cpos[rank][1] = py; S.cpos[rank][2] = pz;
+      S.cframe[rank][0] = nx; S.cframe[rank][1] = ny; S.cframe[rank][2] = nz;
+      S.cdist[rank] = dist; S.cg1[rank] = (short)g1; S.cg2[rank] = (short)g2;
+    }
+    SYNC();
+  }
+#endif
 
   // ------------------------------------------------------------------ constraint rows (mj_makeConstraint + mj_makeImpedance [3P])
   // x^p of the impedance sigmoid: p = 2 (MuJoCo's default solimp) is a product; the general pow() is large, so it is kept
@@ -1645,6 +1686,34 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     e[0] = dot(n, u); e[1] = dot(t1, u); e[2] = dot(t2, u); e[3] = dot(n, w);
     if constexpr (NB > 4) { e[NB - 2] = dot(t1, w); e[NB - 1] = dot(t2, w); }
   }
+#if defined(UR5_MANY) && !defined(UR5_EMUL)
+  // side lists: for every accumulator slot the contact sides (2 c + side) that act on its body, in contact order. Lane (slot, chunk) counts the sides of
+  // its 32 contacts, a two-level prefix sum places them, the same lane writes them: a counting sort whose result does not depend on any schedule.
+  UR5_FN void build_side_lists() {
+    constexpr int NCH = L::NCH;
+    static_assert(L::NSLOT * NCH <= UR5_NT, "one (slot, chunk) item per lane");
+    const int ns = nslot(), item = UR5_LANE, sl = item / NCH, ch = item - sl * NCH;
+    const int c0 = 32 * ch, c1 = c0 + 32 < S.ncon ? c0 + 32 : S.ncon;
+    int cnt = 0;
+    if (sl < ns) {
+      for (int c = c0; c < c1; c++) cnt += (S.csl[c][0] == sl ? 1 : 0) + (S.csl[c][1] == sl ? 1 : 0);
+      S.side_cnt[item] = (short)cnt;
+    }
+    SYNC();
+    if (UR5_LANE < ns) { int t = 0; for (int k = 0; k < NCH; k++) t += S.side_cnt[UR5_LANE * NCH + k]; S.slot_tot[UR5_LANE] = (short)t; }
+    SYNC();
+    if (sl < ns) {
+      int o = 0;
+      for (int q = 0; q < sl; q++) o += S.slot_tot[q];
+      if (ch == 0) { S.slot_ptr[sl] = (short)o; if (sl == ns - 1) S.slot_ptr[ns] = (short)(o + S.slot_tot[sl]); }
+      for (int k = 0; k < ch; k++) o += S.side_cnt[sl * NCH + k];
+      for (int c = c0; c < c1; c++) {
+        if (S.csl[c][0] == sl) S.side_list[o++] = (short)(2 * c);
+        if (S.csl[c][1] == sl) S.side_list[o++] = (short)(2 * c + 1);
+      }
+    }
+  }
+#endif
   UR5_CALL void make_constraints_fn() { make_constraints_body(); }
   UR5_FN void make_constraints() { if constexpr (FLAT) make_constraints_body(); else make_constraints_fn(); }
   UR5_PHASE_B void make_constraints_body() {
@@ -1771,6 +1840,9 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       int g1 = S.cg1[c], g2 = S.cg2[c];
       make_frame(v3(S.cframe[c]), S.cframe[c]);
       S.cA[c] = body_of_geom(g1); S.cB[c] = body_of_geom(g2);
+#if defined(UR5_MANY) && !defined(UR5_EMUL)
+      S.csl[c][0] = (short)(S.cA[c] >= 0 ? slot_of(S.cA[c]) : -1); S.csl[c][1] = (short)(S.cB[c] >= 0 ? slot_of(S.cB[c]) : -1);
+#endif
       S.cdim[c] = M.g_condim[g1] > M.g_condim[g2] ? M.g_condim[g1] : M.g_condim[g2];
       for (int j = 0; j < (NB > 4 ? 3 : 2); j++) S.cfri[c][j] = maxv((real)M.g_friction[g1][j], (real)M.g_friction[g2][j]);
       real margin = maxv((real)M.g_margin[g1], (real)M.g_margin[g2]);
@@ -1860,6 +1932,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       for (int w = 0; w < UR5_NT / 64; w++) { if (w < (UR5_LANE >> 6)) base += S.redi[w]; total += S.redi[w]; }
       if (cp) S.couple[base + __popcll(mask & ((1ull << (UR5_LANE & 63)) - 1ull))] = c;
       if (UR5_LANE == 0) S.ncouple = total;
+      build_side_lists();
     }
 #endif
     SYNC();
@@ -2005,8 +2078,56 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     for (int k = 1; k < NB; k++) v += w[k] * (ea[0] * eb[k] + ea[k] * eb[0]) + w[NB - 1 + k] * ea[k] * eb[k];
     return v;
   }
+#if defined(UR5_MANY) && !defined(UR5_EMUL)
+  // component g of the 6-vector [r x a ; a]
+  UR5_FN static real wrench_comp(v3 r, v3 a, int g) { const v3 cr = cross(r, a); return g < 3 ? cr[g] : a[g - 3]; }
+  // The many-object kernel GATHERS: lane (slot, entry) walks the slot's side list (contact order) and writes one entry of the body's wrench WB (entries 0-5) or of
+  // its twist-space Hessian G (6-26). Same terms as the scatter below, summed in an order that no wavefront schedule can change; every entry of every slot
+  // is written, so nothing has to be zeroed first. The lanes of a slot read the same contact (LDS broadcasts) and recompute its weights.
+  UR5_FN void contact_gather(const bool doW, const bool doG) {
+    PAR(idx, nslot() * 27) {
+      const int sl = idx / 27, ent = idx - 27 * sl;
+      if (ent < 6 ? !doW : !doG) continue;
+      int gi = 0, gj = 0;
+      if (ent >= 6) { const int e = ent - 6; while ((gi + 1) * (gi + 2) / 2 <= e) gi++; gj = e - gi * (gi + 1) / 2; }
+      const v3 ref = body_ref(body_of_slot(sl));
+      real acc = 0;
+      for (int o = S.slot_ptr[sl]; o < S.slot_ptr[sl + 1]; o++) {
+        const int sd = S.side_list[o], c = sd >> 1;
+        v3 ax[3] = {v3(S.cframe[c]), v3(S.cframe[c] + 3), cross(v3(S.cframe[c]), v3(S.cframe[c] + 3))};
+        real fb[NB], w[2 * NB - 1];
+        contact_weights(c, fb, w);
+        const v3 r = v3(S.cpos[c]) - ref;
+        if (ent < 6) {
+          const real sg = (sd & 1) ? (real)1 : (real)-1;
+          const v3 F = ax[0] * fb[0] + ax[1] * fb[1] + ax[2] * fb[2];
+          v3 T = ax[0] * fb[3];
+          if constexpr (NB > 4) T = T + ax[1] * fb[NB - 2] + ax[2] * fb[NB - 1];
+          acc += sg * (ent < 3 ? (cross(r, F) + T)[ent] : F[ent - 3]);
+        } else {
+          // F_k (6-vector [rot; lin]): k<3 -> [r x a_k ; a_k], k>=3 -> [a_{k-3} ; 0];  G_ij = sum_kl W_kl F_k[i] F_l[j] (arrow-shaped W)
+          real fi[NB], fj[NB];
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            fi[k] = wrench_comp(r, ax[k], gi); fj[k] = wrench_comp(r, ax[k], gj);
+            if (3 + k < NB) { fi[3 + k] = gi < 3 ? ax[k][gi] : (real)0; fj[3 + k] = gj < 3 ? ax[k][gj] : (real)0; }
+          }
+          real v = w[0] * fi[0] * fj[0];
+#pragma unroll
+          for (int k = 1; k < NB; k++) v += w[k] * (fi[0] * fj[k] + fi[k] * fj[0]) + w[NB - 1 + k] * fi[k] * fj[k];
+          acc += v;
+        }
+      }
+      if (ent < 6) S.WB[sl][ent] = acc; else S.G[sl][ent - 6] = acc;
+    }
+  }
+#endif
   // every contact lane scatters its two sides: doW -> body wrenches WB (the gradient), doG -> twist-space Hessians G
   UR5_FN void contact_scatter(const bool doW, const bool doG) {
+#if defined(UR5_MANY) && !defined(UR5_EMUL)
+    contact_gather(doW, doG);
+    return;
+#endif
     PAR(c, S.ncon) {
       v3 ax[3] = {v3(S.cframe[c]), v3(S.cframe[c] + 3), cross(v3(S.cframe[c]), v3(S.cframe[c] + 3))};
       real fb[NB], w[2 * NB - 1];
@@ -2057,7 +2178,9 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     const int nbod = nb();
     // per-body wrench (gradient) and 6x6 twist-space Hessian accumulators: every contact lane scatters its two sides with
     // LDS float atomics (ds_add_f64). Only this wavefront touches these words, so the sums are reproducible run to run.
+#if !defined(UR5_MANY) || defined(UR5_EMUL)
     PAR(idx, nslot() * 27) { int b = idx / 27, ent = idx % 27; if (ent < 6) S.WB[b][ent] = 0; else S.G[b][ent - 6] = 0; }
+#endif
 #ifdef UR5_MANY
     // The Newton Hessian depends on the iterate only through the SET of active rows (D is fixed within a step), so it is
     // piecewise constant: when no row changed state since the previous iteration, the factor in LDS is still the factor
@@ -2406,6 +2529,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     // labelled the ordering is merely less compact -- the envelope below is computed from whatever order results.
     PAR(p2, nblk) S.island[p2] = p2;
     SYNC();
+#ifdef UR5_EMUL
     for (int round = 0; round < 6; round++) {
       PAR(q, S.ncouple) {
         const int c = S.couple[q];
@@ -2415,6 +2539,24 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       }
       SYNC();
     }
+#else
+    // Every round reads the labels of the previous round only (the new ones collect in blk_first, which is initialised further down): the maximum is exact
+    // and order-free, so the labels after each round -- converged or not -- are the same whatever the wavefronts' timing. A label is itself a block of the
+    // island, so label[label[.]] (pointer jumping) is a member too and doubles the reach of a round.
+    for (int round = 0; round < 6; round++) {
+      PAR(p2, nblk) S.blk_first[p2] = S.island[p2];
+      SYNC();
+      PAR(q, S.ncouple) {
+        const int c = S.couple[q];
+        const int ia = S.cA[c] < M.nrd ? nobj : S.cA[c] - M.nrd, ib = S.cB[c] < M.nrd ? nobj : S.cB[c] - M.nrd;
+        const int la = S.island[ia], lb = S.island[ib];
+        if (la < lb) UR5_ATOMIC_MAX(&S.blk_first[ia], lb); else if (lb < la) UR5_ATOMIC_MAX(&S.blk_first[ib], la);
+      }
+      SYNC();
+      PAR(p2, nblk) S.island[p2] = S.blk_first[S.blk_first[p2]];
+      SYNC();
+    }
+#endif
     PAR(k, nobj) {   // order: island, then x
       const real key = S.bpos[M.nrd + k][0];
       const int lab = S.island[k];
@@ -2494,6 +2636,36 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       }
     }
     PAR(p2, nblk) { int o = S.reach_ptr[p2]; for (int q = p2 + 1; q <= S.blk_last[p2]; q++) if (S.blk_first[q] <= p2) S.reach_list[o++] = (short)q; }
+#ifndef UR5_EMUL
+    // chains of the coupled contacts that fill the same coupling block of H (same pair of blocks): envelope_assemble sums along a chain, in contact order
+    PAR(q, S.ncouple) {
+      const int c = S.couple[q];
+      const int pa = blk_of_body(S.cA[c]), pb = blk_of_body(S.cB[c]);
+      S.ckey[q] = (short)(pa < pb ? pa * 64 + pb : pb * 64 + pa);
+    }
+    SYNC();
+    {
+      static_assert(UR5_MAXCON <= UR5_NT && UR5_MAXOBJ + 1 <= 64, "one coupled contact per lane, block pairs as 64 a + b");
+      const int q = UR5_LANE, nc = S.ncouple;
+      bool head = false;
+      if (q < nc) {
+        const int key = S.ckey[q];
+        head = true;
+        for (int j = 0; j < q; j++) if (S.ckey[j] == key) head = false;
+        int nx = -1;
+        for (int j = nc - 1; j > q; j--) if (S.ckey[j] == key) nx = j;
+        S.cnext[q] = (short)nx;
+      }
+      const unsigned long long mask = __ballot(head);
+      if ((UR5_LANE & 63) == 0) S.redi[UR5_LANE >> 6] = __popcll(mask);
+      SYNC();
+      int base = 0, total = 0;
+#pragma unroll
+      for (int w = 0; w < UR5_NT / 64; w++) { if (w < (UR5_LANE >> 6)) base += S.redi[w]; total += S.redi[w]; }
+      if (head) S.chead[base + __popcll(mask & ((1ull << (UR5_LANE & 63)) - 1ull))] = (short)q;
+      if (UR5_LANE == 0) S.nhead = total;
+    }
+#endif
     SYNC();
   }
   // row number c (0 .. nr-1) among the rows below panel p2 that reach it; nrb = number of reaching blocks (only the last can be the 8-wide robot)
@@ -2555,7 +2727,31 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     }
     SYNC();
     PROF(PF_X6);   // zeroing + diagonal blocks (the rest of H_asm is the coupling loop)
-    // coupling blocks: every (contact, entry) pair in parallel, summed with float atomics
+#ifndef UR5_EMUL
+    // coupling blocks: lane (block pair, entry) sums the entry's terms along the pair's chain of contacts (contact order) and adds the total to H once
+    PAR(idx, S.nhead * 64) {
+      const int q0 = S.chead[idx >> 6], ent = idx & 63;
+      const int ky = S.ckey[q0], colblk = ky >> 6, rowblk = ky & 63;
+      const int nr = blk_width(rowblk), ncw = blk_width(colblk);
+      if (ent >= nr * ncw) continue;
+      const int li = ent / ncw, lj = ent - li * ncw;
+      const bool both_robot = rowblk == colblk;   // two robot bodies (finger against finger): the robot's own diagonal block, symmetrised
+      if (both_robot && li < lj) continue;
+      real acc = 0;
+      for (int q = q0; q >= 0; q = S.cnext[q]) {
+        const int c = S.couple[q], A = S.cA[c], B = S.cB[c];
+        real v;
+        if (both_robot) { v = couple_term(c, A, li, B, lj); v = li == lj ? 2 * v : v + couple_term(c, A, lj, B, li); }
+        else if (blk_of_body(A) == rowblk) v = couple_term(c, A, li, B, lj);
+        else v = couple_term(c, A, lj, B, li);
+        acc += v;
+      }
+      if (acc != 0) *hptr<INLDS>(6 * rowblk + li, 6 * colblk + lj) += (double)acc;
+    }
+    SYNC();
+    return;
+#endif
+    // lane emulation: every (contact, entry) pair, one after the other
     PAR(idx, S.ncouple * 64) {
       const int c = S.couple[idx >> 6], ent = idx & 63;
       const int A = S.cA[c], B = S.cB[c];
@@ -3332,7 +3528,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
             case 13:  // :297 to the drop position
               pr.need_ik = true; pr.xyz = v3((real)0.6, 0, (real)1.15); pr.mask = 0x1fu; pr.tol = (real)0.01; pr.max_steps = 1200; slot = 8; break;
             case 14:  // :312-321 closing check at the drop position
-              if (P.check_mode == 0 && result_grasp) { write_target(6, (real)-0.4); pr.mask = 1u << 6; pr.tol = (real)0.01; pr.max_steps = 1000; slot = 9; }
+              if (P.check_mode != 1 && result_grasp) { write_target(6, (real)-0.4); pr.mask = 1u << 6; pr.tol = (real)0.01; pr.max_steps = P.check_mode == 2 ? 100 : 1000; slot = 9; }   // check_mode 2 = demo_mode (:318-321)
               else { pc = 16; chosen = false; }
               break;
             case 15: result_final = last_res; pc = 16; chosen = false; break;
@@ -3350,7 +3546,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
               result = grasped ? 1 : 0;
               if (P.reset_seeds && P.reset_seeds[env] != 0) {
                 SYNC();
-                if (UR5_LANE == 0) { ur5_reset_record(M, P.qpos0, S.rec, P.reset_seeds[env]); S.status = 0; invalidate_pair_cache(); }   // status bits are sticky until a reset: ur5_reset / ur5_reset_dev clear them too
+                if (UR5_LANE == 0) { const real ended = (real)((int)S.rec[UR5_REC_MISC + 7] | S.status); ur5_reset_record(M, P.qpos0, S.rec, P.reset_seeds[env]); S.rec[UR5_REC_MISC + 7] = ended; S.status = 0; invalidate_pair_cache(); }   // the attempt's status bits stay readable (counters: bits 8-15) after the episode reset that follows it in this launch
                 SYNC();
                 pr.mask = mask_all(); pr.tol = (real)1e-7; pr.max_steps = 10; pr.repeat = P.reset_chunks;   // :473 stay(1000)
                 if (pr.repeat <= 0) pr.done = true;
@@ -3544,7 +3740,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
                 case 13:  // :297 to the drop position
                   pr.need_ik = true; pr.xyz = v3((real)0.6, 0, (real)1.15); pr.mask = 0x1fu; pr.tol = (real)0.01; pr.max_steps = 1200; slot = 8; break;
                 case 14:  // :312-321 closing check at the drop position
-                  if (P.check_mode == 0 && result_grasp) { write_target(6, (real)-0.4); pr.mask = 1u << 6; pr.tol = (real)0.01; pr.max_steps = 1000; slot = 9; }
+                  if (P.check_mode != 1 && result_grasp) { write_target(6, (real)-0.4); pr.mask = 1u << 6; pr.tol = (real)0.01; pr.max_steps = P.check_mode == 2 ? 100 : 1000; slot = 9; }   // check_mode 2 = demo_mode (:318-321)
                   else { pc = 16; chosen = false; }
                   break;
                 case 15: result_final = last_res; pc = 16; chosen = false; break;
@@ -3562,7 +3758,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
                   result = grasped ? 1 : 0;
                   if (P.reset_seeds && P.reset_seeds[env] != 0) {
                     SYNC();
-                    if (UR5_LANE == 0) { ur5_reset_record(M, P.qpos0, S.rec, P.reset_seeds[env]); S.status = 0; invalidate_pair_cache(); }   // status bits are sticky until a reset: ur5_reset / ur5_reset_dev clear them too
+                    if (UR5_LANE == 0) { const real ended = (real)((int)S.rec[UR5_REC_MISC + 7] | S.status); ur5_reset_record(M, P.qpos0, S.rec, P.reset_seeds[env]); S.rec[UR5_REC_MISC + 7] = ended; S.status = 0; invalidate_pair_cache(); }   // the attempt's status bits stay readable (counters: bits 8-15) after the episode reset that follows it in this launch
                     SYNC();
                     pr.mask = mask_all(); pr.tol = (real)1e-7; pr.max_steps = 10; pr.repeat = P.reset_chunks;   // :473 stay(1000)
                     if (pr.repeat <= 0) pr.done = true;

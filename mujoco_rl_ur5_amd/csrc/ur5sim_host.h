@@ -649,7 +649,7 @@ int ur5_get_counters(ur5_sim* h, int64_t* c) {
   if (rc) return rc;
   for (int e = 0; e < h->n; e++) {
     const double* r = h->h_rec.data() + (size_t)e * UR5_REC_STRIDE + UR5_REC_MISC;
-    c[6 * e] = (int64_t)r[0]; c[6 * e + 1] = (int64_t)r[1]; c[6 * e + 2] = (int64_t)r[3]; c[6 * e + 3] = (int64_t)r[4]; c[6 * e + 4] = (int64_t)r[5]; c[6 * e + 5] = (int64_t)r[6];
+    c[6 * e] = (int64_t)r[0]; c[6 * e + 1] = (int64_t)r[1]; c[6 * e + 2] = (int64_t)r[3] | ((int64_t)r[7] << 8); c[6 * e + 3] = (int64_t)r[4]; c[6 * e + 4] = (int64_t)r[5]; c[6 * e + 5] = (int64_t)r[6];
   }
   return 0;
 }

@@ -68,7 +68,8 @@ class GraspEnv(object):
         if observation not in ("flat", "render"):
             raise ValueError("observation must be 'flat' or 'render'")
         self.observation_mode = observation
-        self.check_mode = check_mode                                         # 0 = in-tree script, 1 = IT1 (README.md:20)
+        # 0 = in-tree script, 1 = IT1 (README.md:20), 2 = in-tree script in demo mode: close_gripper(max_steps=100) as the final check (:318-321)
+        self.check_mode = 2 if (demo and check_mode == 0) else check_mode
         self.base_seed = base_seed                                           # Grasping_Agent_multidiscrete.py:64
         # multi-rank runs: this handle simulates scenes [first_scene_id, first_scene_id + n_envs) of n_total; seeds are keyed by the
         # GLOBAL scene id (sharding.global_seeds), so a scene's trajectory does not depend on how the batch is sharded

@@ -163,7 +163,9 @@ class BatchSim:
         c = np.zeros((self.n, 6), dtype=np.int64)
         self._check(self.lib.ur5_get_counters(self._h, c.ctypes.data_as(C.POINTER(C.c_int64))), "ur5_get_counters")
         # column 5 is variant-specific (include/ur5sim.h): reused Newton factors (many-object engine) / steps served by the broad phase's pair cache
-        return dict(total_steps=c[:, 0], last_steps=c[:, 1], status=c[:, 2], solver_iters=c[:, 3], ncon_max=c[:, 4], factor_reuse=c[:, 5], cached_broadphase_steps=c[:, 5])
+        # status: bits of the running episode; status_ended: bits raised in episodes that a fused attempt + reset launch has ended since the last host-side reset
+        return dict(total_steps=c[:, 0], last_steps=c[:, 1], status=c[:, 2] & 0xFF, status_ended=(c[:, 2] >> 8) & 0xFF, solver_iters=c[:, 3], ncon_max=c[:, 4],
+                    factor_reuse=c[:, 5], cached_broadphase_steps=c[:, 5])
 
     # ---- dynamics
     def step(self, nsteps=1):

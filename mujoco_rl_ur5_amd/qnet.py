@@ -18,11 +18,43 @@ import torch
 import torch.nn as nn
 
 
+_FORCE_GEMM_1X1 = False          # tests: take the GEMM path on the host too
+
+
+class _BatchNorm2d(nn.BatchNorm2d):
+    """``nn.BatchNorm2d`` (same parameters, buffers and state_dict keys) with a second training-mode behaviour: inside ``per_sample_statistics()``
+    every image is normalised with ITS OWN mean / variance, and the running statistics are left alone.
+
+    Why: the reference never calls ``eval()``; its ``select_action`` (Grasping_Agent_multidiscrete.py:232-299) feeds ONE observation through the
+    network in training mode, so batch norm there normalises with that image's statistics. Batching N scenes through the module as is would mix
+    the scenes' statistics -- a scene's Q map, and its greedy action, would depend on which other scenes share its chunk (and on how scenes are
+    sharded over ranks). Per-image statistics are the exact batched equivalent of N batch-1 training-mode forwards."""
+    per_sample = False
+
+    def forward(self, x):
+        if not (_BatchNorm2d.per_sample and self.training):
+            return super().forward(x)
+        n, c, h, w = x.shape
+        y = nn.functional.batch_norm(x.reshape(1, n * c, h, w), None, None, self.weight.repeat(n), self.bias.repeat(n), True, 0.0, self.eps)
+        return y.view(n, c, h, w)
+
+
+class per_sample_statistics:
+    """Context manager: batch norm layers of this module normalise every image by itself (action selection over a batch of scenes)."""
+
+    def __enter__(self):
+        self._old, _BatchNorm2d.per_sample = _BatchNorm2d.per_sample, True
+
+    def __exit__(self, *exc):
+        _BatchNorm2d.per_sample = self._old
+
+
 def _conv1x1_as_gemm(conv, x):
     """A 1x1 convolution as one batched GEMM over the channel axis (rocBLAS / hipBLASLt): [O, C] x [N, C, H*W] -> [N, O, H*W]. Same parameters as the
     ``nn.Conv2d`` it replaces (checkpoints load unchanged). On the MI355X box MIOpen's immediate mode has no tuned solution for these layers and falls
     back to its naive kernel (``naive_conv_ab_nonpacked_*``: 39 % of the DQN loop's GPU time, profiles/r03_m_dqn_kernel_stats.csv)."""
-    if not x.is_cuda:                    # on the host the reference's own operator (the CPU tests compare a 13-step Adam sequence with the reference to 2e-4)
+    assert conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.dilation == (1, 1) and conv.groups == 1, conv
+    if not (x.is_cuda or _FORCE_GEMM_1X1):   # on the host the reference's own operator (the CPU tests compare a 13-step Adam sequence with the reference to 2e-4)
         return conv(x)
     n, c, h, w = x.shape
     y = torch.matmul(conv.weight.view(conv.out_channels, c), x.reshape(n, c, h * w))
@@ -43,10 +75,10 @@ class BasicBlock(nn.Module):
     def __init__(self, inplanes, planes):
         super().__init__()
         self.conv1 = _conv3x3(inplanes, planes)
-        self.bn1 = nn.BatchNorm2d(planes)
+        self.bn1 = _BatchNorm2d(planes)
         self.relu = nn.ReLU(inplace=True)
         self.conv2 = _conv3x3(planes, planes)
-        self.bn2 = nn.BatchNorm2d(planes)
+        self.bn2 = _BatchNorm2d(planes)
         self.downsample = None
         self.stride = 1
         self.conv3 = nn.Conv2d(inplanes, planes, kernel_size=1, stride=1) if inplanes != planes else None
@@ -167,4 +199,46 @@ class ReplayBuffer:
         picks = self._rng.sample(range(self.count), batch_size - 1) + [last]
         idx = torch.tensor(picks, device=self.device)
         state = torch.cat((self.rgb[idx].float() / 255.0, self.depth[idx].float()), dim=1)
+        if self.shared:
+            # every rank drew the same slots (same python RNG, same ring bookkeeping); a slot's image lives on the rank that simulated the scene.
+            # Each rank contributes the rows it owns, zeros elsewhere; the sum over ranks is the batch -- exact in fp32 (x + 0 + ... + 0).
+            import torch.distributed as dist
+            state = state * self.owned[idx].view(-1, 1, 1, 1).to(state.dtype)
+            if dist.get_backend() != "nccl" and state.is_cuda:      # gloo with several ranks on one GPU (tests): reduce through host memory
+                host = state.cpu()
+                dist.all_reduce(host)
+                state = host.to(self.device)
+            else:
+                dist.all_reduce(state)
         return state, self.action[idx], self.reward[idx]
+
+    # ---- the SHARED replay buffer of a multi-rank job (BASELINE.json north_star: "RCCL ... to all-gather grasp outcomes into the shared replay buffer")
+    # One logical ring for the whole job, in GLOBAL scene order -- exactly the ring a single process simulating all scenes would fill
+    # (Grasping_Agent_multidiscrete.py:551-554 is the single push site). Its bookkeeping (position, count, action, reward: what the gathered 16-byte
+    # outcome records carry) is replicated on every rank; the 280 KB observation of a transition stays on the rank that rendered it (`owned`).
+    shared = False
+
+    def make_shared(self):
+        self.shared = True
+        self.owned = torch.zeros(self.size, dtype=torch.bool, device=self.device)
+        return self
+
+    def push_shared(self, gid0, actions, rewards, local_state, local_lo):
+        """Transitions of the global scenes gid0 .. gid0 + len(actions) - 1 (consecutive ids): actions / rewards of ALL of them (from the gathered
+        outcome records), and the states of the ones this rank simulated -- ``local_state[i]`` belongs to global scene ``local_lo + i``."""
+        n = int(actions.shape[0])
+        drop = max(0, n - self.size)                    # as in push(): n consecutive pushes keep the last `size`
+        if drop:
+            self.position = (self.position + drop) % self.size
+        g = torch.arange(gid0 + drop, gid0 + n, device=self.device)
+        idx = (self.position + torch.arange(n - drop, device=self.device)) % self.size
+        self.action[idx] = actions[drop:].reshape(-1, 1).to(self.device).long()
+        self.reward[idx] = rewards[drop:].reshape(-1, 1).to(self.device).float()
+        mine = (g >= local_lo) & (g < local_lo + local_state.shape[0])
+        self.owned[idx] = mine
+        if bool(mine.any()):
+            st = local_state[(g[mine] - local_lo)]
+            self.rgb[idx[mine]] = (st[:, :3].to(self.device) * 255.0).round().clamp(0, 255).to(torch.uint8)
+            self.depth[idx[mine]] = st[:, 3:4].to(self.device).float()
+        self.position = (self.position + n - drop) % self.size
+        self.count = min(self.size, self.count + n)

@@ -48,3 +48,54 @@ def gather_outcomes(records, device=None):
     out = torch.empty((dist.get_world_size() * t.shape[0], t.shape[1]), dtype=t.dtype, device=t.device)
     dist.all_gather_into_tensor(out, t.contiguous())
     return out
+
+
+def broadcast_from_rank0(t):
+    """In-place broadcast of a tensor from rank 0 (no-op in a single process); gloo with CUDA tensors goes through host memory."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return t
+    if dist.get_backend() != "nccl" and t.is_cuda:
+        h = t.cpu()
+        dist.broadcast(h, 0)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, 0)
+    return t
+
+
+# ------------------------------------------------------------------ random numbers keyed by GLOBAL scene id
+# A generator per rank would hand rank 1's first scene the numbers rank 0's first scene gets: the agent's exploration, depth noise and colour
+# jitter would depend on how the batch is sharded. These draws are a pure function of (seed, global scene id, round, stream, index) instead --
+# SplitMix64's finaliser over a counter, evaluated with torch integer ops on whatever device holds the scene ids -- so N ranks with n scenes each
+# draw exactly what one rank with N n scenes draws (tests/test_sharding.py).
+_M1, _M2, _GOLD = 0xBF58476D1CE4E5B9 - (1 << 64), 0x94D049BB133111EB - (1 << 64), 0x9E3779B97F4A7C15 - (1 << 64)
+
+
+def _lsr(z, k):
+    return (z >> k) & ((1 << (64 - k)) - 1)          # logical shift of an int64 tensor
+
+
+def _mix64(z):
+    z = (z ^ _lsr(z, 30)) * _M1
+    z = (z ^ _lsr(z, 27)) * _M2
+    return z ^ _lsr(z, 31)
+
+
+def scene_uniform(seed, gids, round_index, stream, count, dtype=None):
+    """U[0, 1) draws [len(gids), count] for the scenes with global ids ``gids`` (int64 tensor) in round ``round_index`` of random stream ``stream``."""
+    import torch
+    dtype = dtype or torch.float32
+    key = _mix64(gids.to(torch.int64) * _GOLD + (int(seed) * 0x632BE5AB + int(round_index)) * 0x1000003 + int(stream))       # one 64-bit key per scene
+    z = _mix64(key[:, None] + torch.arange(1, count + 1, dtype=torch.int64, device=gids.device)[None, :] * _GOLD)
+    if dtype == torch.float64:
+        return _lsr(z, 11).to(torch.float64) * (1.0 / 9007199254740992.0)
+    return _lsr(z, 40).to(torch.float32) * (1.0 / 16777216.0)
+
+
+def scene_normal(seed, gids, round_index, stream, count):
+    """N(0, 1) draws [len(gids), count], float32 (Box-Muller on two uniform streams)."""
+    import math
+    import torch
+    u = scene_uniform(seed, gids, round_index, stream, 2 * count)
+    return torch.sqrt(-2.0 * torch.log(1.0 - u[:, :count])) * torch.cos((2.0 * math.pi) * u[:, count:])

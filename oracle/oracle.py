@@ -41,6 +41,7 @@ def lib():
             getattr(L, f).restype = C.c_long
         L.ur5o_set_options.argtypes = [vp, C.c_int, C.c_double, C.c_int]
         L.ur5o_set_solver_limits.argtypes = [vp, C.c_int, C.c_double]
+        L.ur5o_set_contact_order.argtypes = [vp, C.c_int]
         L.ur5o_primal_cost.argtypes = [vp, dp, dp, dp]
         L.ur5o_get_state.argtypes = [vp, dp, dp, dp, dp]
         L.ur5o_set_state.argtypes = [vp, dp, dp, dp, dp]
@@ -120,6 +121,10 @@ class Oracle:
     def set_solver_limits(self, iterations=0, tolerance=-1.0):
         """Override the model's solver iteration cap / tolerance (0 / negative: the model's own)."""
         lib().ur5o_set_solver_limits(self._h, int(iterations), float(tolerance))
+
+    def set_contact_order(self, mode):
+        """Test hook: 0 = contacts in geom-pair order, 1 = the same contacts reversed (a rounding-level perturbation of every sum over contacts)."""
+        lib().ur5o_set_contact_order(self._h, int(mode))
 
     def primal_cost(self, qacc):
         """(cost, |gradient|) of the constraint QP of the last forward() at the acceleration `qacc`."""

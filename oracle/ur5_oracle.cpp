@@ -977,7 +977,11 @@ struct Sim {
       else if (t1 == GEOM_BOX && t2 == GEOM_BOX) collide_box_box(g1, g2, margin);
       else collide_convex(g1, g2, margin);
     }
+    // test hook (ur5o_set_contact_order): the same contact SET in reversed order. Mathematically the same step; every sum over contacts associates
+    // differently, i.e. a last-bit perturbation -- what tools/pile_chaos_floor.py uses to measure how far a pile attempt amplifies rounding.
+    if (contact_order == 1) std::reverse(contacts.begin(), contacts.end());
   }
+  int contact_order = 0;
 
   // ------------------------------------------------------------------ constraint rows  [3P, SURVEY C.4]
   static double powr(double x, double p) { return p == 2.0 ? x * x : std::pow(x, p); }   // p = 2 is MuJoCo's default
@@ -1633,7 +1637,8 @@ struct Sim {
   }
 
   // GraspingEnv.py:205-386. check_mode 0 = in-tree script (IT2+: check after moving to the drop position, 1000 steps);
-  // check_mode 1 = IT1 (README.md:20): lift straight up, close_gripper(max_steps=500), then carry on.
+  // check_mode 1 = IT1 (README.md:20): lift straight up, close_gripper(max_steps=500), then carry on;
+  // check_mode 2 = the in-tree script with demo_mode=True (GraspingEnv.py:318-321): the check at the drop position lasts 100 steps.
   // phase_steps[12] receives last_movement_steps of each scripted movement (0 when skipped).
   int grasp_attempt(const double* coordinates, int rotation, int check_mode, double table_height, int* phase_steps, int* phase_result) {
     static const double rot_deg[6] = {0, 30, 60, 90, -30, -60};  // GraspingEnv.py:40
@@ -1681,8 +1686,8 @@ struct Sim {
     double cd[3] = {0.6, 0.0, 1.15};
     phase_result[8] = move_ee(cd, 0.01, 1200);                  // :297
     phase_steps[8] = last_steps;
-    if (check_mode == 0 && result_grasp) {                      // :312-321
-      result_final = close_gripper(1000);
+    if (check_mode != 1 && result_grasp) {                      // :312-321 (check_mode 2 = demo_mode: close_gripper(max_steps=100))
+      result_final = close_gripper(check_mode == 2 ? 100 : 1000);
       phase_steps[9] = last_steps; phase_result[9] = result_final;
     }
     bool grasped = (result_final == RES_MAX_STEPS) && result_grasp;  // :327
@@ -1749,6 +1754,7 @@ void ur5o_destroy(void* h) { delete (Sim*)h; }
 int ur5o_nq(void* h) { return ((Sim*)h)->nq; }
 int ur5o_nv(void* h) { return ((Sim*)h)->nv; }
 int ur5o_nu(void* h) { return ((Sim*)h)->nu; }
+void ur5o_set_contact_order(void* h, int mode) { ((Sim*)h)->contact_order = mode; }
 void ur5o_set_options(void* h, int contacts_enabled, double pid_dt, int solver) {
   Sim* s = (Sim*)h;
   s->contacts_enabled = contacts_enabled;

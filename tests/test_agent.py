@@ -55,8 +55,12 @@ def test_agent_rounds_on_cpu(model_it1, emul_lib):
     agent.eps_start = agent.eps_end = 0.0                                   # greedy: argmax of the Q maps
     action, greedy = agent.epsilon_greedy(state, obs)
     with torch.no_grad():
-        q = agent.policy_net(state)
-    assert greedy.all() and int(action[1]) == int(q[1].reshape(-1).argmax())
+        q1 = agent.policy_net(state[1:2])                                   # the reference's select_action: ONE observation, network in training mode (:232-299)
+    assert greedy.all() and int(action[1]) == int(q1.reshape(-1).argmax())
+    # ... and a scene's Q map does not depend on which scenes share its forward pass (batch norm with per-image statistics, qnet.per_sample_statistics)
+    v2, i2 = agent._q_all(state)
+    v1, i1 = agent._q_all(state, chunk=1)
+    assert torch.equal(i1, i2) and torch.allclose(v1, v2, atol=1e-6) and abs(float(v2[1]) - float(q1.max())) < 1e-6
     agent.eps_start = agent.eps_end = 1.0
     losses = []
     for r in range(2 * BATCH_SIZE // 2 + 1):

@@ -334,6 +334,45 @@ def test_pile_grasp_bits_against_the_oracle_on_gpu(model_many):
     assert bits >= n - 3 and codes >= n - 6, (bits, codes, rew[sel].tolist(), orew)   # piles are chaotic: 95-97 % agreement per scene in the 256-scene run
 
 
+@pytest.mark.gpu
+def test_pile_kernel_is_run_to_run_deterministic_on_gpu(model_many):
+    """The reference is one thread of MuJoCo: same state, same result (MujocoController.py:379). ur5m_run_kernel spreads a scene over four wavefronts;
+    since round 4 its contacts are sorted into geom-pair order and every sum over contacts (body wrenches, twist-space Hessians, coupling blocks) runs
+    along fixed lists instead of LDS float atomics, so nothing depends on how the wavefronts were scheduled: the settle of 256 piles (500 steps of falling,
+    colliding objects) and a whole grasp round, each run twice from the same records, must agree in EVERY word -- rewards, the 12 phase step counts and result
+    codes, and the full state records including the solver-iteration and step counters. (CPU twin: tests/test_engine_simt.py permutes the lane schedule.)"""
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    from pile_aim import pick_box
+    n = 256
+    sim = BatchSim(model_many, n)
+    seeds = 500 + np.arange(n, dtype=np.uint64)
+    sim.reset(seeds, 1, 1000.0)
+    rec_a = sim.state_tensor("cuda").clone()
+    sim.reset(seeds, 1, 1000.0)
+    torch.cuda.synchronize()
+    assert torch.equal(rec_a, sim.state_tensor("cuda")), "two settles of the same seeds differ"
+    st = sim.get_state()
+    acts, rots = np.zeros((n, 3)), np.arange(n) % 6
+    acts[:] = [0.0, -0.6, 1.0]
+    for e in range(n):
+        b = pick_box(model_many, st["qpos"][e])
+        if b is not None:
+            acts[e], rots[e] = b[1], b[2]
+    runs = []
+    for _ in range(2):
+        sim.state_tensor("cuda").copy_(rec_a)
+        torch.cuda.synchronize()
+        rew, ps, pr = sim.grasp_attempt(acts, rot=rots, check_mode=0)
+        torch.cuda.synchronize()
+        runs.append((rew.copy(), ps.copy(), pr.copy(), sim.state_tensor("cuda").clone().cpu().numpy().view(np.uint64)))
+    (r0, s0, c0, q0), (r1, s1, c1, q1) = runs
+    assert sim.counters()["status"].max() == 0
+    assert r0.sum() >= 3                                                       # a round with successes in it
+    differing = int(np.any(q0 != q1, axis=1).sum())
+    assert np.array_equal(r0, r1) and np.array_equal(s0, s1) and np.array_equal(c0, c1) and differing == 0, (differing, int((r0 != r1).sum()))
+
+
 # ------------------------------------------------------------------ arm-link collision hulls (DESIGN.md D5)
 ARM_MESHES = ("base", "shoulder", "upperarm", "forearm", "wrist1", "wrist2", "wrist3")
 

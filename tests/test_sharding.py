@@ -82,6 +82,71 @@ def test_two_rank_gloo_gather_equals_single_process(emul_lib, model_it1, tmp_pat
     assert got[16:].astype(int).tolist() == ps[:2].ravel().tolist()       # rank 0's scenes: same step counts as the 1-rank run
 
 
+def _agent_worker(rank, world, port, emul_lib, out, n_total, rounds):
+    """One rank of the config-5 loop (mujoco_rl_ur5_amd/agent.py) on the lane-emulation engine with host tensors."""
+    import hashlib
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from mujoco_rl_ur5_amd.agent import BatchedGraspAgent
+    from mujoco_rl_ur5_amd.envs import GraspEnv
+    from mujoco_rl_ur5_amd.model import load_model
+    torch.set_num_threads(1)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = sharding.shard_range(n_total, rank, world)
+    env = GraspEnv(file=load_model("it1_4box"), n_envs=hi - lo, first_scene_id=lo, n_total=n_total, show_obs=False, observation="render",
+                   image_width=24, image_height=24, check_mode=1, _lib_path=emul_lib)
+    env.reset()
+    agent = BatchedGraspAgent(env=env, device="cpu", mem_size=40, eps_start=0.5, eps_end=0.5, max_updates_per_round=4)
+    assert agent.memory.shared == (world > 1)
+    losses, recs, greedy = [], [], []
+    for _ in range(rounds):
+        o = agent.round()
+        losses += o["losses"]
+        recs.append(o["outcomes"].numpy().copy())
+        greedy.append(o["greedy"].numpy().copy())
+    w = torch.cat([p.detach().reshape(-1) for p in agent.policy_net.parameters()] + [b.detach().reshape(-1).float() for b in agent.policy_net.buffers()])
+    digest = hashlib.sha256(w.numpy().tobytes()).hexdigest()
+    res = dict(rank=rank, losses=losses, recs=np.stack(recs), digest=digest, greedy=np.concatenate(greedy), updates=agent.learner.updates_done,
+               ring=(agent.memory.position, agent.memory.count), owned=int(agent.memory.owned.sum()) if world > 1 else -1)
+    if world > 1:
+        parts = [None] * world
+        dist.all_gather_object(parts, res)
+        dist.barrier()
+    else:
+        parts = [res]
+    if rank == 0:
+        import pickle
+        with open(out, "wb") as f:
+            pickle.dump(parts, f)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_are_one_agent(emul_lib, tmp_path):
+    """BASELINE.json config 5 / north_star: "RCCL ... to all-gather grasp outcomes into the shared replay buffer". The reference has ONE push-then-learn site
+    (Grasping_Agent_multidiscrete.py:551-556) and one network (:388-446). Two gloo ranks with 4 scenes each must BE the agent that one process with 8 scenes
+    is: same outcome records in every round (exploration, jitter and depth noise are keyed by global scene id; action selection normalises per image), the
+    same loss sequence from the shared replay ring, bit-identical weights on both ranks -- and those equal to the single process's."""
+    import pickle
+    import torch.multiprocessing as mp
+    port = 29500 + (os.getpid() % 2000) + 7
+    one, two = str(tmp_path / "one.pkl"), str(tmp_path / "two.pkl")
+    n_total, rounds = 8, 6                                                    # learning starts once 24 transitions are stored: rounds 3, 4, 5 learn
+    mp.spawn(_agent_worker, args=(1, port, emul_lib, one, n_total, rounds), nprocs=1, join=True)
+    mp.spawn(_agent_worker, args=(2, port + 1, emul_lib, two, n_total, rounds), nprocs=2, join=True)
+    (a,), (b0, b1) = pickle.load(open(one, "rb")), pickle.load(open(two, "rb"))
+    assert a["updates"] == b0["updates"] == b1["updates"] >= 9 and len(a["losses"]) == a["updates"]
+    assert np.array_equal(b0["recs"], b1["recs"]) and np.array_equal(a["recs"], b0["recs"])       # [rounds, 8, 4]: id, pixel, rotation, reward
+    assert a["recs"][:, :, 0].tolist() == [list(range(8))] * rounds and a["greedy"].any() and not a["greedy"].all()
+    assert b0["losses"] == b1["losses"] == a["losses"]                                            # one learner: the same optimiser steps everywhere
+    assert b0["digest"] == b1["digest"] == a["digest"]                                            # bit-identical weights (and batch-norm buffers)
+    assert b0["ring"] == b1["ring"] == a["ring"] and b0["owned"] + b1["owned"] == min(40, n_total * rounds)   # every slot's image lives on exactly one rank
+
+
 def _gpu_worker(rank, world, port, n_total, out):
     """One rank of the real multi-GPU path, except that every rank sits on device 0 (the test box has one GPU) and the collective runs over
     gloo: bench.py's round driver on the rank's shard with the real libur5sim.so."""

@@ -1,0 +1,9 @@
+#!/bin/bash
+# round 4, first GPU call: parity tests, the deterministic pile kernel (twice-run check at 3072 piles + states for the CPU-side chaos floor), same-box A/B
+# against the round-3 kernel, per-phase cycles of the pile step
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/r04_a_pytest_gpu.log 2>&1; echo "pytest rc $?" >> gpurun_out/r04_a_pytest_gpu.log
+tail -5 gpurun_out/r04_a_pytest_gpu.log
+timeout 600 python tools/gpu_many_dump.py 3072 256 gpurun_out/r04_many_states.npz > gpurun_out/r04_a_many_dump.json 2> gpurun_out/r04_a_many_dump.err; cat gpurun_out/r04_a_many_dump.json
+timeout 600 tools/gpu_ab_many.sh r04a 512 1 tools/libur5sim_r03.so
+UR5_PROF_LIB=tools/libur5sim_prof.so timeout 600 python tools/gpu_profile_phases.py 256 many > gpurun_out/r04_a_many_phase_cycles_256piles.log 2>&1; tail -30 gpurun_out/r04_a_many_phase_cycles_256piles.log
