@@ -263,9 +263,11 @@ class BatchedGraspAgent:
         return self.last_loss
 
     # ------------------------------------------------------------------ one round of the episode loop (:540-560)
-    def round(self, learn=True):
-        """observe -> act -> grasp -> store -> learn, for every scene of this rank; outcomes gathered over ranks (X1)."""
+    def round(self, learn=True, return_observation=False):
+        """observe -> act -> grasp -> store -> learn, for every scene of this rank; outcomes gathered over ranks (X1).
+        return_observation: also hand back copies of the raw observation the actions were chosen in (what generate_data.py stores)."""
         obs = self.env.observation_device(self.device)
+        raw = {k: v.clone() for k, v in obs.items()} if return_observation else None
         state = self.transform_observation(obs)
         action, greedy = self.epsilon_greedy(state, obs)
         env_action = self.transform_action(action)
@@ -276,5 +278,5 @@ class BatchedGraspAgent:
                                                   first_scene_id=self.first_scene_id, n_actions_1=self.n_actions_1)   # :551-556
         self.last_loss = losses[-1] if losses else None
         self.rounds_done += 1
-        return {"reward": reward, "skipped": skipped, "greedy": greedy, "loss": self.last_loss if learn else None, "losses": losses,
+        return {"observation": raw, "action": action, "reward": reward, "skipped": skipped, "greedy": greedy, "loss": self.last_loss if learn else None, "losses": losses,
                 "update_to_data": utd, "outcomes": outcomes, "epsilon": self.eps_threshold}

@@ -181,6 +181,9 @@ template <int W, class T> __device__ __forceinline__ T ur5_wave_max(T v) {   // 
 enum { PF_KIN = 0, PF_CRB, PF_VEL, PF_BROAD, PF_NARROW, PF_ROWS, PF_NEWTON_INIT, PF_IMAGES, PF_LINESEARCH, PF_GRADG, PF_HASM, PF_CHOL, PF_SOLVE,
        PF_INTEGRATE, PF_PID, PF_IK, PF_CORECLK, PF_REALCLK, PF_X0, PF_X1, PF_X2, PF_X3, PF_X4, PF_X5, PF_X6, PF_X7, PF_COUNT };   // PF_X7: MPR pairs (count, not cycles)   // the last two: start / end of the scene's wave in 100 MHz ticks (s_memrealtime)
 
+#ifndef UR5_FORCE_GLOBAL_ENV
+#define UR5_FORCE_GLOBAL_ENV 0   // experiment: 1 = the envelope always lives in the scene's global-memory scratch (what a smaller LDS image would cost)
+#endif
 #ifndef UR5_SUP_K
 #define UR5_SUP_K 4   // hull vertices per lane and trip of the cooperative support scan
 #endif
@@ -357,14 +360,14 @@ template <class real, int NV_> struct Lds {
   real red[3 * 16];                                  // cross-wave reductions
   int redi[16];
   // Fixed-order accumulation (round 4): four wavefronts share a scene, so LDS float atomics would land in an order that changes from run to
-  // run. Instead every body slot owns the list of its contact sides (2 c + side, in contact order) and every Hessian coupling block the chain of
-  // its contacts; sums run along these lists, so a scene's results do not depend on how its wavefronts are scheduled (MujocoController.py:379
-  // is one deterministic thread).
-  static constexpr int NCH = (UR5_MAXCON + 31) / 32;    // contact chunks of the list construction: one (slot, chunk) item per lane
-  short csl[UR5_MAXCON][2];                          // accumulator slot of a contact's two bodies (-1: static side)
-  short side_list[2 * UR5_MAXCON], side_cnt[NSLOT * NCH], slot_tot[NSLOT], slot_ptr[NSLOT + 1];
-  short ckey[UR5_MAXCON], cnext[UR5_MAXCON], chead[UR5_MAXCON];   // per coupled contact: block pair, next contact of the same pair; first contacts of the pairs
-  int nhead;
+  // run. Instead every body slot owns the list of its contact sides (2 c + side, in contact order): the contact lanes stage their terms, the slot's
+  // lanes sum them along the list; every Hessian coupling block is owned by one wavefront, which adds its contacts' terms in contact order. A scene's
+  // results then do not depend on how its wavefronts are scheduled (MujocoController.py:379 is one deterministic thread).
+  short csl[UR5_MAXCON][2];                          // accumulator slot of a contact's two bodies (-1: static side); flat index = side id 2 c + side
+  short side_list[2 * UR5_MAXCON], slot_ptr[NSLOT + 1];
+  unsigned char slot_cnt[UR5_NT / 64][NSLOT + 1];    // sides of a slot held by the lanes of each wavefront (list construction)
+  short ckey[UR5_MAXCON];                            // per coupled contact: its pair of Hessian blocks, 64 * smaller + larger
+  short wlist[UR5_MAXCON], wptr[UR5_NT / 64 + 1];    // the coupled contacts grouped by the wavefront that owns their block pair, contact order inside a group
 
 #endif
   // dynamics vectors (dof space)
@@ -412,7 +415,11 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
 #ifdef UR5_EMUL
   static constexpr bool FLAT = true;
 #else
+#ifdef UR5_MANY_SPLIT_PHASES      // experiment: the many-object kernel with its phases as real functions (own register allocation each), like the wavefront-per-scene kernel
+  static constexpr bool FLAT = false;
+#else
   static constexpr bool FLAT = GS_ != 64;
+#endif
 #endif
   typedef Lds<real, NV_> L;
   typedef V3<real> v3;
@@ -1687,30 +1694,43 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     if constexpr (NB > 4) { e[NB - 2] = dot(t1, w); e[NB - 1] = dot(t2, w); }
   }
 #if defined(UR5_MANY) && !defined(UR5_EMUL)
-  // side lists: for every accumulator slot the contact sides (2 c + side) that act on its body, in contact order. Lane (slot, chunk) counts the sides of
-  // its 32 contacts, a two-level prefix sum places them, the same lane writes them: a counting sort whose result does not depend on any schedule.
+  // side lists: for every accumulator slot the contact sides (side id 2 c + side) that act on its body, in contact order. Lane = side id, so a counting sort
+  // by slot that keeps lane order is a stable sort: one ballot per slot gives every side its rank among the same-slot sides of its wavefront, the wavefronts'
+  // counts per slot (LDS) give the offsets. Schedule-free: ballots and integer sums only.
   UR5_FN void build_side_lists() {
-    constexpr int NCH = L::NCH;
-    static_assert(L::NSLOT * NCH <= UR5_NT, "one (slot, chunk) item per lane");
-    const int ns = nslot(), item = UR5_LANE, sl = item / NCH, ch = item - sl * NCH;
-    const int c0 = 32 * ch, c1 = c0 + 32 < S.ncon ? c0 + 32 : S.ncon;
-    int cnt = 0;
-    if (sl < ns) {
-      for (int c = c0; c < c1; c++) cnt += (S.csl[c][0] == sl ? 1 : 0) + (S.csl[c][1] == sl ? 1 : 0);
-      S.side_cnt[item] = (short)cnt;
-    }
-    SYNC();
-    if (UR5_LANE < ns) { int t = 0; for (int k = 0; k < NCH; k++) t += S.side_cnt[UR5_LANE * NCH + k]; S.slot_tot[UR5_LANE] = (short)t; }
-    SYNC();
-    if (sl < ns) {
-      int o = 0;
-      for (int q = 0; q < sl; q++) o += S.slot_tot[q];
-      if (ch == 0) { S.slot_ptr[sl] = (short)o; if (sl == ns - 1) S.slot_ptr[ns] = (short)(o + S.slot_tot[sl]); }
-      for (int k = 0; k < ch; k++) o += S.side_cnt[sl * NCH + k];
-      for (int c = c0; c < c1; c++) {
-        if (S.csl[c][0] == sl) S.side_list[o++] = (short)(2 * c);
-        if (S.csl[c][1] == sl) S.side_list[o++] = (short)(2 * c + 1);
+    static_assert(2 * UR5_MAXCON <= 2 * UR5_NT, "at most two rounds of one side per lane");
+    const short* key = &S.csl[0][0];
+    const int ns2 = 2 * S.ncon, nsl = nslot(), wv = UR5_LANE >> 6, wl = UR5_LANE & 63;
+    int carry_round = 0;                                                     // sides of my slot placed by earlier rounds (only for > UR5_NT sides)
+    for (int r0 = 0; r0 == 0 || r0 < ns2; r0 += UR5_NT) {
+      const int sd = r0 + UR5_LANE;
+      const int my = sd < ns2 ? (int)key[sd] : -1;
+      int rank = 0;
+      for (int sl = 0; sl < nsl; sl++) {
+        const unsigned long long m = __ballot(my == sl);
+        if (my == sl) rank = __popcll(m & ((1ull << wl) - 1ull));
+        if (wl == 0) S.slot_cnt[wv][sl] = (unsigned char)__popcll(m);
       }
+      SYNC();
+      if (r0 == 0) {
+        PAR(sl, nsl + 1) {                                                   // first round: the slots' offsets need the totals of ALL rounds -> count the sides beyond this round directly
+          int cnt = 0;
+          for (int q = 0; q < sl; q++) for (int w = 0; w < UR5_NT / 64; w++) cnt += S.slot_cnt[w][q];
+          for (int j = UR5_NT; j < ns2; j++) cnt += (key[j] >= 0 && key[j] < sl) ? 1 : 0;
+          S.slot_ptr[sl] = (short)cnt;
+        }
+        SYNC();
+      }
+      if (my >= 0) {
+        int o = S.slot_ptr[my] + carry_round + rank;
+        for (int w = 0; w < wv; w++) o += S.slot_cnt[w][my];
+        S.side_list[o] = (short)sd;
+      }
+      if (r0 + UR5_NT >= ns2) break;
+      SYNC();
+      // (more than UR5_NT sides: never seen on the reference's piles, 80 contacts at most) the next round's sides of a slot go behind this round's
+      { int t = 0; const int mine = (r0 + UR5_NT + UR5_LANE) < ns2 ? (int)key[r0 + UR5_NT + UR5_LANE] : -1; if (mine >= 0) for (int w = 0; w < UR5_NT / 64; w++) t += S.slot_cnt[w][mine]; carry_round += t; }
+      SYNC();
     }
   }
 #endif
@@ -2079,46 +2099,76 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     return v;
   }
 #if defined(UR5_MANY) && !defined(UR5_EMUL)
-  // component g of the 6-vector [r x a ; a]
-  UR5_FN static real wrench_comp(v3 r, v3 a, int g) { const v3 cr = cross(r, a); return g < 3 ? cr[g] : a[g - 3]; }
-  // The many-object kernel GATHERS: lane (slot, entry) walks the slot's side list (contact order) and writes one entry of the body's wrench WB (entries 0-5) or of
-  // its twist-space Hessian G (6-26). Same terms as the scatter below, summed in an order that no wavefront schedule can change; every entry of every slot
-  // is written, so nothing has to be zeroed first. The lanes of a slot read the same contact (LDS broadcasts) and recompute its weights.
+  // The many-object kernel STAGES and GATHERS instead of scattering with atomics: the contact lanes compute exactly the terms of the scatter below and store them
+  // per side -- wrench terms [side][6] in the panel area (only the factorisation uses it), Hessian terms [side][21] in the envelope area (G is only built when the
+  // envelope is about to be re-assembled) --, then lane (slot, entry) adds its slot's sides in list order = contact order. No float atomic, no dependence on the
+  // wavefronts' timing; every entry of every slot is written, so nothing is zeroed first. Contacts are staged UR5_GCHUNK at a time (a settled pile has 40-80).
+  static constexpr int GCHUNK = UR5_HENV_CAP / 42 < 1 ? 1 : (UR5_HENV_CAP / 42 < UR5_MAXCON ? UR5_HENV_CAP / 42 : UR5_MAXCON);
+  static_assert(2 * UR5_MAXCON * 6 <= NV_ * UR5_MAXRD, "the panel area holds the staged wrench terms of every side");
   UR5_FN void contact_gather(const bool doW, const bool doG) {
-    PAR(idx, nslot() * 27) {
-      const int sl = idx / 27, ent = idx - 27 * sl;
-      if (ent < 6 ? !doW : !doG) continue;
-      int gi = 0, gj = 0;
-      if (ent >= 6) { const int e = ent - 6; while ((gi + 1) * (gi + 2) / 2 <= e) gi++; gj = e - gi * (gi + 1) / 2; }
-      const v3 ref = body_ref(body_of_slot(sl));
-      real acc = 0;
-      for (int o = S.slot_ptr[sl]; o < S.slot_ptr[sl + 1]; o++) {
-        const int sd = S.side_list[o], c = sd >> 1;
+    real* const stW = &S.panel[0][0];
+    real* const stG = reinterpret_cast<real*>(S.henv);
+    const int chunk = doG ? GCHUNK : UR5_MAXCON;
+    for (int c0 = 0; c0 == 0 || c0 < S.ncon; c0 += chunk) {
+      const int c1 = c0 + chunk < S.ncon ? c0 + chunk : S.ncon;
+      for (int sd = 2 * c0 + UR5_LANE; sd < 2 * c1; sd += GS) {          // one lane per SIDE: the two sides of a contact recompute its weights, and finish in half the time
+        const int c = sd >> 1, side = sd & 1;
+        const int b = side == 0 ? S.cA[c] : S.cB[c];
+        if (b < 0) continue;
         v3 ax[3] = {v3(S.cframe[c]), v3(S.cframe[c] + 3), cross(v3(S.cframe[c]), v3(S.cframe[c] + 3))};
         real fb[NB], w[2 * NB - 1];
         contact_weights(c, fb, w);
-        const v3 r = v3(S.cpos[c]) - ref;
-        if (ent < 6) {
-          const real sg = (sd & 1) ? (real)1 : (real)-1;
-          const v3 F = ax[0] * fb[0] + ax[1] * fb[1] + ax[2] * fb[2];
+        const real sg = side == 0 ? (real)-1 : (real)1;
+        const v3 r = v3(S.cpos[c]) - body_ref(b);
+        if (doW) {
+          v3 F = ax[0] * fb[0] + ax[1] * fb[1] + ax[2] * fb[2];
           v3 T = ax[0] * fb[3];
           if constexpr (NB > 4) T = T + ax[1] * fb[NB - 2] + ax[2] * fb[NB - 1];
-          acc += sg * (ent < 3 ? (cross(r, F) + T)[ent] : F[ent - 3]);
-        } else {
-          // F_k (6-vector [rot; lin]): k<3 -> [r x a_k ; a_k], k>=3 -> [a_{k-3} ; 0];  G_ij = sum_kl W_kl F_k[i] F_l[j] (arrow-shaped W)
-          real fi[NB], fj[NB];
-#pragma unroll
-          for (int k = 0; k < 3; k++) {
-            fi[k] = wrench_comp(r, ax[k], gi); fj[k] = wrench_comp(r, ax[k], gj);
-            if (3 + k < NB) { fi[3 + k] = gi < 3 ? ax[k][gi] : (real)0; fj[3 + k] = gj < 3 ? ax[k][gj] : (real)0; }
-          }
-          real v = w[0] * fi[0] * fj[0];
-#pragma unroll
-          for (int k = 1; k < NB; k++) v += w[k] * (fi[0] * fj[k] + fi[k] * fj[0]) + w[NB - 1 + k] * fi[k] * fj[k];
-          acc += v;
+          const v3 Mo = cross(r, F) + T;
+          real* o = stW + 6 * sd;
+          o[0] = sg * Mo.x; o[1] = sg * Mo.y; o[2] = sg * Mo.z; o[3] = sg * F.x; o[4] = sg * F.y; o[5] = sg * F.z;
         }
+        if (!doG) continue;
+        // F_k (6-vector [rot; lin]): k<3 -> [r x a_k ; a_k], k>=3 -> [a_{k-3} ; 0];  G += sum_kl W_kl F_k F_l^T (arrow-shaped W)
+        real Fk[NB][6];
+        for (int k = 0; k < 3; k++) {
+          v3 ra = cross(r, ax[k]);
+          Fk[k][0] = ra.x; Fk[k][1] = ra.y; Fk[k][2] = ra.z; Fk[k][3] = ax[k].x; Fk[k][4] = ax[k].y; Fk[k][5] = ax[k].z;
+          if (3 + k < NB) { Fk[3 + k][0] = ax[k].x; Fk[3 + k][1] = ax[k].y; Fk[3 + k][2] = ax[k].z; Fk[3 + k][3] = 0; Fk[3 + k][4] = 0; Fk[3 + k][5] = 0; }
+        }
+        real* o = stG + 21 * (sd - 2 * c0);
+        int ent = 0;
+        for (int gi = 0; gi < 6; gi++)
+          for (int gj = 0; gj <= gi; gj++, ent++) {
+            real v = w[0] * Fk[0][gi] * Fk[0][gj];
+            for (int k = 1; k < NB; k++) v += w[k] * (Fk[0][gi] * Fk[k][gj] + Fk[k][gi] * Fk[0][gj]) + w[NB - 1 + k] * Fk[k][gi] * Fk[k][gj];
+            o[ent] = v;
+          }
       }
-      if (ent < 6) S.WB[sl][ent] = acc; else S.G[sl][ent - 6] = acc;
+      SYNC();
+      PAR(idx, nslot() * 27) {
+        const int sl = idx / 27, ent = idx - 27 * sl;
+        if (ent < 6 ? !doW : !doG) continue;
+        real acc = c0 == 0 ? (real)0 : (ent < 6 ? S.WB[sl][ent] : S.G[sl][ent - 6]);      // later rounds continue the sum where the previous one stopped
+        const int o1 = S.slot_ptr[sl + 1];
+        const real* const st = ent < 6 ? stW + ent : stG + (ent - 6) - 42 * c0;
+        const int stride = ent < 6 ? 6 : 21;
+        // a slot's list is in contact order and the rounds take consecutive runs of it; four sides per trip, their loads issued together (the sum keeps list order:
+        // a side outside the round or past the end contributes an exact zero)
+        for (int o = S.slot_ptr[sl]; o < o1; o += 4) {
+          int sd[4];
+          real v[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) sd[k] = S.side_list[o + k < o1 ? o + k : o1 - 1];
+#pragma unroll
+          for (int k = 0; k < 4; k++) { const int c = sd[k] >> 1; v[k] = (o + k < o1 && c >= c0 && c < c1) ? st[stride * sd[k]] : (real)0; }
+          acc = ((acc + v[0]) + v[1]) + v[2];
+          acc += v[3];
+        }
+        if (ent < 6) S.WB[sl][ent] = acc; else S.G[sl][ent - 6] = acc;
+      }
+      if (c1 >= S.ncon) break;
+      SYNC();
     }
   }
 #endif
@@ -2613,7 +2663,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     PAR(i, nv) {
       const int p2 = i < 6 * nobj ? i / 6 : nobj, j = i - 6 * p2, f = 6 * (p2 - S.blk_first[p2]);
       S.env_ptr[i] = S.blk_ptr[p2] + j * f + j * (j + 1) / 2;
-      if (i == nv - 1) { const int tot = S.env_ptr[i] + f + j + 1; S.env_ptr[nv] = tot; S.env_inlds = tot <= UR5_HENV_CAP; }
+      if (i == nv - 1) { const int tot = S.env_ptr[i] + f + j + 1; S.env_ptr[nv] = tot; S.env_inlds = tot <= UR5_HENV_CAP && !UR5_FORCE_GLOBAL_ENV; }
     }
     PAR(l, S.nlvl + 1) {   // panels with a lower level come first: lvl_ptr[l] = their number
       int o = 0;
@@ -2637,33 +2687,34 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     }
     PAR(p2, nblk) { int o = S.reach_ptr[p2]; for (int q = p2 + 1; q <= S.blk_last[p2]; q++) if (S.blk_first[q] <= p2) S.reach_list[o++] = (short)q; }
 #ifndef UR5_EMUL
-    // chains of the coupled contacts that fill the same coupling block of H (same pair of blocks): envelope_assemble sums along a chain, in contact order
-    PAR(q, S.ncouple) {
-      const int c = S.couple[q];
-      const int pa = blk_of_body(S.cA[c]), pb = blk_of_body(S.cB[c]);
-      S.ckey[q] = (short)(pa < pb ? pa * 64 + pb : pb * 64 + pa);
-    }
-    SYNC();
+    // the pair of Hessian blocks every coupled contact adds to (envelope_assemble: a block pair is owned by ONE wavefront)
     {
-      static_assert(UR5_MAXCON <= UR5_NT && UR5_MAXOBJ + 1 <= 64, "one coupled contact per lane, block pairs as 64 a + b");
-      const int q = UR5_LANE, nc = S.ncouple;
-      bool head = false;
-      if (q < nc) {
-        const int key = S.ckey[q];
-        head = true;
-        for (int j = 0; j < q; j++) if (S.ckey[j] == key) head = false;
-        int nx = -1;
-        for (int j = nc - 1; j > q; j--) if (S.ckey[j] == key) nx = j;
-        S.cnext[q] = (short)nx;
+      // ... and the coupled contacts grouped by owner wavefront (owner = a hash of the block pair), contact order inside a group: one coupled contact per lane,
+      // a ballot per owner ranks the lanes, the wavefronts' counts give the offsets (as for the side lists)
+      static_assert(UR5_MAXCON <= UR5_NT, "one coupled contact per lane");
+      constexpr int NW = UR5_NT / 64;
+      const int q = UR5_LANE, wv = UR5_LANE >> 6, wl = UR5_LANE & 63;
+      int own = -1;
+      if (q < S.ncouple) {
+        const int c = S.couple[q];
+        const int pa = blk_of_body(S.cA[c]), pb = blk_of_body(S.cB[c]);
+        S.ckey[q] = (short)(pa < pb ? pa * 64 + pb : pb * 64 + pa);
+        own = (pa + pb + (pa < pb ? pa : pb)) & (NW - 1);
       }
-      const unsigned long long mask = __ballot(head);
-      if ((UR5_LANE & 63) == 0) S.redi[UR5_LANE >> 6] = __popcll(mask);
-      SYNC();
-      int base = 0, total = 0;
+      int rank = 0;
 #pragma unroll
-      for (int w = 0; w < UR5_NT / 64; w++) { if (w < (UR5_LANE >> 6)) base += S.redi[w]; total += S.redi[w]; }
-      if (head) S.chead[base + __popcll(mask & ((1ull << (UR5_LANE & 63)) - 1ull))] = (short)q;
-      if (UR5_LANE == 0) S.nhead = total;
+      for (int w = 0; w < NW; w++) {
+        const unsigned long long m = __ballot(own == w);
+        if (own == w) rank = __popcll(m & ((1ull << wl) - 1ull));
+        if (wl == 0) S.slot_cnt[wv][w] = (unsigned char)__popcll(m);
+      }
+      SYNC();
+      if (own >= 0) {
+        int o = rank;
+        for (int w = 0; w < NW; w++) for (int v = 0; v < NW; v++) if (w < own || (w == own && v < wv)) o += S.slot_cnt[v][w];
+        S.wlist[o] = (short)q;
+      }
+      if (UR5_LANE <= NW) { int o = 0; for (int w = 0; w < UR5_LANE; w++) for (int v = 0; v < NW; v++) o += S.slot_cnt[v][w]; S.wptr[UR5_LANE] = (short)o; }
     }
 #endif
     SYNC();
@@ -2715,9 +2766,18 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       int di = M.nrd + 6 * k + i, dj = M.nrd + 6 * k + j;
       real v = 0;
       if (S.bodymask >> b & 1ull) {
-        real ti[6], tj[6];
-        unit_twist(b, i, ti); unit_twist(b, j, tj);
-        for (int a2 = 0; a2 < 6; a2++) { real t = 0; for (int bb = 0; bb < 6; bb++) t += S.G[M.nrg + k][sym6(a2, bb)] * tj[bb]; v += ti[a2] * t; }
+        // T^T G T with the object's unit twists written out (unit_twist: dof i < 3 = [0; e_i], dof i >= 3 = [R col(i-3); 0]): the linear block is a copy of G's,
+        // the mixed block one contraction with R, the angular block two -- the terms (and their order) that the generic 6 x 6 x 6 product leaves non-zero
+        const real* Gs = S.G[M.nrg + k];
+        if (i < 3) v = Gs[sym6(3 + i, 3 + j)];
+        else {
+          m3 R; R.load(S.bmat[b]);
+          const v3 ci = R.col(i - 3);
+          real t[3];
+          if (j < 3) { for (int a2 = 0; a2 < 3; a2++) t[a2] = Gs[sym6(a2, 3 + j)]; }
+          else { const v3 cj = R.col(j - 3); for (int a2 = 0; a2 < 3; a2++) t[a2] = Gs[sym6(a2, 0)] * cj.x + Gs[sym6(a2, 1)] * cj.y + Gs[sym6(a2, 2)] * cj.z; }
+          v = ci.x * t[0] + ci.y * t[1] + ci.z * t[2];
+        }
       }
       if (i == j) {
         v += S.Mobj[6 * k + i];
@@ -2728,25 +2788,27 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     SYNC();
     PROF(PF_X6);   // zeroing + diagonal blocks (the rest of H_asm is the coupling loop)
 #ifndef UR5_EMUL
-    // coupling blocks: lane (block pair, entry) sums the entry's terms along the pair's chain of contacts (contact order) and adds the total to H once
-    PAR(idx, S.nhead * 64) {
-      const int q0 = S.chead[idx >> 6], ent = idx & 63;
-      const int ky = S.ckey[q0], colblk = ky >> 6, rowblk = ky & 63;
-      const int nr = blk_width(rowblk), ncw = blk_width(colblk);
-      if (ent >= nr * ncw) continue;
-      const int li = ent / ncw, lj = ent - li * ncw;
-      const bool both_robot = rowblk == colblk;   // two robot bodies (finger against finger): the robot's own diagonal block, symmetrised
-      if (both_robot && li < lj) continue;
-      real acc = 0;
-      for (int q = q0; q >= 0; q = S.cnext[q]) {
+    // coupling blocks. Several contacts add to the same block (a box resting on a box: four), and float atomics from four wavefronts would land in a different
+    // order from run to run. Instead a block pair belongs to ONE wavefront: it walks ITS coupled contacts (S.wlist, contact order), and its 64 lanes add the contact's (up to 8 x 8) entries with plain read-modify-writes -- lane `ent` always owns the same entry of a block,
+    // so a sum's order is the contact order whatever the other wavefronts do.
+    {
+      static_assert(UR5_MAXRD * UR5_MAXRD <= 64 && UR5_MAXOBJ + 1 <= 64, "one entry of a coupling block per lane of a wavefront");
+      const int wv = UR5_LANE >> 6, ent = UR5_LANE & 63;
+      for (int k = S.wptr[wv]; k < S.wptr[wv + 1]; k++) {
+        const int q = S.wlist[k];
+        const int ky = S.ckey[q], colblk = ky >> 6, rowblk = ky & 63;
+        const int nr = blk_width(rowblk), ncw = blk_width(colblk);
+        if (ent >= nr * ncw) continue;
+        const int li = ent / ncw, lj = ent - li * ncw;
+        const bool both_robot = rowblk == colblk;   // two robot bodies (finger against finger): the robot's own diagonal block, symmetrised
+        if (both_robot && li < lj) continue;
         const int c = S.couple[q], A = S.cA[c], B = S.cB[c];
         real v;
         if (both_robot) { v = couple_term(c, A, li, B, lj); v = li == lj ? 2 * v : v + couple_term(c, A, lj, B, li); }
         else if (blk_of_body(A) == rowblk) v = couple_term(c, A, li, B, lj);
         else v = couple_term(c, A, lj, B, li);
-        acc += v;
+        if (v != 0) *hptr<INLDS>(6 * rowblk + li, 6 * colblk + lj) += (double)v;
       }
-      if (acc != 0) *hptr<INLDS>(6 * rowblk + li, 6 * colblk + lj) += (double)acc;
     }
     SYNC();
     return;
@@ -3181,6 +3243,83 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       if (sn < (real)1e-15) break;
       real gtol = tolerance * (real)0.01 * sn / scale;
       real lo = 0, hi = -1, a = 0, d1, d2;
+#if defined(UR5_MANY) && !defined(UR5_EMUL) && UR5_NT > 64 && !defined(UR5_LS_BLOCK)
+      // The exact line search is a scalar iteration over sums of <= 160 contacts + 16 rows: with the contacts spread over the workgroup every evaluation paid two
+      // workgroup barriers and an LDS round trip for ~100 instructions of work. Wavefront 0 alone takes all of it: lane l keeps contacts l, l + 64, l + 128 (their
+      // images along the iterate and along the search direction, friction factors folded in) and special row l in registers for the whole search, an evaluation is
+      // pure arithmetic + three DPP wave sums, and the other wavefronts wait at ONE barrier for the step length and the constraint cost at it.
+      real ccost_a = 0;
+      if (UR5_LANE < 64) {
+        constexpr int CPL = (UR5_MAXCON + 63) / 64;
+        real e0[CPL], j0[CPL], Dc[CPL], ek[CPL][NB - 1], jk[CPL][NB - 1];
+        int nk[CPL];                        // friction directions of the slot's contact (0: a frictionless contact, one row); -1: no contact
+#pragma unroll
+        for (int t = 0; t < CPL; t++) {
+          const int c = UR5_LANE + 64 * t;
+          nk[t] = -1; e0[t] = j0[t] = Dc[t] = 0;
+#pragma unroll
+          for (int k = 0; k < NB - 1; k++) ek[t][k] = jk[t][k] = 0;
+          if (c < S.ncon) {
+            const int cdim = S.cdim[c];
+            nk[t] = cdim == 1 ? 0 : cdim - 1;
+            e0[t] = S.ce[c][0]; j0[t] = S.cde[c][0]; Dc[t] = S.cD[c];
+#pragma unroll
+            for (int k = 1; k < NB; k++) if (k < cdim) { const real mu = row_mu(c, k); ek[t][k - 1] = mu * S.ce[c][k]; jk[t][k - 1] = mu * S.cde[c][k]; }
+          }
+        }
+        const bool has_row = UR5_LANE < S.nsr;
+        const real r0 = has_row ? S.sr_jar[UR5_LANE] : (real)0, rv = has_row ? S.sr_jv[UR5_LANE] : (real)0, rD = has_row ? S.sr_D[UR5_LANE] : (real)0;
+        const bool r_uni = has_row && S.sr_uni[UR5_LANE] != 0;
+        const int ncon = S.ncon;
+        auto eval = [&](const real alpha, real& cc, real& g1, real& g2) {
+          cc = 0; g1 = 0; g2 = 0;
+#pragma unroll
+          for (int t = 0; t < CPL; t++) {
+            if (64 * t >= ncon) continue;                                     // wave-uniform: most steps have fewer than 64 contacts
+            if (nk[t] < 0) continue;
+            const real D = Dc[t], t0 = e0[t] + alpha * j0[t];
+            if (nk[t] == 0) { if (t0 < 0) { cc += (real)0.5 * D * t0 * t0; g1 += D * t0 * j0[t]; g2 += D * j0[t] * j0[t]; } }
+            else {
+#pragma unroll
+              for (int k = 0; k < NB - 1; k++) {
+                if (k >= nk[t]) continue;
+                const real tk = ek[t][k] + alpha * jk[t][k];
+                const real rp = t0 + tk, rm = t0 - tk, bp = j0[t] + jk[t][k], bm = j0[t] - jk[t][k];
+                if (rp < 0) { cc += (real)0.5 * D * rp * rp; g1 += D * rp * bp; g2 += D * bp * bp; }
+                if (rm < 0) { cc += (real)0.5 * D * rm * rm; g1 += D * rm * bm; g2 += D * bm * bm; }
+              }
+            }
+          }
+          if (has_row) { const real r = r0 + alpha * rv; if (!r_uni || r < 0) { cc += (real)0.5 * rD * r * r; g1 += rD * r * rv; g2 += rD * rv * rv; } }
+          cc = ur5_wave_sum(cc); g1 = ur5_wave_sum(g1); g2 = ur5_wave_sum(g2);
+        };
+        real kc, k1, k2;
+        eval(0, kc, k1, k2);
+        d1 = k1 + q1; d2 = k2 + q2;
+        if (d1 < 0) {
+          for (int ls = 0; ls < 50; ls++) {
+            real an = a - d1 / d2;
+            if (hi > 0 && (an <= lo || an >= hi)) an = (real)0.5 * (lo + hi);
+            if (hi < 0 && an <= lo) an = 2 * lo + (real)1e-12;
+            a = an;
+            eval(a, kc, k1, k2);
+            d1 = k1 + q1 + a * q2; d2 = k2 + q2;
+            if (fabs(d1) <= gtol) break;
+            if (d1 < 0) lo = a; else hi = a;
+          }
+        }
+        if (UR5_LANE == 0) { S.red[0] = a; S.red[1] = kc; }                  // kc: the constraint cost at the last point evaluated = the accepted step
+      }
+      SYNC();
+      a = S.red[0]; ccost_a = S.red[1];
+      if (a <= 0) break;
+      SYNC();
+      PAR(i, nv) { S.x[i] += a * S.search[i]; S.Ma[i] += a * S.Mv[i]; }
+      PAR(c, S.ncon) for (int k = 0; k < NB; k++) { S.ce[c][k] += a * S.cde[c][k]; S.cde[c][k] = 0; }
+      PAR(s, S.nsr) { S.sr_jar[s] += a * S.sr_jv[s]; S.sr_jv[s] = 0; }
+      SYNC();
+      real newcost = gauss_cost(S.x, S.Ma) + ccost_a;
+#else
       { Cost3 k0 = constraint_cost(0); d1 = k0.d1 + q1; d2 = k0.d2 + q2; }
       if (d1 < 0) {
         for (int ls = 0; ls < 50; ls++) {
@@ -3201,6 +3340,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       PAR(s, S.nsr) { S.sr_jar[s] += a * S.sr_jv[s]; S.sr_jv[s] = 0; }
       SYNC();
       real newcost = gauss_cost(S.x, S.Ma) + constraint_cost(0).c;
+#endif
       improvement = scale * (cost - newcost);
       cost = newcost;
       SYNC();

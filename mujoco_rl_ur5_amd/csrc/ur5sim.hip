@@ -20,7 +20,9 @@
 #ifndef UR5_WAVES_PER_EU
 #define UR5_WAVES_PER_EU 2
 #endif
-#ifdef UR5_MANY
+#if defined(UR5_MANY) && defined(UR5_MANY_OCC2)   // experiment: two pile scenes per CU need <= 256 registers per lane (and an LDS image <= 80 KB)
+#define UR5_KERNEL_ATTR(GS) __launch_bounds__(UR5_NT) __attribute__((amdgpu_waves_per_eu(2, 2)))
+#elif defined(UR5_MANY)
 #define UR5_KERNEL_ATTR(GS) __launch_bounds__(UR5_NT)
 #else
 #define UR5_KERNEL_ATTR(GS) __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((GS) < 64 ? 1 : UR5_WAVES_PER_EU)))

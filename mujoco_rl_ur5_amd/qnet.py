@@ -63,6 +63,19 @@ def _conv1x1_as_gemm(conv, x):
     return y.view(n, conv.out_channels, h, w)
 
 
+def _conv3x3_as_gemm(conv, x):
+    """The network's FIRST convolution (4 -> 64 channels, 3x3, 200 x 200 images) as im2col + one batched GEMM: [64, 36] x [N, 36, H*W]. With 4 input channels
+    MIOpen has no Winograd / implicit-GEMM solution and its immediate mode falls back to `naive_conv_ab_nonpacked_{fwd,wrw}` (profiles/r03_m_dqn_kernel_stats.csv);
+    the column matrix of a 4-channel image is only 36 rows, and the weight gradient becomes a GEMM as well (the input needs no gradient). Same parameters as the
+    ``nn.Conv2d`` it replaces; the host path keeps the reference's operator."""
+    assert conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None, conv
+    if not (x.is_cuda or _FORCE_GEMM_1X1):
+        return conv(x)
+    n, c, h, w = x.shape
+    cols = nn.functional.unfold(x, kernel_size=3, padding=1)                          # [N, 9 C, H W], rows ordered (channel, ky, kx) like weight.view(O, -1)
+    return torch.matmul(conv.weight.view(conv.out_channels, 9 * c), cols).view(n, conv.out_channels, h, w)
+
+
 def _conv3x3(cin, cout):
     return nn.Conv2d(cin, cout, kernel_size=3, stride=1, padding=1, bias=False)
 
@@ -102,7 +115,7 @@ class Perception_Module(nn.Module):
         self.RB3 = BasicBlock(256, 512)
 
     def forward(self, x, verbose=0):
-        return self.RB3(self.RB2(self.MP2(self.RB1(self.MP1(self.C1(x))))))
+        return self.RB3(self.RB2(self.MP2(self.RB1(self.MP1(_conv3x3_as_gemm(self.C1, x))))))
 
 
 class _GraspingHead(nn.Module):

@@ -46,3 +46,51 @@ def test_a_written_file_read_by_the_references_own_class():
         mine = ds.transform_observation(ds.state_list[i], jitter_and_noise=False).numpy()
         assert np.array_equal(mine[:3], ref[:3].astype(np.float32))                 # ToTensor: rgb / 255, channel first
         assert np.abs(mine[3] - ref[3]).max() < 0.03                                 # depth: the reference's draw of its N(0, 1e-3) noise apart
+
+
+def _generate_and_check(tmp_path, device, lib, width, n_envs):
+    """generate_data.py's loop on the batched agent: every transition of every round lands in the files, in scene order, with the raw observation the
+    action was chosen in; the files load through Grasping_Dataset (whose items the reference's own class reproduces, test above)."""
+    from mujoco_rl_ur5_amd.agent import BatchedGraspAgent
+    from mujoco_rl_ur5_amd.envs import GraspEnv
+    from mujoco_rl_ur5_amd.generate_data import generate_data
+    from mujoco_rl_ur5_amd.model import load_model
+    env = GraspEnv(file=load_model("it1_4box"), n_envs=n_envs, show_obs=False, observation="render", image_width=width, image_height=width, check_mode=1,
+                   _lib_path=lib)
+    agent = BatchedGraspAgent(env=env, device=device, mem_size=100, seed=122)
+    seen = []
+    orig = agent.round
+
+    def spy(**kw):
+        out = orig(**kw)
+        seen.append((out["observation"]["depth"].cpu().numpy().copy(), out["action"].cpu().numpy().copy(), out["reward"].cpu().numpy().copy()))
+        return out
+    agent.round = spy
+    files, counter = generate_data(agent, str(tmp_path / "Data"), episodes=2, steps=3, learn=True)
+    total = 2 * 3 * n_envs
+    assert len(files) == -(-total // FILE_SIZE) and sum(counter.values()) == total and env._episode >= 2
+    acts = np.concatenate([a for _, a, _ in seen])
+    rews = np.concatenate([r for _, _, r in seen])
+    deps = np.concatenate([d for d, _, _ in seen])
+    got_a, got_r, k = [], [], 0
+    for f in files:
+        ds = Grasping_Dataset(f, seed=0)
+        for i in range(len(ds)):
+            x, a, r = ds[i]
+            assert x.shape == (4, width, width) and np.array_equal(ds.state_list[i]["depth"], deps[k])       # the observation of THAT transition
+            got_a.append(int(a)); got_r.append(int(r)); k += 1
+    assert got_a == acts.tolist() and got_r == rews.tolist() and k == total
+    assert max(got_a) < 6 * width * width and set(got_r) <= {0, 1}
+    env.close()
+
+
+def test_generate_data_loop_fills_the_files_from_the_batched_agent(tmp_path, emul_lib):
+    _generate_and_check(tmp_path, "cpu", emul_lib, 24, 3)
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_generate_data_on_gpu(tmp_path):
+    _generate_and_check(tmp_path, "cuda", None, 200, 8)

@@ -345,13 +345,14 @@ def test_pile_kernel_is_run_to_run_deterministic_on_gpu(model_many):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
     from pile_aim import pick_box
     n = 256
-    sim = BatchSim(model_many, n)
+    sim, twin = BatchSim(model_many, n), BatchSim(model_many, n)               # (two handles: a second reset of ONE handle starts from another PID history)
     seeds = 500 + np.arange(n, dtype=np.uint64)
     sim.reset(seeds, 1, 1000.0)
+    twin.reset(seeds, 1, 1000.0)
     rec_a = sim.state_tensor("cuda").clone()
-    sim.reset(seeds, 1, 1000.0)
     torch.cuda.synchronize()
-    assert torch.equal(rec_a, sim.state_tensor("cuda")), "two settles of the same seeds differ"
+    assert torch.equal(rec_a, twin.state_tensor("cuda")), "two settles of the same seeds differ"
+    twin.close()
     st = sim.get_state()
     acts, rots = np.zeros((n, 3)), np.arange(n) % 6
     acts[:] = [0.0, -0.6, 1.0]

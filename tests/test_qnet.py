@@ -171,3 +171,42 @@ def test_batched_push_and_learn_reproduces_the_reference_s_cadence_on_gpu():
     rel = np.abs(np.array(losses) - ref) / np.maximum(np.abs(ref), 1e-3)
     assert len(losses) == len(ref) and rel[0] < 1e-4 and rel[:3].max() < 5e-2 and rel.max() < 0.3, (rel.round(4).tolist(), s, g["after_sum"], a, g["after_abs_sum"])
     assert abs(a - g["after_abs_sum"]) < 0.1 * g["after_abs_sum"], (a, g["after_abs_sum"])
+
+
+def _gemm_paths_equal_the_convolutions(device):
+    """qnet routes the 1x1 convolutions and the 4-channel first 3x3 convolution through GEMMs on the GPU (MIOpen's immediate mode has only its naive kernels for
+    them): outputs, input gradients and weight / bias gradients must equal the nn.Conv2d they replace."""
+    import mujoco_rl_ur5_amd.qnet as Q
+    torch.manual_seed(3)
+    cases = [(torch.nn.Conv2d(64, 128, kernel_size=1, stride=1), Q._conv1x1_as_gemm, (3, 64, 10, 12)),        # BasicBlock.conv3 (with bias)
+             (torch.nn.Conv2d(64, 6, kernel_size=1), Q._conv1x1_as_gemm, (2, 64, 16, 16)),                    # the head's C1
+             (Q._conv3x3(4, 64), Q._conv3x3_as_gemm, (2, 4, 20, 24))]                                          # Perception_Module.C1
+    old = Q._FORCE_GEMM_1X1
+    Q._FORCE_GEMM_1X1 = True
+    try:
+        for conv, fn, shape in cases:
+            conv = conv.to(device)
+            x1 = torch.randn(shape, device=device, requires_grad=True)
+            x2 = x1.detach().clone().requires_grad_(True)
+            g = torch.randn(conv(x1).shape, device=device)
+            y1 = conv(x1)
+            y1.backward(g)
+            gw1, gb1 = conv.weight.grad.clone(), None if conv.bias is None else conv.bias.grad.clone()
+            conv.zero_grad()
+            y2 = fn(conv, x2)
+            y2.backward(g)
+            assert torch.allclose(y1, y2, rtol=1e-4, atol=1e-5) and torch.allclose(x1.grad, x2.grad, rtol=1e-4, atol=1e-5)
+            assert torch.allclose(gw1, conv.weight.grad, rtol=1e-4, atol=1e-4) and (gb1 is None or torch.allclose(gb1, conv.bias.grad, rtol=1e-4, atol=1e-4))
+        with pytest.raises(AssertionError):
+            Q._conv1x1_as_gemm(torch.nn.Conv2d(8, 8, kernel_size=3, padding=1), torch.zeros(1, 8, 4, 4))   # the helper refuses what it does not implement
+    finally:
+        Q._FORCE_GEMM_1X1 = old
+
+
+def test_gemm_paths_equal_the_convolutions_on_cpu():
+    _gemm_paths_equal_the_convolutions("cpu")
+
+
+@pytest.mark.gpu
+def test_gemm_paths_equal_the_convolutions_on_gpu():
+    _gemm_paths_equal_the_convolutions("cuda")

@@ -21,10 +21,11 @@ sim = BatchSim(m, pool)
 seeds = seed0 + np.arange(pool, dtype=np.uint64)
 sim.reset(seeds, 1, 1000.0)
 settle_ms = sim.last_launch_ms()
-rec_a = sim.state_tensor("cuda").clone()
-sim.reset(seeds, 1, 1000.0)                                   # the settle itself, twice: 500 steps of falling and colliding objects
+twin = BatchSim(m, pool)                                      # the settle itself, twice (a fresh handle: a second reset of the same one starts from another PID history)
+twin.reset(seeds, 1, 1000.0)
 torch.cuda.synchronize()
-settle_equal = bool(torch.equal(rec_a, sim.state_tensor("cuda")))
+settle_equal = bool(torch.equal(sim.state_tensor("cuda"), twin.state_tensor("cuda")))
+twin.close()
 st, ctrl = sim.get_state(), sim.get_ctrl()
 acts, rots, scores = np.zeros((pool, 3)), np.zeros(pool, dtype=np.int64), np.full(pool, np.nan)
 acts[:] = [0.0, -0.6, 1.0]

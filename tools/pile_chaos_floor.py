@@ -17,7 +17,7 @@ from oracle.oracle import Oracle
 src = sys.argv[1]
 threads = int(sys.argv[2]) if len(sys.argv) > 2 else (os.cpu_count() or 8)
 limit = int(sys.argv[3]) if len(sys.argv) > 3 else 10 ** 9
-D = np.load(src)
+D = {k: v for k, v in np.load(src).items()}                  # in memory: the threads index these arrays
 n = min(limit, len(D["sel"]))
 m = load_model("/UR5+gripper/UR5gripper_2_finger_many_objects.xml")
 VARIANTS = ("base", "reversed_contacts", "one_ulp")
