@@ -298,7 +298,7 @@ class Job:
             gr.sim.close()
 
 
-def rendered_sub_result(torch, dist, sharding, dev, dev_id, workload, n, rounds, warmup, with_cpu):
+def rendered_sub_result(torch, dist, sharding, dev, dev_id, workload, n, rounds, warmup, with_cpu, groups=2):
     """N = 1 measurement of BASELINE.json configs[2] (it4) / configs[3] (many) in the driver's one line, with the headline's machinery: the same
     stationary episode structure (EP rounds, a quarter of the batch resets per round inside the attempt's launch), every round renders the
     200x200 RGB-D observation, re-aims ON THE DEVICE from the current state, takes the grasp height from the rendered depth under the aimed pixel
@@ -306,7 +306,7 @@ def rendered_sub_result(torch, dist, sharding, dev, dev_id, workload, n, rounds,
     from mujoco_rl_ur5_amd.model import load_model
     many = workload == "many"
     model = load_model("/UR5+gripper/UR5gripper_2_finger_many_objects.xml" if many else "/UR5+gripper/UR5gripper_2_finger.xml")
-    job = Job(torch, dist, sharding, model, workload, "aimed", n, n, 0, 1, dev, dev_id, 2, warmup + rounds)
+    job = Job(torch, dist, sharding, model, workload, "aimed", n, n, 0, 1, dev, dev_id, groups, warmup + rounds)
     job.run_rounds(0, warmup)
     dt, c0, c1, kms, _ = job.timed(warmup, warmup + rounds)
     steps = int((c1["total_steps"] - c0["total_steps"]).sum())
@@ -393,6 +393,7 @@ def main():
                     help="run ONLY this secondary measurement (N = 1) and print it as {name: result}: what the rocprofv3 passes of tools/gpu_evidence_extras.sh profile")
     ap.add_argument("--sub-scenes", type=int, default=None, help="with --sub: scene count instead of the sub-result's own (same-box A/Bs of engine builds)")
     ap.add_argument("--sub-rounds", type=int, default=None, help="with --sub: timed rounds")
+    ap.add_argument("--sub-groups", type=int, default=2, help="with --sub-scenes / --sub-rounds: scene groups (handles + streams) of the sub-result")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for 2 ranks on one device)")
     args = ap.parse_args()
 
@@ -428,10 +429,10 @@ def main():
             "many4096": lambda cpu: rendered_sub_result(torch, dist, sharding, dev, dev_id, "many", 4096, 2, 1, False),   # north_star: "a 4096-env synthetic pile" on one GPU
             "dqn": lambda cpu: dqn_sub_result(torch, dev, dev_id, 512, 2, 1)}
     if args.sub:
-        if args.sub in ("it4", "many", "many4096") and (args.sub_scenes or args.sub_rounds):
+        if args.sub in ("it4", "many", "many4096") and (args.sub_scenes or args.sub_rounds or args.sub_groups != 2):
             wl = "it4" if args.sub == "it4" else "many"
             dflt = {"it4": (4096, 4), "many": (2048, 2), "many4096": (4096, 2)}[args.sub]
-            res = rendered_sub_result(torch, dist, sharding, dev, dev_id, wl, args.sub_scenes or dflt[0], args.sub_rounds or dflt[1], 1, False)
+            res = rendered_sub_result(torch, dist, sharding, dev, dev_id, wl, args.sub_scenes or dflt[0], args.sub_rounds or dflt[1], 1, False, args.sub_groups)
         else:
             res = subs[args.sub](False)
         print(json.dumps({args.sub: res}), flush=True)

@@ -102,7 +102,7 @@ double ur5_kernel_ms_total(ur5_sim* h);
 /* counters[n][6] host: total physics steps, last_movement_steps, status bits, Newton iterations, max contacts seen in a step,
    and a variant-specific work counter: many-object engine -- Newton iterations that reused the previous Cholesky factor; wavefront-per-scene
    engine -- physics steps whose broad phase ran from the cached pair list instead of scanning every pair (same candidates either way).
-   Status bits (sticky until ur5_reset): 1 = more contacts than slots (30 / 160), 2 = a step produced a non-finite (or > 1e10) state: the
+   Status bits (sticky until ur5_reset): 1 = more contacts than slots (30 / 96), 2 = a step produced a non-finite (or > 1e10) state: the
    scene went back to qpos0 like mj_resetData [3P] and keeps running, 4 = more equality/limit rows than slots (16), 8 = more broad-phase
    survivors than slots (64 / 512). Any set bit means the scene's results are not trustworthy. The status column carries the bits of the running episode
    in bits 0-7 and, in bits 8-15, the bits of every episode that ur5_grasp_attempt_reset_dev has ended INSIDE a launch since the last ur5_reset /

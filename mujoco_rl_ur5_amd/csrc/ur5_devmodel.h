@@ -32,7 +32,8 @@ typedef int ur5_pair_t;
 #define UR5_MAXG 80
 #define UR5_MAXDG 56
 #define UR5_MAXPAIR 2560
-#define UR5_MAXCON 160
+#define UR5_MAXCON 96                              // 3072 settled + grasped piles of the reference's scene peak at 80 contacts (profiles/r04_b_many_determinism_3072piles.json);
+                                                   // more than 96 raises UR5_ST_CONTACT_OVERFLOW. 160 slots cost 19 KB of LDS that two scenes per CU cannot spare
 #define UR5_MAXCAND 512
 #define UR5_MAXHV 1024                             // 590 for the gripper's full hulls + 7 x 32 for the optional arm-link hulls
 #define UR5_NB 6                                   // + 2 rolling directions (condim 6)
@@ -182,8 +183,15 @@ struct Ur5Launch {
 #define UR5_DEBUG_STRIDE 2048
 #else
 #define UR5_DEBUG_STRIDE 4096
-#define UR5_HESS_STRIDE (UR5_MAXNV * (UR5_MAXNV + 1) / 2 + UR5_MAXNV)   // worst case: the full lower triangle
+// Per-scene scratch in global memory (L2-resident, 4 MB per XCD): everything of the Newton factorisation that is touched once per panel instead of once per
+// instruction lives here since round 4, so that the LDS image of a pile is < 80 KB and TWO scenes share a CU (two wavefronts per SIMD hide each other's
+// latencies; the same-box A/B of the envelope in global memory alone: -6 %). Layout in doubles: envelope of H / its factor (worst case: the full lower
+// triangle) | current block column of the factorisation | factored diagonal blocks | staged twist-space Hessian terms of the contact sides.
+#define UR5_SCR_PANEL (UR5_MAXNV * (UR5_MAXNV + 1) / 2 + UR5_MAXNV)
+#define UR5_SCR_DCACHE (UR5_SCR_PANEL + UR5_MAXNV * UR5_MAXRD)
+#define UR5_SCR_STG (UR5_SCR_DCACHE + (UR5_MAXOBJ + 1) * 44)
+#define UR5_HESS_STRIDE ((UR5_SCR_STG + 2 * UR5_MAXCON * 21 + 63) / 64 * 64)
 #ifndef UR5_HENV_CAP
-#define UR5_HENV_CAP 3584                          // envelopes up to this many doubles stay in LDS (tests shrink it to force the global path)
+#define UR5_HENV_CAP 8                             // envelopes up to this many doubles would stay in LDS: none does (kept as a switch: a build with a large cap puts them back)
 #endif
 #endif

@@ -337,28 +337,31 @@ template <class real, int NV_> struct Lds {
 #ifndef UR5_MANY
     real H[HSIZE];
 #else
-    real panel[NV_][UR5_MAXRD];                      // current block column of the envelope factorisation (H itself: global memory)
+    real tw[NSLOT][6];                               // body twists of a dof vector: built and consumed inside images() / the Newton warm start
+    real stw[2 * UR5_MAXCON][6];                     // staged wrench terms of the contact sides: built and consumed inside contact_gather()
 #endif
   };
 #ifdef UR5_MANY
   // envelope (skyline) storage of the Newton Hessian in global memory, dofs permuted: objects sorted along x, robot last
   double* hess;
-  int env_first[NV_], env_ptr[NV_ + 1];              // first stored column of a row, offset of the row
+  unsigned char env_first[NV_];                      // first stored column of a row (a multiple of 6 below 6 * 41),
+  unsigned short env_ptr[NV_ + 1];                   // offset of the row (the full lower triangle is 31 k doubles)
   short obj_rank[UR5_MAXOBJ], obj_at[UR5_MAXOBJ];   // sorted position of an object and back
   int island[UR5_MAXOBJ + 1];                        // island label of object k / of the robot (index nobj)
   int blk_first[UR5_MAXOBJ + 1], blk_ptr[UR5_MAXOBJ + 1];      // per block (sorted position; robot = block nobj): first coupled block (atomic min), envelope offset of its first row
   short blk_last[UR5_MAXOBJ + 1], lv[UR5_MAXOBJ + 1], reach_cnt[UR5_MAXOBJ + 1];   // last block reaching it, level of its panel (-1: none), blocks reaching it
   double henv[UR5_HENV_CAP];                         // the envelope itself when it fits (it does for settled 40-object piles)
   int env_inlds, nseq, act_changed, nskip;
-  short reach_ptr[UR5_MAXOBJ + 2], reach_list[(UR5_MAXOBJ + 1) * UR5_MAXOBJ / 2];   // per panel: the blocks below it whose rows reach it
+  static constexpr int REACH_CAP = (UR5_MAXOBJ + 1) * UR5_MAXOBJ / 4;                // half the worst case: 410 off-diagonal blocks = an envelope of > 15 k doubles
+  short reach_ptr[UR5_MAXOBJ + 2], reach_list[REACH_CAP];                            // (settled piles: ~45 blocks, 2.5 k doubles); beyond it the scene is flagged
+                                                                                     // per panel: the blocks below it whose rows reach it
   unsigned short cact[UR5_MAXCON];                   // active-row signature of every contact at the previous Newton iteration
   int sr_act[UR5_MAXSR];
-  real dcache[UR5_MAXOBJ + 1][44];                   // factored diagonal blocks, packed lower triangle + 1/diagonal
   short seq[UR5_MAXOBJ + 1];                         // blocks that take part in the sequential factorisation (the others are uncoupled)
   short lvl_ptr[UR5_MAXOBJ + 3], lvl_list[UR5_MAXOBJ + 1];   // the same panels grouped by level: panels of one level belong to different
   int nlvl;                                          // envelope groups (islands) and are processed together, one wavefront each
-  real red[3 * 16];                                  // cross-wave reductions
-  int redi[16];
+  real red[3 * (UR5_NT / 64)];                       // cross-wave reductions
+  int redi[UR5_NT / 64];
   // Fixed-order accumulation (round 4): four wavefronts share a scene, so LDS float atomics would land in an order that changes from run to
   // run. Instead every body slot owns the list of its contact sides (2 c + side, in contact order): the contact lanes stage their terms, the slot's
   // lanes sum them along the list; every Hessian coupling block is owned by one wavefront, which adds its contacts' terms in contact order. A scene's
@@ -366,17 +369,26 @@ template <class real, int NV_> struct Lds {
   short csl[UR5_MAXCON][2];                          // accumulator slot of a contact's two bodies (-1: static side); flat index = side id 2 c + side
   short side_list[2 * UR5_MAXCON], slot_ptr[NSLOT + 1];
   unsigned char slot_cnt[UR5_NT / 64][NSLOT + 1];    // sides of a slot held by the lanes of each wavefront (list construction)
-  short ckey[UR5_MAXCON];                            // per coupled contact: its pair of Hessian blocks, 64 * smaller + larger
-  short wlist[UR5_MAXCON], wptr[UR5_NT / 64 + 1];    // the coupled contacts grouped by the wavefront that owns their block pair, contact order inside a group
+  unsigned long long wrec[UR5_MAXCON];               // the coupled contacts grouped by the wavefront that owns their block pair, contact order inside a group:
+  short wptr[UR5_NT / 64 + 1];                       // one packed record each (contact | body A << 8 | body B << 16 | block pair << 24 | A-owns-the-row-block << 40)
 
 #endif
   // dynamics vectors (dof space)
-  real fs[NV_], as[NV_], x[NV_], Ma[NV_], grad[NV_], search[NV_], Mv[NV_], tmpv[NV_ + 4];
+  real fs[NV_], as[NV_], x[NV_], Ma[NV_], search[NV_], Mv[NV_], tmpv[NV_ + 4];
+#ifndef UR5_MANY
+  real grad[NV_];                                    // (the many-object kernel keeps the gradient in `search` until the solve overwrites it)
+#endif
   // contacts
   int ncon, nsr, ncand, ncouple;
   unsigned cplmask;              // bit k: object k takes part in a contact between two movable bodies; bit 31: one of them has a robot side
   unsigned long long bodymask;   // cbodies that carry at least one contact
+#ifndef UR5_MANY
   int cA[UR5_MAXCON], cB[UR5_MAXCON], cdim[UR5_MAXCON];
+#else
+  int cA[UR5_MAXCON];                                // (also the sort key of sort_contacts() while the contacts are collected)
+  signed char cB[UR5_MAXCON];                        // narrow types: every byte counts towards two scenes per CU
+  unsigned char cdim[UR5_MAXCON];
+#endif
   short cg1[UR5_MAXCON], cg2[UR5_MAXCON];
   short cand[UR5_MAXCAND];
 #ifndef UR5_MANY
@@ -386,7 +398,11 @@ template <class real, int NV_> struct Lds {
   float moved[UR5_MAXDG];
   int nsup;
 #endif
+#ifndef UR5_MANY
   int couple[UR5_MAXCON];
+#else
+  short couple[UR5_MAXCON];                          // contacts between two movable bodies (and, during the narrow phase, the queue of hull pairs)
+#endif
   real cpos[UR5_MAXCON][3], cframe[UR5_MAXCON][6], cdist[UR5_MAXCON], cfri[UR5_MAXCON][NB > 4 ? 3 : 2];   // cframe: normal, tangent 1 (tangent 2 = n x t1)
   real cD[UR5_MAXCON];
   real ceoff[UR5_MAXCON][NB], ce[UR5_MAXCON][NB], cde[UR5_MAXCON][NB];   // ceoff: -aref in base space
@@ -397,7 +413,10 @@ template <class real, int NV_> struct Lds {
   int sr_d1[UR5_MAXSR], sr_d2[UR5_MAXSR], sr_uni[UR5_MAXSR];
   real sr_c1[UR5_MAXSR], sr_c2[UR5_MAXSR], sr_D[UR5_MAXSR], sr_aref[UR5_MAXSR], sr_jar[UR5_MAXSR], sr_jv[UR5_MAXSR];
   // body accumulators (twist space)
-  real tw[NSLOT][6], WB[NSLOT][6], G[NSLOT][21];   // indexed by slot_of(body)
+#ifndef UR5_MANY
+  real tw[NSLOT][6];
+#endif
+  real WB[NSLOT][6], G[NSLOT][21];   // indexed by slot_of(body)
 #if defined(UR5_PROFILE) && !defined(UR5_EMUL)
   double prof[PF_COUNT];
 #endif
@@ -2103,11 +2122,10 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
   // per side -- wrench terms [side][6] in the panel area (only the factorisation uses it), Hessian terms [side][21] in the envelope area (G is only built when the
   // envelope is about to be re-assembled) --, then lane (slot, entry) adds its slot's sides in list order = contact order. No float atomic, no dependence on the
   // wavefronts' timing; every entry of every slot is written, so nothing is zeroed first. Contacts are staged UR5_GCHUNK at a time (a settled pile has 40-80).
-  static constexpr int GCHUNK = UR5_HENV_CAP / 42 < 1 ? 1 : (UR5_HENV_CAP / 42 < UR5_MAXCON ? UR5_HENV_CAP / 42 : UR5_MAXCON);
-  static_assert(2 * UR5_MAXCON * 6 <= NV_ * UR5_MAXRD, "the panel area holds the staged wrench terms of every side");
+  static constexpr int GCHUNK = UR5_MAXCON;          // (the staging area in the scene's global scratch holds every side: one round)
   UR5_FN void contact_gather(const bool doW, const bool doG) {
-    real* const stW = &S.panel[0][0];
-    real* const stG = reinterpret_cast<real*>(S.henv);
+    real* const stW = &S.stw[0][0];
+    real* const stG = S.hess + UR5_SCR_STG;
     const int chunk = doG ? GCHUNK : UR5_MAXCON;
     for (int c0 = 0; c0 == 0 || c0 < S.ncon; c0 += chunk) {
       const int c1 = c0 + chunk < S.ncon ? c0 + chunk : S.ncon;
@@ -2253,7 +2271,13 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
 #else
     const bool refactor = true;
 #endif
+#if defined(UR5_MANY) && !defined(UR5_EMUL)
+    // the staged gather costs two barriers and a walk over the side lists whether it sums 6 or 27 entries per slot: wrench and Hessian terms go through it together
+    // whenever the factor has to be rebuilt (the one iteration per step that turns out to be converged builds its G for nothing; the other ~10 save a second pass)
+    contact_scatter(true, refactor);
+#else
     contact_scatter(true, !check && refactor);   // first iteration: one pass does both
+#endif
     SYNC();
     // gradient = Ma - fs - J^T f
     PAR(i, M.nv) {
@@ -2273,20 +2297,25 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
         if (S.sr_d1[s] == i) jf += S.sr_c1[s] * f;
         if (S.sr_d2[s] == i) jf += S.sr_c2[s] * f;
       }
-      S.grad[i] = S.Ma[i] - S.fs[i] - jf;
-      S.search[i] = S.grad[i];
+      const real gi = S.Ma[i] - S.fs[i] - jf;
+#ifndef UR5_MANY
+      S.grad[i] = gi;
+#endif
+      S.search[i] = gi;
     }
     if (check) {   // iterations after the first: the Hessian is only worth building when the gradient says "not converged"
       real gn = 0;
-      PAR(i, M.nv) gn += S.grad[i] * S.grad[i];
+      PAR(i, M.nv) gn += S.search[i] * S.search[i];
       gn = WAVE_SUM(gn);
       if (scale * sqrt(gn) < tolerance) return true;
+#if !defined(UR5_MANY) || defined(UR5_EMUL)
       if (refactor) { contact_scatter(false, true); SYNC(); }
+#endif
     }
     PROF(PF_GRADG);
 #ifdef UR5_MANY
     if (UR5_LANE == 0) { S.act_changed = 0; if (!refactor) S.nskip++; }   // every lane read the flag before the barrier above
-    PAR(i, M.nv) S.Mv[pdof(i)] = S.grad[i];   // right-hand side in permuted order
+    PAR(i, M.nv) S.Mv[pdof(i)] = S.search[i];   // right-hand side in permuted order (search still holds the gradient)
     if (S.env_inlds) {
       if (refactor) { envelope_assemble<true>(); PROF(PF_HASM); envelope_factor<true>(); PROF(PF_CHOL); }
       envelope_solve<true>(); PROF(PF_SOLVE);
@@ -2570,6 +2599,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
   }
   UR5_FN int blk_of_body(int b) const { return b < M.nrd ? M.nobj : S.obj_rank[b - M.nrd]; }
   UR5_FN int blk_width(int p) const { return p < M.nobj ? 6 : M.nrd; }
+  UR5_FN real* panel_row(int i) { return S.hess + UR5_SCR_PANEL + UR5_MAXRD * i; }   // current block column of the factorisation, by global row
   template <bool INLDS> UR5_FN double* hptr(int I, int J) { return (INLDS ? S.henv : S.hess) + S.env_ptr[I] + (J - S.env_first[I]); }
   UR5_BIG void envelope_structure() {
     static_assert(UR5_NT >= UR5_MAXNV, "one thread per Hessian row");
@@ -2638,7 +2668,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       for (int q = p2 + 1; q < nblk; q++) if (S.blk_first[q] <= p2) { last = q; cnt++; }
       S.blk_last[p2] = (short)last; S.reach_cnt[p2] = (short)cnt;
     }
-    PAR(i, nv) S.env_first[i] = 6 * S.blk_first[i < 6 * nobj ? i / 6 : nobj];
+    PAR(i, nv) S.env_first[i] = (unsigned char)(6 * S.blk_first[i < 6 * nobj ? i / 6 : nobj]);
     SYNC();
     // envelope pointers: row i of block p starts at (stored entries of the blocks before p) + (stored entries of the block's rows before i);
     // a row of block p at local index j stores 6 p + j - 6 blk_first[p] + 1 entries
@@ -2662,8 +2692,8 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     SYNC();
     PAR(i, nv) {
       const int p2 = i < 6 * nobj ? i / 6 : nobj, j = i - 6 * p2, f = 6 * (p2 - S.blk_first[p2]);
-      S.env_ptr[i] = S.blk_ptr[p2] + j * f + j * (j + 1) / 2;
-      if (i == nv - 1) { const int tot = S.env_ptr[i] + f + j + 1; S.env_ptr[nv] = tot; S.env_inlds = tot <= UR5_HENV_CAP && !UR5_FORCE_GLOBAL_ENV; }
+      S.env_ptr[i] = (unsigned short)(S.blk_ptr[p2] + j * f + j * (j + 1) / 2);
+      if (i == nv - 1) { const int tot = S.env_ptr[i] + f + j + 1; S.env_ptr[nv] = (unsigned short)tot; S.env_inlds = tot <= UR5_HENV_CAP && !UR5_FORCE_GLOBAL_ENV; }
     }
     PAR(l, S.nlvl + 1) {   // panels with a lower level come first: lvl_ptr[l] = their number
       int o = 0;
@@ -2685,7 +2715,8 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
         S.lvl_list[o] = (short)p2;
       }
     }
-    PAR(p2, nblk) { int o = S.reach_ptr[p2]; for (int q = p2 + 1; q <= S.blk_last[p2]; q++) if (S.blk_first[q] <= p2) S.reach_list[o++] = (short)q; }
+    if (S.reach_ptr[nblk] > L::REACH_CAP) S.status |= UR5_ST_ROW_OVERFLOW;   // (benign race: every lane ORs the same bit) the lists below are cut off: flagged, never silent
+    PAR(p2, nblk) { int o = S.reach_ptr[p2]; for (int q = p2 + 1; q <= S.blk_last[p2]; q++) if (S.blk_first[q] <= p2) { if (o < L::REACH_CAP) S.reach_list[o] = (short)q; o++; } }
 #ifndef UR5_EMUL
     // the pair of Hessian blocks every coupled contact adds to (envelope_assemble: a block pair is owned by ONE wavefront)
     {
@@ -2695,11 +2726,13 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       constexpr int NW = UR5_NT / 64;
       const int q = UR5_LANE, wv = UR5_LANE >> 6, wl = UR5_LANE & 63;
       int own = -1;
+      unsigned long long rec = 0;
       if (q < S.ncouple) {
-        const int c = S.couple[q];
-        const int pa = blk_of_body(S.cA[c]), pb = blk_of_body(S.cB[c]);
-        S.ckey[q] = (short)(pa < pb ? pa * 64 + pb : pb * 64 + pa);
+        const int c = S.couple[q], A = S.cA[c], B = S.cB[c];
+        const int pa = blk_of_body(A), pb = blk_of_body(B);
+        const int ky = pa < pb ? pa * 64 + pb : pb * 64 + pa;
         own = (pa + pb + (pa < pb ? pa : pb)) & (NW - 1);
+        rec = (unsigned long long)c | (unsigned long long)A << 8 | (unsigned long long)B << 16 | (unsigned long long)ky << 24 | (unsigned long long)(pa >= pb ? 1 : 0) << 40;
       }
       int rank = 0;
 #pragma unroll
@@ -2712,7 +2745,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       if (own >= 0) {
         int o = rank;
         for (int w = 0; w < NW; w++) for (int v = 0; v < NW; v++) if (w < own || (w == own && v < wv)) o += S.slot_cnt[v][w];
-        S.wlist[o] = (short)q;
+        S.wrec[o] = rec;
       }
       if (UR5_LANE <= NW) { int o = 0; for (int w = 0; w < UR5_LANE; w++) for (int v = 0; v < NW; v++) o += S.slot_cnt[v][w]; S.wptr[UR5_LANE] = (short)o; }
     }
@@ -2795,17 +2828,17 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       static_assert(UR5_MAXRD * UR5_MAXRD <= 64 && UR5_MAXOBJ + 1 <= 64, "one entry of a coupling block per lane of a wavefront");
       const int wv = UR5_LANE >> 6, ent = UR5_LANE & 63;
       for (int k = S.wptr[wv]; k < S.wptr[wv + 1]; k++) {
-        const int q = S.wlist[k];
-        const int ky = S.ckey[q], colblk = ky >> 6, rowblk = ky & 63;
+        const unsigned long long rec = S.wrec[k];   // everything the entry needs to find its data in ONE load (the chain list -> contact -> bodies -> blocks was four)
+        const int c = (int)(rec & 255u), A = (int)(rec >> 8 & 255u), B = (int)(rec >> 16 & 255u), ky = (int)(rec >> 24 & 0xffffu);
+        const int colblk = ky >> 6, rowblk = ky & 63;
         const int nr = blk_width(rowblk), ncw = blk_width(colblk);
         if (ent >= nr * ncw) continue;
         const int li = ent / ncw, lj = ent - li * ncw;
         const bool both_robot = rowblk == colblk;   // two robot bodies (finger against finger): the robot's own diagonal block, symmetrised
         if (both_robot && li < lj) continue;
-        const int c = S.couple[q], A = S.cA[c], B = S.cB[c];
         real v;
         if (both_robot) { v = couple_term(c, A, li, B, lj); v = li == lj ? 2 * v : v + couple_term(c, A, lj, B, li); }
-        else if (blk_of_body(A) == rowblk) v = couple_term(c, A, li, B, lj);
+        else if (rec >> 40 & 1u) v = couple_term(c, A, li, B, lj);
         else v = couple_term(c, A, lj, B, li);
         if (v != 0) *hptr<INLDS>(6 * rowblk + li, 6 * colblk + lj) += (double)v;
       }
@@ -2868,7 +2901,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
   }
   // factored blocks are kept packed (lower triangle, then 1 / diagonal) in S.dcache for the triangular solves
   template <int W> UR5_FN void diag_store(int p2, const Diag<W>& d) {
-    real* c = S.dcache[p2];
+    real* c = S.hess + UR5_SCR_DCACHE + 44 * p2;
 #pragma unroll
     for (int a = 0; a < W; a++) {
 #pragma unroll
@@ -2877,7 +2910,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     }
   }
   template <int W> UR5_FN void diag_cached(int p2, Diag<W>& d) {
-    const real* c = S.dcache[p2];
+    const real* c = S.hess + UR5_SCR_DCACHE + 44 * p2;
 #pragma unroll
     for (int a = 0; a < W; a++) {
 #pragma unroll
@@ -2942,7 +2975,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       }
     }
 #pragma unroll
-    for (int k = 0; k < W; k++) S.panel[i][k] = out[k];
+    for (int k = 0; k < W; k++) panel_row(i)[k] = out[k];
   }
   // Work split inside a level: on the GPU wavefront w of the workgroup owns panel base + w of the pass and its 64 lanes stride over
   // that panel's rows; the lane-emulation build walks the panels of a pass one after the other.
@@ -2972,14 +3005,14 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     UR5_PLANE(c, nr) {
       const int i = reach_row(p2, nrb, c);
       double* row = hptr<INLDS>(i, c0);
-      for (int k = 0; k < w; k++) row[k] = (double)S.panel[i][k];
+      for (int k = 0; k < w; k++) row[k] = (double)panel_row(i)[k];
     }
     UR5_PLANE(idx, nr * nr) {
       const int ii = idx / nr, jj = idx - ii * nr;
       if (jj > ii) continue;
       const int i = reach_row(p2, nrb, ii), j = reach_row(p2, nrb, jj);
       real sacc = 0;
-      for (int k = 0; k < w; k++) sacc += S.panel[i][k] * S.panel[j][k];
+      { const real* pi = panel_row(i); const real* pj = panel_row(j); for (int k = 0; k < w; k++) sacc += pi[k] * pj[k]; }
       *hptr<INLDS>(i, j) -= (double)sacc;
     }
   }

@@ -27,6 +27,9 @@
 #else
 #define UR5_KERNEL_ATTR(GS) __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((GS) < 64 ? 1 : UR5_WAVES_PER_EU)))
 #endif
+#if defined(UR5_MANY) && defined(UR5_MANY_OCC2)
+static_assert(2 * sizeof(ur5::Lds<double, UR5_MAXNV>) <= 160 * 1024, "two 40-object scenes per CU: the pile's LDS image must stay below 80 KB");
+#endif
 #if !defined(UR5_MANY) && !defined(UR5_PROFILE)   // (the per-phase cycle accounting build adds its counters to the image)
 static_assert(8 * sizeof(ur5::Lds<double, 32>) <= 160 * 1024, "the IT1 scene image must leave room for 8 scenes per CU (2 waves per SIMD): LDS is what caps residency");
 #endif

@@ -16,7 +16,7 @@ DEFAULT_LIB = os.path.join(_HERE, "csrc", "libur5sim.so")
 
 RES_NONE, RES_SUCCESS, RES_MAX_STEPS, RES_IK_FAIL = -1, 0, 1, 2
 # limits of the two engine variants (csrc/ur5_devmodel.h): (max objects, debug stride, record stride, max contacts)
-_VARIANT = {0: (6, 2048, 192, 30), 1: (40, 4096, 832, 160)}
+_VARIANT = {0: (6, 2048, 192, 30), 1: (40, 4096, 832, 96)}
 EXPORTS = ["ur5_last_error", "ur5_create", "ur5_destroy", "ur5_num_envs", "ur5_nq", "ur5_nv", "ur5_nu", "ur5_reset", "ur5_reset_dev", "ur5_kernel_ms_total",
            "ur5_set_state", "ur5_get_state", "ur5_set_ctrl", "ur5_get_ctrl", "ur5_step", "ur5_move_group", "ur5_stay",
            "ur5_move_ee", "ur5_ik", "ur5_grasp_attempt", "ur5_grasp_attempt_dev", "ur5_grasp_attempt_reset_dev", "ur5_sync", "ur5_set_stream", "ur5_set_order_dev", "ur5_last_launch_ms",
