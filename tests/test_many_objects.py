@@ -330,8 +330,11 @@ def test_pile_grasp_bits_against_the_oracle_on_gpu(model_many):
     bits = sum(int(r == rew[e]) for e, (r, _) in zip(sel, res))
     codes = sum(int(pro.tolist() == pr[e].tolist()) for e, (_, pro) in zip(sel, res))
     assert sum(orew) >= 2, orew                                               # a statistic with positives (28 % in the 256-scene run)
-    # (the four wavefronts of a pile add into LDS accumulators in an order that can differ from run to run: the bound is statistical, 3 of 24 at 95 % per scene is P < 3 %)
-    assert bits >= n - 3 and codes >= n - 6, (bits, codes, rew[sel].tolist(), orew)   # piles are chaotic: 95-97 % agreement per scene in the 256-scene run
+    # Piles are chaotic, and round 4 measured how chaotic (tools/pile_chaos_floor.py, profiles/r04_pile_chaos_floor_256of3072.json): the ORACLE agrees with its own
+    # rounding-level twins -- the same contacts in reversed order, one coordinate moved by 1 ulp -- on 94.5-96.1 % of the grasp bits and 89-91 % of the result codes of
+    # 256 such attempts; the kernel (deterministic since round 4: a failing scene can be replayed) agrees with the oracle and its twins on 94.1-95.7 % / 89-91 %. The bound
+    # is therefore statistical: at 94.5 % per scene, 5 or more of 24 bits differ with P ~ 1 %; at 90 %, 8 or more of 24 code vectors with P < 1 %.
+    assert bits >= n - 4 and codes >= n - 7, (bits, codes, rew[sel].tolist(), orew)
 
 
 @pytest.mark.gpu

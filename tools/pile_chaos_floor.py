@@ -20,7 +20,7 @@ limit = int(sys.argv[3]) if len(sys.argv) > 3 else 10 ** 9
 D = {k: v for k, v in np.load(src).items()}                  # in memory: the threads index these arrays
 n = min(limit, len(D["sel"]))
 m = load_model("/UR5+gripper/UR5gripper_2_finger_many_objects.xml")
-VARIANTS = ("base", "reversed_contacts", "one_ulp")
+VARIANTS = tuple(sys.argv[4].split(",")) if len(sys.argv) > 4 else ("base", "reversed_contacts", "one_ulp")   # "base" alone: GPU-vs-oracle of a new kernel against the recorded floor
 
 
 def one(job):
@@ -60,6 +60,10 @@ def compare(A, B):
 
 
 gpu = [(int(D["gpu_reward"][e]), D["gpu_phase_steps"][e], D["gpu_phase_result"][e], D["gpu_qpos_after"][e]) for e in range(n)]
+if VARIANTS == ("base",):
+    print(json.dumps(dict(scenes=n, source=os.path.basename(src), oracle_seconds=round(time.time() - t0, 1), threads=threads, gpu_vs_oracle=compare(R["base"], gpu),
+                          note="GPU kernel vs the oracle from the kernel's settled states; the floor to compare with is profiles/r04_pile_chaos_floor_256of3072.json")))
+    sys.exit(0)
 out = dict(scenes=n, source=os.path.basename(src), oracle_seconds=round(time.time() - t0, 1), threads=threads,
            oracle_newton_iters_per_step=float(sum(r[4] for r in R["base"]) / max(1, sum(r[5] for r in R["base"]))),
            oracle_vs_oracle_reversed_contacts=compare(R["base"], R["reversed_contacts"]),
@@ -67,4 +71,8 @@ out = dict(scenes=n, source=os.path.basename(src), oracle_seconds=round(time.tim
            oracle_reversed_vs_oracle_one_ulp=compare(R["reversed_contacts"], R["one_ulp"]),
            gpu_vs_oracle=compare(R["base"], gpu), gpu_vs_oracle_reversed_contacts=compare(R["reversed_contacts"], gpu), gpu_vs_oracle_one_ulp=compare(R["one_ulp"], gpu),
            note="all runs start from the HIP kernel's settled state of the same scenes; 'floor' = agreement of the oracle with its own rounding-level twins")
+fl = [out[k]["grasp_bit_agreement"] for k in ("oracle_vs_oracle_reversed_contacts", "oracle_vs_oracle_one_ulp", "oracle_reversed_vs_oracle_one_ulp")]
+gp = [out[k]["grasp_bit_agreement"] for k in ("gpu_vs_oracle", "gpu_vs_oracle_reversed_contacts", "gpu_vs_oracle_one_ulp")]
+out["summary"] = dict(floor_grasp_bit_agreement_min_mean_max=[min(fl), sum(fl) / 3, max(fl)], gpu_grasp_bit_agreement_min_mean_max=[min(gp), sum(gp) / 3, max(gp)],
+                      gpu_at_or_above_floor_minus_1_percent=bool(min(gp) >= min(fl) - 0.01))
 print(json.dumps(out))
