@@ -338,7 +338,7 @@ template <class real, int NV_> struct Lds {
     real H[HSIZE];
 #else
     real tw[NSLOT][6];                               // body twists of a dof vector: built and consumed inside images() / the Newton warm start
-    real stw[2 * UR5_MAXCON][6];                     // staged wrench terms of the contact sides: built and consumed inside contact_gather()
+    real stw[2 * UR5_MAXCON][6];                     // staged wrench terms of the contact sides: built and consumed inside contact_gather(); the factorisation's panel rows
 #endif
   };
 #ifdef UR5_MANY
@@ -1502,9 +1502,11 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
         const int b = body_of_geom(g);
         v3 om(S.cvel[b]), vl(S.cvel[b] + 3);
         const v3 v = vl + cross(om, v3(S.dgpos[i]) - body_ref(b));
-        const float mv = S.moved[i] + (float)(norm(v) * h * (real)1.0001 + (real)1e-9);
+        // |v| h is the travel to first order; along a step the velocity of a point on the articulated chain turns by up to |omega| h (second-order term
+        // <= |omega|^2 r h^2 / 2, ~0.3 % of |v| h at 3 rad/s): 1 % of inflation and a rebuild at 90 % of the slack keep the superset property strict
+        const float mv = S.moved[i] + (float)(norm(v) * h * (real)1.01 + (real)1e-9);
         S.moved[i] = mv;
-        if (!(mv <= (float)UR5_SUP_DELTA)) over = true;
+        if (!(mv <= (float)(0.9 * UR5_SUP_DELTA))) over = true;
       }
       if (over) S.nsup = -1;   // benign race: every writer stores the same value
       SYNC();
@@ -2599,7 +2601,17 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
   }
   UR5_FN int blk_of_body(int b) const { return b < M.nrd ? M.nobj : S.obj_rank[b - M.nrd]; }
   UR5_FN int blk_width(int p) const { return p < M.nobj ? 6 : M.nrd; }
-  UR5_FN real* panel_row(int i) { return S.hess + UR5_SCR_PANEL + UR5_MAXRD * i; }   // current block column of the factorisation, by global row
+  UR5_FN real* panel_row(int i) { return S.hess + UR5_SCR_PANEL + UR5_MAXRD * i; }   // current block column of the factorisation, by global row (global scratch)
+  // ... or, when the panel is an object's (6 columns) and at most LPANEL_ROWS rows reach it -- nearly always --, in the wavefront's quarter of the LDS area that the
+  // staged wrench terms / body twists / kinematic temporaries use at other times (nothing else touches it during a factorisation), indexed by the row's position
+  // among the reaching rows: the write -> barrier -> read of every level stays out of global memory
+  static constexpr int LPANEL_ROWS = 2 * UR5_MAXCON * 6 / (UR5_NT / 64) / 6;
+  UR5_FN static bool panel_in_lds(int w, int nr) { return w == 6 && nr <= LPANEL_ROWS; }
+#ifdef UR5_EMUL
+  UR5_FN real* panel_at(int i, int c, bool inl) { return inl ? &S.stw[0][0] + 6 * c : panel_row(i); }
+#else
+  UR5_FN real* panel_at(int i, int c, bool inl) { return inl ? &S.stw[0][0] + (UR5_LANE >> 6) * (LPANEL_ROWS * 6) + 6 * c : panel_row(i); }
+#endif
   template <bool INLDS> UR5_FN double* hptr(int I, int J) { return (INLDS ? S.henv : S.hess) + S.env_ptr[I] + (J - S.env_first[I]); }
   UR5_BIG void envelope_structure() {
     static_assert(UR5_NT >= UR5_MAXNV, "one thread per Hessian row");
@@ -2918,6 +2930,9 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       d.inv[a] = c[36 + a];
     }
   }
+  // (Round 4 also tried an LDS copy of the factored diagonal blocks for the duration of every triangular solve -- 9 KB packed, one cooperative copy per solve into the
+  // staging area: the solves got 8 % SLOWER (one more memory round trip and two barriers per solve; the per-level fetches hit the vector L1 anyway),
+  // profiles/r04_i_many_phase_cycles_512piles.log. The level loops are bound by their dependent arithmetic and barriers, not by where the blocks live.)
   template <int W> UR5_FN static real pick(const real (&v)[W], int k) {   // v[k] without a run-time register index
     real o = v[0];
 #pragma unroll
@@ -2950,7 +2965,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     diag_factor<INLDS, W>(c0, d);
     if (r == 0) diag_store<W>(p2, d);
   }
-  template <bool INLDS, int W> UR5_FN void factor_panel_row(int i, int ii, int p2, int c0) {
+  template <bool INLDS, int W> UR5_FN void factor_panel_row(int i, int ii, int p2, int c0, bool inl) {
     Diag<W> d;
     const bool prefactored = S.blk_first[p2] == p2;
     if (prefactored) diag_cached<W>(p2, d); else diag_factor<INLDS, W>(c0, d);
@@ -2974,8 +2989,11 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
         out[k] = sacc * d.inv[k];
       }
     }
+    if (ii >= W) {   // (the block's own rows live on in dcache; only the rows below it are read back by the trailing update)
+      real* o = panel_at(i, ii - W, inl);
 #pragma unroll
-    for (int k = 0; k < W; k++) panel_row(i)[k] = out[k];
+      for (int k = 0; k < W; k++) o[k] = out[k];
+    }
   }
   // Work split inside a level: on the GPU wavefront w of the workgroup owns panel base + w of the pass and its 64 lanes stride over
   // that panel's rows; the lane-emulation build walks the panels of a pass one after the other.
@@ -2992,9 +3010,10 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
   template <bool INLDS> UR5_FN void panel_factor_rows(int p2) {
     const int c0 = 6 * p2, w = blk_width(p2);
     const int nrb = S.reach_ptr[p2 + 1] - S.reach_ptr[p2], nr = reach_rows(p2, nrb);
+    const bool inl = panel_in_lds(w, nr);
     UR5_PLANE(t, w + nr) {
       const int i = t < w ? c0 + t : reach_row(p2, nrb, t - w);
-      if (p2 < M.nobj) factor_panel_row<INLDS, 6>(i, t, p2, c0); else factor_panel_row<INLDS, UR5_MAXRD>(i, t, p2, c0);
+      if (p2 < M.nobj) factor_panel_row<INLDS, 6>(i, t, p2, c0, inl); else factor_panel_row<INLDS, UR5_MAXRD>(i, t, p2, c0, inl);
     }
   }
   // A2: the finished column entries of the rows below go back to H (the block itself lives on in dcache);
@@ -3002,17 +3021,19 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
   template <bool INLDS> UR5_FN void panel_trailing_update(int p2) {
     const int c0 = 6 * p2, w = blk_width(p2);
     const int nrb = S.reach_ptr[p2 + 1] - S.reach_ptr[p2], nr = reach_rows(p2, nrb);
+    const bool inl = panel_in_lds(w, nr);
     UR5_PLANE(c, nr) {
       const int i = reach_row(p2, nrb, c);
       double* row = hptr<INLDS>(i, c0);
-      for (int k = 0; k < w; k++) row[k] = (double)panel_row(i)[k];
+      const real* pr = panel_at(i, c, inl);
+      for (int k = 0; k < w; k++) row[k] = (double)pr[k];
     }
     UR5_PLANE(idx, nr * nr) {
       const int ii = idx / nr, jj = idx - ii * nr;
       if (jj > ii) continue;
       const int i = reach_row(p2, nrb, ii), j = reach_row(p2, nrb, jj);
       real sacc = 0;
-      { const real* pi = panel_row(i); const real* pj = panel_row(j); for (int k = 0; k < w; k++) sacc += pi[k] * pj[k]; }
+      { const real* pi = panel_at(i, ii, inl); const real* pj = panel_at(j, jj, inl); for (int k = 0; k < w; k++) sacc += pi[k] * pj[k]; }
       *hptr<INLDS>(i, j) -= (double)sacc;
     }
   }

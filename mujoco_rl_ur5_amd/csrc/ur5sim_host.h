@@ -430,7 +430,8 @@ struct ur5_sim {
   double *d_target = nullptr, *d_tol = nullptr, *d_debug = nullptr, *d_hess = nullptr, *d_qpos0 = nullptr;
   void* d_gpose = nullptr;        // render: per-scene geom poses + screen boxes (HIP backend)
   const int* d_order = nullptr;   // dispatch order of the scripted launches (ur5_set_order_dev), NULL = scene order; points at d_order_buf
-  int* d_order_buf = nullptr;     // handle-owned copy: the caller's tensor may be freed or rewritten once ur5_set_order_dev has returned
+  int* d_order_buf = nullptr;     // handle-owned copy, made by an ASYNCHRONOUS device-to-device copy on the handle's stream: the caller's buffer must stay valid (and unmodified) until the work
+                                  // queued on that stream so far has run (include/ur5sim.h); same-stream callers (ur5_set_stream) have nothing to do
   uint64_t model_hash = 0;        // of hm: handles with equal models share the device's constant-memory copy
   double kernel_ms_total = 0;   // engine-kernel time of every launch since ur5_create (HIP events on the handle's stream)
   int *d_max = nullptr, *d_result = nullptr, *d_steps = nullptr, *d_ps = nullptr, *d_pr = nullptr;

@@ -86,7 +86,7 @@ class GraspEnv(object):
             if world > 1 and self.first_scene_id == dist.get_rank() * self.n_envs:
                 n_total = world * self.n_envs                                # this rank's contiguous shard (sharding.shard_range)
             elif self.first_scene_id == 0:
-                n_total = self.n_envs                                        # a stand-alone handle
+                n_total = self.n_envs                                        # a stand-alone handle (also on rank 0 of a multi-rank job that shards by hand: pass n_total there)
             else:
                 raise ValueError("first_scene_id > 0 needs n_total (the global scene count): seeds are keyed by global scene id and episode, "
                                  "and a per-rank stride would make ranks re-simulate each other's episodes")

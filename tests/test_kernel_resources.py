@@ -42,6 +42,8 @@ def test_kernel_registers_and_scratch(tmp_path):
     assert small["max_flat_workgroup_size"] == 64 and many["max_flat_workgroup_size"] == 256
     assert small["private_segment_fixed_size"] <= 512, small                    # B per lane, the whole call tree (was 1 216)
     assert six["private_segment_fixed_size"] <= 800, six                        # 824 until the integration became a real function in this instantiation
-    assert many["private_segment_fixed_size"] <= 768 and many["vgpr_count"] == 512, many   # 512 in round 3; the fixed-order gathers of round 4 cost two more spilled doubles
+    # round 4: TWO pile scenes per CU -- the kernel is capped at 256 registers (same-box A/B of the cap alone: +-0 %, the step is latency-bound), spills 1 KB per lane, and
+    # its LDS image must leave room for a second scene (checked where the image is defined: static_assert in csrc/ur5sim.hip; the launch passes sizeof(Lds) as dynamic LDS)
+    assert many["private_segment_fixed_size"] <= 1280 and many["vgpr_count"] <= 256, many
     assert find("ur5_render_kernel")["private_segment_fixed_size"] == 0
     assert small["group_segment_fixed_size"] == 0                               # the scene is dynamic LDS, sized at launch
