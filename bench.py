@@ -5,6 +5,7 @@ closing check (README.md:20 of the reference). A "step" is one grasp-attempt rou
 
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py --gpus N ...          (no launcher: bench.py starts the N ranks itself through torch.distributed.run, RCCL, 127.0.0.1)
 
 Workload (stationary by construction, stated in the JSON line as config.rule):
   * every scene lives through episodes of EP = 4 rounds: one grasp attempt per round, and after the last one reset_model (objects
