@@ -390,7 +390,7 @@ def main():
     ap.add_argument("--groups", type=int, default=2, help="scene groups per GPU, one engine handle + HIP stream each, rounds pipelined (1 = one handle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the uniform-rule figure and the it4 / many sub-results (N = 1 only)")
-    ap.add_argument("--sub", choices=("it4", "many", "many4096", "dqn"), default=None,
+    ap.add_argument("--sub", choices=("it4", "many", "many4096", "dqn", "dqn2048"), default=None,
                     help="run ONLY this secondary measurement (N = 1) and print it as {name: result}: what the rocprofv3 passes of tools/gpu_evidence_extras.sh profile")
     ap.add_argument("--sub-scenes", type=int, default=None, help="with --sub: scene count instead of the sub-result's own (same-box A/Bs of engine builds)")
     ap.add_argument("--sub-rounds", type=int, default=None, help="with --sub: timed rounds")
@@ -428,7 +428,10 @@ def main():
     subs = {"it4": lambda cpu: rendered_sub_result(torch, dist, sharding, dev, dev_id, "it4", 4096, 4, 1, cpu),
             "many": lambda cpu: rendered_sub_result(torch, dist, sharding, dev, dev_id, "many", 2048, 2, 1, cpu),   # BASELINE configs[3]: 16384 piles on 8 GPUs = 2048 per GPU
             "many4096": lambda cpu: rendered_sub_result(torch, dist, sharding, dev, dev_id, "many", 4096, 2, 1, False),   # north_star: "a 4096-env synthetic pile" on one GPU
-            "dqn": lambda cpu: dqn_sub_result(torch, dev, dev_id, 512, 2, 1)}
+            "dqn": lambda cpu: dqn_sub_result(torch, dev, dev_id, 512, 2, 1),
+            # the same loop at the per-GPU scene count of configs[3] / [4] (16384 piles on 8 GPUs): with 512 piles a round lasts as long as its longest scene (2 piles per CU,
+            # every scene resident at once: the chip idles through the tail), with 2048 the tail amortises
+            "dqn2048": lambda cpu: dqn_sub_result(torch, dev, dev_id, 2048, 1, 1)}
     if args.sub:
         if args.sub in ("it4", "many", "many4096") and (args.sub_scenes or args.sub_rounds or args.sub_groups != 2):
             wl = "it4" if args.sub == "it4" else "many"
@@ -531,14 +534,14 @@ def main():
     if rank == 0 and world == 1 and not args.no_extras:
         torch.cuda.synchronize()
         # the headline line must not depend on the secondary measurements: a failure there is reported in place of the sub-result
-        for key in ("it4", "many", "many4096", "dqn"):
+        for key in ("it4", "many", "many4096", "dqn", "dqn2048"):
             fn = (lambda k=key: subs[k](not args.no_cpu_baseline))
             try:
                 out[key] = fn()
             except Exception as exc:  # noqa: BLE001
                 out[key] = {"error": f"{type(exc).__name__}: {exc}"}
         # the secondary results once more as top-level scalars (a driver that keeps only scalar keys of the line keeps these)
-        for key in ("it4", "many", "many4096", "dqn"):
+        for key in ("it4", "many", "many4096", "dqn", "dqn2048"):
             for f in ("env_steps_per_s", "grasp_attempts_per_s", "roofline_frac", "grasp_success_rate", "newton_iters_per_step"):
                 if isinstance(out.get(key), dict) and f in out[key]:
                     out[f"{key}_{f}"] = out[key][f]

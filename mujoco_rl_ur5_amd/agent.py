@@ -277,6 +277,16 @@ class BatchedGraspAgent:
         losses, utd = self.learner.push_and_learn(state, action, reward, learn=learn, outcomes=outcomes if self.world > 1 else None,
                                                   first_scene_id=self.first_scene_id, n_actions_1=self.n_actions_1)   # :551-556
         self.last_loss = losses[-1] if losses else None
+        if self.world > 1 and learn and losses:
+            # The replicas take identical steps on identical batches, but GPU kernels are not bit-reproducible across processes (MIOpen's weight-gradient kernels
+            # accumulate with atomics): left alone the copies drift apart at rounding level. One broadcast of rank 0's weights, batch-norm buffers and Adam moments
+            # per round (88 MB over RCCL, against seconds of physics) makes "one agent" exact again; on the CPU it is a copy of equal values.
+            for t in list(self.policy_net.parameters()) + list(self.policy_net.buffers()):
+                sharding.broadcast_from_rank0(t.data)
+            for st in self.optimizer.state.values():
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        sharding.broadcast_from_rank0(v)
         self.rounds_done += 1
         return {"observation": raw, "action": action, "reward": reward, "skipped": skipped, "greedy": greedy, "loss": self.last_loss if learn else None, "losses": losses,
                 "update_to_data": utd, "outcomes": outcomes, "epsilon": self.eps_threshold}

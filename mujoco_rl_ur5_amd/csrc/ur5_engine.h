@@ -3297,13 +3297,21 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       if (sn < (real)1e-15) break;
       real gtol = tolerance * (real)0.01 * sn / scale;
       real lo = 0, hi = -1, a = 0, d1, d2;
-#if defined(UR5_MANY) && !defined(UR5_EMUL) && UR5_NT > 64 && !defined(UR5_LS_BLOCK)
+#if !defined(UR5_EMUL) && ((defined(UR5_MANY) && UR5_NT > 64 && !defined(UR5_LS_BLOCK)) || (!defined(UR5_MANY) && !defined(UR5_SMALL_LS_LDS)))
       // The exact line search is a scalar iteration over sums of <= 160 contacts + 16 rows: with the contacts spread over the workgroup every evaluation paid two
       // workgroup barriers and an LDS round trip for ~100 instructions of work. Wavefront 0 alone takes all of it: lane l keeps contacts l, l + 64, l + 128 (their
       // images along the iterate and along the search direction, friction factors folded in) and special row l in registers for the whole search, an evaluation is
       // pure arithmetic + three DPP wave sums, and the other wavefronts wait at ONE barrier for the step length and the constraint cost at it.
+      // The wavefront-per-scene kernel searches the same way (its scene has one wavefront: nothing to broadcast, contact l on lane l): +3.2 % env-steps/s on the headline
+      // workload, same-box A/B (profiles/r04_n_ab_small_line_search_in_registers.log); -DUR5_SMALL_LS_LDS is the old search that re-reads the images from LDS per evaluation
       real ccost_a = 0;
+#if UR5_NT > 64
+#define UR5_LS_SUM(v) ur5_wave_sum(v)
       if (UR5_LANE < 64) {
+#else
+#define UR5_LS_SUM(v) group_sum(v)
+      {
+#endif
         constexpr int CPL = (UR5_MAXCON + 63) / 64;
         real e0[CPL], j0[CPL], Dc[CPL], ek[CPL][NB - 1], jk[CPL][NB - 1];
         int nk[CPL];                        // friction directions of the slot's contact (0: a frictionless contact, one row); -1: no contact
@@ -3345,7 +3353,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
             }
           }
           if (has_row) { const real r = r0 + alpha * rv; if (!r_uni || r < 0) { cc += (real)0.5 * rD * r * r; g1 += rD * r * rv; g2 += rD * rv * rv; } }
-          cc = ur5_wave_sum(cc); g1 = ur5_wave_sum(g1); g2 = ur5_wave_sum(g2);
+          cc = UR5_LS_SUM(cc); g1 = UR5_LS_SUM(g1); g2 = UR5_LS_SUM(g2);
         };
         real kc, k1, k2;
         eval(0, kc, k1, k2);
@@ -3362,10 +3370,16 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
             if (d1 < 0) lo = a; else hi = a;
           }
         }
+#if UR5_NT > 64
         if (UR5_LANE == 0) { S.red[0] = a; S.red[1] = kc; }                  // kc: the constraint cost at the last point evaluated = the accepted step
       }
       SYNC();
       a = S.red[0]; ccost_a = S.red[1];
+#else
+        ccost_a = kc;
+      }
+#endif
+#undef UR5_LS_SUM
       if (a <= 0) break;
       SYNC();
       PAR(i, nv) { S.x[i] += a * S.search[i]; S.Ma[i] += a * S.Mv[i]; }

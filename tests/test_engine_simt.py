@@ -142,7 +142,7 @@ def test_cross_lane_operation_budget_of_a_step(model_it1, simt_lib):
     sim.step(50)
     dpp, readlane, shuffle, ballot, wave_barrier, block_barrier, atomic, _ = (counts() - c0) / 50
     assert 30 <= wave_barrier <= 60 and block_barrier == 0, wave_barrier
-    assert 150 <= dpp <= 260 and 20 <= readlane <= 60 and 80 <= shuffle <= 160 and ballot <= 8, (dpp, readlane, shuffle, ballot)
+    assert 110 <= dpp <= 260 and 20 <= readlane <= 60 and 80 <= shuffle <= 160 and ballot <= 8, (dpp, readlane, shuffle, ballot)   # 144 DPP moves since the line search reuses its last cost (round 4)
     assert 10 <= atomic <= 40, atomic
 
 

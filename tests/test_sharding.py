@@ -82,8 +82,8 @@ def test_two_rank_gloo_gather_equals_single_process(emul_lib, model_it1, tmp_pat
     assert got[16:].astype(int).tolist() == ps[:2].ravel().tolist()       # rank 0's scenes: same step counts as the 1-rank run
 
 
-def _agent_worker(rank, world, port, emul_lib, out, n_total, rounds):
-    """One rank of the config-5 loop (mujoco_rl_ur5_amd/agent.py) on the lane-emulation engine with host tensors."""
+def _agent_worker(rank, world, port, emul_lib, out, n_total, rounds, device="cpu", width=24):
+    """One rank of the config-5 loop (mujoco_rl_ur5_amd/agent.py): the lane-emulation engine with host tensors, or (device "cuda") the real library on cuda:0."""
     import hashlib
     import torch
     import torch.distributed as dist
@@ -97,19 +97,21 @@ def _agent_worker(rank, world, port, emul_lib, out, n_total, rounds):
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     lo, hi = sharding.shard_range(n_total, rank, world)
+    if device != "cpu":
+        torch.cuda.set_device(0)
     env = GraspEnv(file=load_model("it1_4box"), n_envs=hi - lo, first_scene_id=lo, n_total=n_total, show_obs=False, observation="render",
-                   image_width=24, image_height=24, check_mode=1, _lib_path=emul_lib)
+                   image_width=width, image_height=width, check_mode=1, _lib_path=emul_lib)
     env.reset()
-    agent = BatchedGraspAgent(env=env, device="cpu", mem_size=40, eps_start=0.5, eps_end=0.5, max_updates_per_round=4)
+    agent = BatchedGraspAgent(env=env, device=device, mem_size=40, eps_start=0.5, eps_end=0.5, max_updates_per_round=4)
     assert agent.memory.shared == (world > 1)
     losses, recs, greedy = [], [], []
     for _ in range(rounds):
         o = agent.round()
         losses += o["losses"]
-        recs.append(o["outcomes"].numpy().copy())
-        greedy.append(o["greedy"].numpy().copy())
+        recs.append(o["outcomes"].cpu().numpy().copy())
+        greedy.append(o["greedy"].cpu().numpy().copy())
     w = torch.cat([p.detach().reshape(-1) for p in agent.policy_net.parameters()] + [b.detach().reshape(-1).float() for b in agent.policy_net.buffers()])
-    digest = hashlib.sha256(w.numpy().tobytes()).hexdigest()
+    digest = hashlib.sha256(w.cpu().numpy().tobytes()).hexdigest()
     res = dict(rank=rank, losses=losses, recs=np.stack(recs), digest=digest, greedy=np.concatenate(greedy), updates=agent.learner.updates_done,
                ring=(agent.memory.position, agent.memory.count), owned=int(agent.memory.owned.sum()) if world > 1 else -1)
     if world > 1:
@@ -145,6 +147,28 @@ def test_two_ranks_are_one_agent(emul_lib, tmp_path):
     assert b0["losses"] == b1["losses"] == a["losses"]                                            # one learner: the same optimiser steps everywhere
     assert b0["digest"] == b1["digest"] == a["digest"]                                            # bit-identical weights (and batch-norm buffers)
     assert b0["ring"] == b1["ring"] == a["ring"] and b0["owned"] + b1["owned"] == min(40, n_total * rounds)   # every slot's image lives on exactly one rank
+
+
+@pytest.mark.gpu
+def test_two_ranks_are_one_agent_on_gpu(tmp_path):
+    """The same on the MI355X: two ranks with 4 scenes each on cuda:0 (gloo collective; the shared replay's batch all-reduce and the outcome gather go through host memory,
+    RCCL on a real multi-GPU node), the real libur5sim.so, 64 x 64 observations, the GEMM convolution paths. GPU kernels are not bit-reproducible across processes
+    (MIOpen's weight-gradient kernels accumulate with atomics: without the per-round weight broadcast of agent.round() the two replicas' digests differed after 5 rounds), so:
+    bit-identical weights on both ranks at the end of every round, loss sequences equal to rounding, outcome records equal; against one rank with 8 scenes the
+    records of the rounds before the first optimiser step are equal by construction and the first losses agree to rounding."""
+    import pickle
+    import torch.multiprocessing as mp
+    port = 29500 + (os.getpid() % 2000) + 11
+    one, two = str(tmp_path / "one.pkl"), str(tmp_path / "two.pkl")
+    n_total, rounds = 8, 5
+    mp.spawn(_agent_worker, args=(1, port, None, one, n_total, rounds, "cuda", 64), nprocs=1, join=True)
+    mp.spawn(_agent_worker, args=(2, port + 1, None, two, n_total, rounds, "cuda", 64), nprocs=2, join=True)
+    (a,), (b0, b1) = pickle.load(open(one, "rb")), pickle.load(open(two, "rb"))
+    assert b0["updates"] == b1["updates"] == a["updates"] >= 6
+    assert b0["digest"] == b1["digest"] and np.allclose(b0["losses"], b1["losses"], rtol=1e-4)    # the replicas of one learner
+    assert np.array_equal(b0["recs"], b1["recs"]) and np.array_equal(a["recs"][:3], b0["recs"][:3])   # before the first optimiser step: identical by construction
+    assert np.allclose(a["losses"][:2], b0["losses"][:2], rtol=1e-3)
+    assert b0["ring"] == b1["ring"] == a["ring"] and b0["owned"] + b1["owned"] == 40
 
 
 def _gpu_worker(rank, world, port, n_total, out):
