@@ -222,7 +222,7 @@ constexpr int NB = UR5_NB;  // base directions per contact: normal, 2 tangents, 
 // another portal face now and then (a 5e-3 jump of a contact normal), and piles of cylinders are full of the degenerate configurations where that happens.
 // With identical arithmetic the kernel reproduces the oracle's contacts from the same state instead of its own variant of them. The wavefront-per-scene
 // kernel keeps contraction: its scenes have few such pairs, and kinematics + collision are a third of its step.
-#if defined(UR5_MANY) && !defined(UR5_EMUL) && !defined(UR5_SIMT)
+#if (defined(UR5_MANY) || defined(UR5_STRICT_SMALL)) && !defined(UR5_EMUL) && !defined(UR5_SIMT)
 #pragma clang fp contract(off)
 #define UR5_STRICT _Pragma("clang fp contract(off)")
 #else
@@ -306,7 +306,7 @@ template <class T> UR5_FN T minv(T a, T b) { return a < b ? a : b; }
 // index of (i, j), i >= j, in a packed symmetric 6x6 (21 entries, row-major lower)
 UR5_FN int sym6(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
 
-#if defined(UR5_MANY) && !defined(UR5_EMUL) && !defined(UR5_SIMT)
+#if (defined(UR5_MANY) || defined(UR5_STRICT_SMALL)) && !defined(UR5_EMUL) && !defined(UR5_SIMT)
 #pragma clang fp contract(fast)
 #endif
 // ---------------------------------------------------------------------------------------------- LDS image of one scene

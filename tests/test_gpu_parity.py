@@ -78,7 +78,7 @@ def test_grasp_attempt_matches_oracle_and_golden(native_mod, model_it1):
         assert r == rew[e]                                                     # grasp bit
         assert pso.tolist() == ps[e].tolist()
         rel = np.abs(s2["qpos"][e][:8] - so["qpos"][:8]).max() / max(1.0, np.abs(so["qpos"][:8]).max())
-        assert rel < 1e-4
+        assert rel < 1e-9                                                      # measured 4e-16 (profiles/r04_p_drop_parity.log)
         # the objects are joints too. Scene e aims at box e % 4: the three boxes it never touches must agree like the arm does; the aimed
         # one is carried over the drop bin and released 0.5 m above its floor (check_mode 0). Measured on the oracle (round 4,
         # tests/test_oracle_kat.py::test_how_far_a_small_scene_attempt_amplifies_a_perturbation): a 1e-13 m perturbation stays below 1e-9 -- summation order
@@ -86,8 +86,10 @@ def test_grasp_attempt_matches_oracle_and_golden(native_mod, model_it1):
         # arithmetic in the kernel) moves the released box by up to 0.11 m while reward and all step counts stay equal
         eo = np.abs(s2["qpos"][e][8:] - so["qpos"][8:]).reshape(-1, 7)[:, :3].max(axis=1)
         others = np.delete(eo, e % 4)
-        assert others.max() < 1e-6, (e, eo)
-        assert eo[e % 4] < 5e-2, (e, eo)
+        # Round 4 measured all of it (tools/gpu_drop_parity.py, 32 scenes, 22 successes: arm 4e-16, untouched boxes <= 3e-11, the released box <= 5e-11) and tightened the
+        # bounds that dated from the 32-vertex hull approximations: 5 cm -> 1e-7 m for the released box, 1e-6 -> 1e-8 for the others
+        assert others.max() < 1e-8, (e, eo)
+        assert eo[e % 4] < 1e-7, (e, eo)
         agree += 1
     assert agree == 8 and set(np.unique(rew)) == {0, 1}
     assert np.all(sim.counters()["status"] == 0)
