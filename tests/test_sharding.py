@@ -167,9 +167,9 @@ def test_two_ranks_are_one_agent_on_gpu(tmp_path):
     assert b0["updates"] == b1["updates"] == a["updates"] >= 6
     # the replicas of one learner: equal weights at every round's end (the broadcast); inside a round the ranks' own loss values drift apart -- Adam turns the
     # rounding-level gradient differences of non-reproducible GPU kernels into percent-level loss differences within four steps -- and rank 0's are the agent's
-    assert b0["digest"] == b1["digest"] and np.allclose(b0["losses"][:2], b1["losses"][:2], rtol=1e-3) and np.allclose(b0["losses"], b1["losses"], rtol=0.15)
+    assert b0["digest"] == b1["digest"] and abs(b0["losses"][0] - b1["losses"][0]) < 1e-4 * b0["losses"][0] and np.allclose(b0["losses"], b1["losses"], rtol=0.15)
     assert np.array_equal(b0["recs"], b1["recs"]) and np.array_equal(a["recs"][:3], b0["recs"][:3])   # before the first optimiser step: identical by construction
-    assert np.allclose(a["losses"][:2], b0["losses"][:2], rtol=1e-3)
+    assert abs(a["losses"][0] - b0["losses"][0]) < 1e-4 * a["losses"][0] and np.allclose(a["losses"][:2], b0["losses"][:2], rtol=0.05)   # the first loss precedes any update; one Adam step later the runs are 1e-3 apart
     assert b0["ring"] == b1["ring"] == a["ring"] and b0["owned"] + b1["owned"] == 40
 
 
