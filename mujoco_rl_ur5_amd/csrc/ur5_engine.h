@@ -2124,10 +2124,22 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
   // per side -- wrench terms [side][6] in the panel area (only the factorisation uses it), Hessian terms [side][21] in the envelope area (G is only built when the
   // envelope is about to be re-assembled) --, then lane (slot, entry) adds its slot's sides in list order = contact order. No float atomic, no dependence on the
   // wavefronts' timing; every entry of every slot is written, so nothing is zeroed first. Contacts are staged UR5_GCHUNK at a time (a settled pile has 40-80).
+#ifdef UR5_STG_LDS
+  // experiment (round 4): the Hessian terms staged in LDS too, 21 contacts at a time (their 42 sides' 6 wrench + 21 Hessian terms fill the 9 KB staging area), instead of
+  // all at once in the scene's global scratch: no scratch traffic for the staging, two more barrier pairs and list walks per refactorisation
+  static constexpr int GCHUNK = 2 * UR5_MAXCON * 6 / 54;
+  static constexpr bool STW_REL = true;
+#else
   static constexpr int GCHUNK = UR5_MAXCON;          // (the staging area in the scene's global scratch holds every side: one round)
+  static constexpr bool STW_REL = false;
+#endif
   UR5_FN void contact_gather(const bool doW, const bool doG) {
     real* const stW = &S.stw[0][0];
+#ifdef UR5_STG_LDS
+    real* const stG = &S.stw[0][0] + 12 * GCHUNK;
+#else
     real* const stG = S.hess + UR5_SCR_STG;
+#endif
     const int chunk = doG ? GCHUNK : UR5_MAXCON;
     for (int c0 = 0; c0 == 0 || c0 < S.ncon; c0 += chunk) {
       const int c1 = c0 + chunk < S.ncon ? c0 + chunk : S.ncon;
@@ -2145,7 +2157,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
           v3 T = ax[0] * fb[3];
           if constexpr (NB > 4) T = T + ax[1] * fb[NB - 2] + ax[2] * fb[NB - 1];
           const v3 Mo = cross(r, F) + T;
-          real* o = stW + 6 * sd;
+          real* o = stW + 6 * (STW_REL ? sd - 2 * c0 : sd);
           o[0] = sg * Mo.x; o[1] = sg * Mo.y; o[2] = sg * Mo.z; o[3] = sg * F.x; o[4] = sg * F.y; o[5] = sg * F.z;
         }
         if (!doG) continue;
@@ -2171,7 +2183,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
         if (ent < 6 ? !doW : !doG) continue;
         real acc = c0 == 0 ? (real)0 : (ent < 6 ? S.WB[sl][ent] : S.G[sl][ent - 6]);      // later rounds continue the sum where the previous one stopped
         const int o1 = S.slot_ptr[sl + 1];
-        const real* const st = ent < 6 ? stW + ent : stG + (ent - 6) - 42 * c0;
+        const real* const st = ent < 6 ? stW + ent - (STW_REL ? 12 * c0 : 0) : stG + (ent - 6) - 42 * c0;
         const int stride = ent < 6 ? 6 : 21;
         // a slot's list is in contact order and the rounds take consecutive runs of it; four sides per trip, their loads issued together (the sum keeps list order:
         // a side outside the round or past the end contributes an exact zero)
