@@ -59,6 +59,11 @@ def broadcast_from_rank0(t):
         h = t.cpu()
         dist.broadcast(h, 0)
         t.copy_(h)
+    elif dist.get_backend() == "nccl" and not t.is_cuda:     # e.g. Adam's host-side `step` counters: RCCL only moves device memory
+        import torch
+        d = t.to(torch.device("cuda", torch.cuda.current_device()))
+        dist.broadcast(d, 0)
+        t.copy_(d.cpu())
     else:
         dist.broadcast(t, 0)
     return t
