@@ -9,7 +9,9 @@
 
 #define UR5_MAXRD 8                                // robot dofs == robot weld groups ("cbodies")
 #define UR5_MAXNU 8
+#ifndef UR5_MAXSR
 #define UR5_MAXSR 16                               // equality + limit rows
+#endif
 #ifndef UR5_MANY
 // ---- small scenes (UR5gripper_2_finger.xml, IT1): one 64-lane wavefront per scene, everything in LDS
 #define UR5_MAXOBJ 6                               // free objects handled by one wavefront
@@ -17,7 +19,9 @@
 #define UR5_MAXG 48
 #define UR5_MAXDG 16                               // dynamic (robot / object) collidable geoms
 #define UR5_MAXPAIR 384
+#ifndef UR5_MAXCON
 #define UR5_MAXCON 30
+#endif
 #define UR5_MAXCAND 64
 #define UR5_MAXHV 1024                             // hull vertices of collidable meshes
 #define UR5_NB 4                                   // base directions per contact: normal, 2 tangents, torsion (condim <= 4)

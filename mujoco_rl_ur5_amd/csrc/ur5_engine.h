@@ -414,11 +414,14 @@ template <class real, int NV_> struct Lds {
   real sr_c1[UR5_MAXSR], sr_c2[UR5_MAXSR], sr_D[UR5_MAXSR], sr_aref[UR5_MAXSR], sr_jar[UR5_MAXSR], sr_jv[UR5_MAXSR];
   // body accumulators (twist space)
 #ifndef UR5_MANY
-  real tw[NSLOT][6];
+  real tw[NSLOT][6];                                 // (could share the staging union as in the many-object image: -384 B, no residency step gained by it alone)
 #endif
   real WB[NSLOT][6], G[NSLOT][21];   // indexed by slot_of(body)
 #if defined(UR5_PROFILE) && !defined(UR5_EMUL)
   double prof[PF_COUNT];
+#endif
+#ifdef UR5_LDS_PAD
+  char lds_pad[UR5_LDS_PAD];                         // experiment: a larger image = fewer scenes per CU (how much throughput does one resident scene buy?)
 #endif
   int status, solver_iters, ncon_max, badstate;
   real pid_dt;

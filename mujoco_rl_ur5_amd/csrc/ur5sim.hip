@@ -31,7 +31,9 @@
 static_assert(2 * sizeof(ur5::Lds<double, UR5_MAXNV>) <= 160 * 1024, "two 40-object scenes per CU: the pile's LDS image must stay below 80 KB");
 #endif
 #if !defined(UR5_MANY) && !defined(UR5_PROFILE)   // (the per-phase cycle accounting build adds its counters to the image)
+#ifndef UR5_LDS_PAD
 static_assert(8 * sizeof(ur5::Lds<double, 32>) <= 160 * 1024, "the IT1 scene image must leave room for 8 scenes per CU (2 waves per SIMD): LDS is what caps residency");
+#endif
 #endif
 template <int NV, int GS>
 __global__ void UR5_KERNEL_ATTR(GS) ur5_run_kernel(double* __restrict__ rec, Ur5Launch P) {
