@@ -229,3 +229,25 @@ def test_two_ranks_on_one_gpu_equal_one_rank_bit_for_bit(tmp_path):
     assert a["recs"].shape == (5, n_total, 4) and np.array_equal(a["recs"], b["recs"])
     assert np.array_equal(a["state"], b["state"])
     assert a["recs"][:, :, 1].max() > 0 and set(np.unique(a["recs"][:, :, 3])) == {0, 1}      # pixel field filled, both outcomes occur
+
+
+def test_scene_keyed_random_numbers_do_not_depend_on_the_shard():
+    """sharding.scene_uniform / scene_normal: a draw is a pure function of (seed, global scene id, round, stream, index), so any shard of the scene ids
+    reproduces the corresponding rows of the whole batch bit for bit; different rounds / streams / seeds / scenes are uncorrelated, the marginals are U[0, 1) and N(0, 1)."""
+    import torch
+    g = torch.arange(16)
+    u = sharding.scene_uniform(20, g, 3, 1, 50000)
+    assert u.shape == (16, 50000) and u.dtype == torch.float32 and float(u.min()) >= 0.0 and float(u.max()) < 1.0
+    assert torch.equal(sharding.scene_uniform(20, g[5:9], 3, 1, 50000), u[5:9])                 # a shard = the rows of the whole batch
+    assert torch.equal(sharding.scene_uniform(20, g[5:9], 3, 1, 100), u[5:9, :100])             # ... and a prefix of the index range
+    assert abs(float(u.mean()) - 0.5) < 2e-3 and abs(float(u.var()) - 1 / 12) < 1e-3
+    u64 = sharding.scene_uniform(20, g, 3, 1, 1000, dtype=torch.float64)
+    assert u64.dtype == torch.float64 and float(u64.max()) < 1.0 and len(torch.unique(u64)) == u64.numel()
+    for other in (sharding.scene_uniform(20, g, 4, 1, 50000), sharding.scene_uniform(20, g, 3, 2, 50000), sharding.scene_uniform(21, g, 3, 1, 50000)):
+        c = torch.corrcoef(torch.stack([u[0], other[0]]))[0, 1]
+        assert abs(float(c)) < 0.02 and not torch.equal(u, other)
+    assert abs(float(torch.corrcoef(torch.stack([u[0], u[1]]))[0, 1])) < 0.02                   # neighbouring scenes
+    assert abs(float(torch.corrcoef(torch.stack([u[0, :-1], u[0, 1:]]))[0, 1])) < 0.02          # neighbouring indices
+    n = sharding.scene_normal(20, g, 0, 4, 50000)
+    assert abs(float(n.mean())) < 5e-3 and abs(float(n.std()) - 1.0) < 5e-3 and torch.isfinite(n).all()
+    assert torch.equal(sharding.scene_normal(20, g[2:4], 0, 4, 50000), n[2:4])
