@@ -324,6 +324,19 @@ template <class real, int NV_> struct Lds {
 #endif
   real Mobj[6 * UR5_MAXOBJ];
   static constexpr int HSIZE = NV_ * (NV_ + 1) / 2;  // packed lower triangle (GPU and lane emulation alike)
+  // Six-object image (NV = 44): the packed Hessian (7 920 B) is 3.5 KB longer than the kinematic temporaries it shares its LDS with. That tail holds
+  // what is dead while a Hessian is being assembled / factored / solved with: the body twists (images()), the search direction's images (cde, sr_jv:
+  // and M search: written after the solve, dead once the step along it is taken) and the aref offsets (consumed by the warm start) -- 25 496 -> 22 744 B =
+  // SEVEN scenes per CU instead of six (LDS is handed out in 1 280 B granules: 18 of the CU's 128, profiles/r04_z_lds_residency.log). The four-box image is bound by the temporaries, not by H, and keeps its layout.
+#ifndef UR5_MANY
+  static constexpr bool TAIL = NV_ > 32;
+#else
+  static constexpr bool TAIL = false;
+#endif
+  static constexpr int KIN_DOUBLES = UR5_MAXRD * (3 + 3 + 6 + 10 + 6 + 6) + NBODY * 6 + UR5_MAXDG * 12;   // the temporaries of the union below
+  static constexpr int TAIL_TW = KIN_DOUBLES, TAIL_CDE = TAIL_TW + 6 * NSLOT, TAIL_CEOFF = TAIL_CDE + NB * UR5_MAXCON, TAIL_SRJV = TAIL_CEOFF + NB * UR5_MAXCON,
+                       TAIL_MV = TAIL_SRJV + UR5_MAXSR;
+  static_assert(!TAIL || TAIL_MV + NV_ <= HSIZE, "the aliased arrays fit behind the temporaries");
 #define UR5_HIDX(i, j) ((i) * ((i) + 1) / 2 + (j))
   // The Hessian staging area shares its LDS with everything that is dead once the constraint rows exist: per-step
   // kinematic temporaries, body velocities and the moving geoms' poses are all recomputed by the next step.
@@ -374,7 +387,7 @@ template <class real, int NV_> struct Lds {
 
 #endif
   // dynamics vectors (dof space)
-  real fs[NV_], as[NV_], x[NV_], Ma[NV_], search[NV_], Mv[NV_], tmpv[NV_ + 4];
+  real fs[NV_], as[NV_], x[NV_], Ma[NV_], search[NV_], Mv[TAIL ? 1 : NV_], tmpv[NV_ + 4];
 #ifndef UR5_MANY
   real grad[NV_];                                    // (the many-object kernel keeps the gradient in `search` until the solve overwrites it)
 #endif
@@ -405,16 +418,16 @@ template <class real, int NV_> struct Lds {
 #endif
   real cpos[UR5_MAXCON][3], cframe[UR5_MAXCON][6], cdist[UR5_MAXCON], cfri[UR5_MAXCON][NB > 4 ? 3 : 2];   // cframe: normal, tangent 1 (tangent 2 = n x t1)
   real cD[UR5_MAXCON];
-  real ceoff[UR5_MAXCON][NB], ce[UR5_MAXCON][NB], cde[UR5_MAXCON][NB];   // ceoff: -aref in base space
+  real ceoff[TAIL ? 1 : UR5_MAXCON][NB], ce[UR5_MAXCON][NB], cde[TAIL ? 1 : UR5_MAXCON][NB];   // ceoff: -aref in base space
 #ifdef UR5_EMUL
   real cfn[UR5_MAXCON];                              // normal force, test introspection only
 #endif
   // special rows (joint equality, joint limits): jar = c1 x[d1] + c2 x[d2] - aref
   int sr_d1[UR5_MAXSR], sr_d2[UR5_MAXSR], sr_uni[UR5_MAXSR];
-  real sr_c1[UR5_MAXSR], sr_c2[UR5_MAXSR], sr_D[UR5_MAXSR], sr_aref[UR5_MAXSR], sr_jar[UR5_MAXSR], sr_jv[UR5_MAXSR];
+  real sr_c1[UR5_MAXSR], sr_c2[UR5_MAXSR], sr_D[UR5_MAXSR], sr_aref[UR5_MAXSR], sr_jar[UR5_MAXSR], sr_jv[TAIL ? 1 : UR5_MAXSR];
   // body accumulators (twist space)
 #ifndef UR5_MANY
-  real tw[NSLOT][6];                                 // (could share the staging union as in the many-object image: -384 B, no residency step gained by it alone)
+  real tw[TAIL ? 1 : NSLOT][6];                      // (four boxes: could share the staging union as in the many-object image: -384 B, no residency step gained by it alone)
 #endif
   real WB[NSLOT][6], G[NSLOT][21];   // indexed by slot_of(body)
 #if defined(UR5_PROFILE) && !defined(UR5_EMUL)
@@ -426,6 +439,20 @@ template <class real, int NV_> struct Lds {
   int status, solver_iters, ncon_max, badstate;
   real pid_dt;
   int contacts_enabled, last_steps, total_steps;
+  // the arrays that live in the Hessian's tail in the six-object image (TAIL), at their own address otherwise
+#ifndef UR5_MANY
+  UR5_FN real (*tw_())[6] { if constexpr (TAIL) return reinterpret_cast<real (*)[6]>(H + TAIL_TW); else return tw; }
+  UR5_FN real (*cde_())[NB] { if constexpr (TAIL) return reinterpret_cast<real (*)[NB]>(H + TAIL_CDE); else return cde; }
+  UR5_FN real (*ceoff_())[NB] { if constexpr (TAIL) return reinterpret_cast<real (*)[NB]>(H + TAIL_CEOFF); else return ceoff; }
+  UR5_FN real* sr_jv_() { if constexpr (TAIL) return H + TAIL_SRJV; else return sr_jv; }
+  UR5_FN real* Mv_() { if constexpr (TAIL) return H + TAIL_MV; else return Mv; }
+#else
+  UR5_FN real (*tw_())[6] { return tw; }
+  UR5_FN real (*cde_())[NB] { return cde; }
+  UR5_FN real (*ceoff_())[NB] { return ceoff; }
+  UR5_FN real* sr_jv_() { return sr_jv; }
+  UR5_FN real* Mv_() { return Mv; }
+#endif
 };
 
 // ---------------------------------------------------------------------------------------------- the engine
@@ -551,7 +578,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     // ping-pong buffers of the pointer-jumping pass: ce / cde (contact images, dead until this step's constraint rows are
     // built) hold the frames, cand (broad-phase list, rebuilt later) the ancestor links
     static_assert(UR5_MAXCON * NB >= 12 * UR5_MAXRD && UR5_MAXCAND * sizeof(short) >= 2 * UR5_MAXRD * sizeof(int), "scratch aliasing");
-    real* const kbuf[2] = {&S.ce[0][0], &S.cde[0][0]};
+    real* const kbuf[2] = {&S.ce[0][0], &S.cde_()[0][0]};
     int* const kanc = reinterpret_cast<int*>(S.cand);
 #define UR5_KR(bf, d) (kbuf[bf] + 9 * (d))
 #define UR5_KP(bf, d) (kbuf[bf] + 9 * UR5_MAXRD + 3 * (d))
@@ -868,7 +895,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
 #ifdef UR5_EMUL
     chol_solve(&S.Lr[0][0], M.nrd, UR5_MAXRD + 1, S.as);
 #else
-    {   // qacc_smooth of the robot: lanes 0-7 hold the rows of chol(Mr); S.x..S.Mv are free until the Newton solve (scratch)
+    {   // qacc_smooth of the robot: lanes 0-7 hold the rows of chol(Mr); S.x..S.Mv_() are free until the Newton solve (scratch)
       Blk b; b.base = fr.base; b.loc = fr.loc; b.size = fr.size;
       real rhs = UR5_LANE < M.nrd ? S.as[UR5_LANE] : (real)0;
       real xs = blk_solve(fr.r, fr.inv, b, rhs, S.x, 2 * UR5_MAXRD);
@@ -1907,8 +1934,8 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       bool hasA = S.cA[c] >= 0, hasB = S.cB[c] >= 0;
       real vb[NB];
       contact_image(c, hasA ? S.cvel[S.cA[c]] : S.cvel[0], hasB ? S.cvel[S.cB[c]] : S.cvel[0], hasA, hasB, vb);
-      for (int k = 0; k < NB; k++) S.ceoff[c][k] = B * vb[k];
-      S.ceoff[c][0] += ckr;
+      for (int k = 0; k < NB; k++) S.ceoff_()[c][k] = B * vb[k];
+      S.ceoff_()[c][0] += ckr;
     }
     SYNC();
 #ifdef UR5_MANY
@@ -2001,20 +2028,20 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       if (b < M.nrd) {
         real v[6] = {0, 0, 0, 0, 0, 0};
         for (int e = 0; e < M.nrd; e++) if (M.rd_anc[b] >> e & 1u) { real q = vec[e]; for (int i = 0; i < 6; i++) v[i] += S.cdof[e][i] * q; }
-        for (int i = 0; i < 6; i++) S.tw[sl][i] = v[i];
+        for (int i = 0; i < 6; i++) S.tw_()[sl][i] = v[i];
       } else {
         int va = M.nrd + 6 * (b - M.nrd);
         m3 R; R.load(S.bmat[b]);
-        mul(R, v3(vec[va + 3], vec[va + 4], vec[va + 5])).store(S.tw[sl]);
-        v3(vec[va], vec[va + 1], vec[va + 2]).store(S.tw[sl] + 3);
+        mul(R, v3(vec[va + 3], vec[va + 4], vec[va + 5])).store(S.tw_()[sl]);
+        v3(vec[va], vec[va + 1], vec[va + 2]).store(S.tw_()[sl] + 3);
       }
     }
     SYNC();
     PAR(c, S.ncon) {
       bool hasA = S.cA[c] >= 0, hasB = S.cB[c] >= 0;
       real e[NB];
-      contact_image(c, hasA ? S.tw[slot_of(S.cA[c])] : S.tw[0], hasB ? S.tw[slot_of(S.cB[c])] : S.tw[0], hasA, hasB, e);
-      if (offset) for (int k = 0; k < NB; k++) e[k] += S.ceoff[c][k];
+      contact_image(c, hasA ? S.tw_()[slot_of(S.cA[c])] : S.tw_()[0], hasB ? S.tw_()[slot_of(S.cB[c])] : S.tw_()[0], hasA, hasB, e);
+      if (offset) for (int k = 0; k < NB; k++) e[k] += S.ceoff_()[c][k];
       for (int k = 0; k < NB; k++) out[c][k] = e[k];
     }
     PAR(s, S.nsr) {
@@ -2041,7 +2068,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     real c0 = 0, g1 = 0, g2 = 0;
     PAR(c, S.ncon) {
       real D = S.cD[c];
-      real e0 = S.ce[c][0] + alpha * S.cde[c][0], j0 = S.cde[c][0];
+      real e0 = S.ce[c][0] + alpha * S.cde_()[c][0], j0 = S.cde_()[c][0];
       if (S.cdim[c] == 1) {
         if (e0 < 0) { c0 += (real)0.5 * D * e0 * e0; g1 += D * e0 * j0; g2 += D * j0 * j0; }
       } else {
@@ -2049,7 +2076,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
         for (int k = 1; k < NB; k++) {
           if (k >= S.cdim[c]) continue;
           real mu = row_mu(c, k);
-          real ek = mu * (S.ce[c][k] + alpha * S.cde[c][k]), jk = mu * S.cde[c][k];
+          real ek = mu * (S.ce[c][k] + alpha * S.cde_()[c][k]), jk = mu * S.cde_()[c][k];
           real rp = e0 + ek, rm = e0 - ek;
           if (rp < 0) { c0 += (real)0.5 * D * rp * rp; g1 += D * rp * (j0 + jk); g2 += D * (j0 + jk) * (j0 + jk); }
           if (rm < 0) { c0 += (real)0.5 * D * rm * rm; g1 += D * rm * (j0 - jk); g2 += D * (j0 - jk) * (j0 - jk); }
@@ -2057,7 +2084,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       }
     }
     PAR(s, S.nsr) {
-      real r = S.sr_jar[s] + alpha * S.sr_jv[s], j = S.sr_jv[s];
+      real r = S.sr_jar[s] + alpha * S.sr_jv_()[s], j = S.sr_jv_()[s];
       if (!S.sr_uni[s] || r < 0) { c0 += (real)0.5 * S.sr_D[s] * r * r; g1 += S.sr_D[s] * r * j; g2 += S.sr_D[s] * j * j; }
     }
     Cost3 r;
@@ -2332,7 +2359,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     PROF(PF_GRADG);
 #ifdef UR5_MANY
     if (UR5_LANE == 0) { S.act_changed = 0; if (!refactor) S.nskip++; }   // every lane read the flag before the barrier above
-    PAR(i, M.nv) S.Mv[pdof(i)] = S.search[i];   // right-hand side in permuted order (search still holds the gradient)
+    PAR(i, M.nv) S.Mv_()[pdof(i)] = S.search[i];   // right-hand side in permuted order (search still holds the gradient)
     if (S.env_inlds) {
       if (refactor) { envelope_assemble<true>(); PROF(PF_HASM); envelope_factor<true>(); PROF(PF_CHOL); }
       envelope_solve<true>(); PROF(PF_SOLVE);
@@ -3077,7 +3104,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       if (p2 < M.nobj) factor_single_row<INLDS, 6>(i, p2); else factor_single_row<INLDS, UR5_MAXRD>(i, p2);
     }
   }
-  // S.search = -H^-1 grad with the factor in place: b = S.Mv (permuted right-hand side, consumed), y = S.tmpv
+  // S.search = -H^-1 grad with the factor in place: b = S.Mv_() (permuted right-hand side, consumed), y = S.tmpv
   template <int W> UR5_FN void solve_single_row(int i, int p2, const real* b) {
     const int c0 = 6 * p2;
     Diag<W> d;
@@ -3135,7 +3162,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
   }
   template <bool INLDS> UR5_BIG void envelope_solve() {
     static_assert(sizeof(S.tmpv) / sizeof(real) >= (size_t)NV_, "tmpv holds a dof vector");
-    real* b = S.Mv;
+    real* b = S.Mv_();
     real* y = S.tmpv;
     SYNC();   // dcache of the uncoupled blocks
     PAR(i, M.nv) {   // uncoupled blocks: the whole solve at once
@@ -3215,8 +3242,8 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       if (i < M.nrd) {
         real sw = 0, ss = 0;
         for (int e = 0; e < M.nrd; e++) { sw += S.Mr[i][e] * warm()[e]; ss += S.Mr[i][e] * S.as[e]; }
-        S.Ma[i] = sw; S.Mv[i] = ss;
-      } else { S.Ma[i] = S.Mobj[i - M.nrd] * warm()[i]; S.Mv[i] = S.Mobj[i - M.nrd] * S.as[i]; }
+        S.Ma[i] = sw; S.Mv_()[i] = ss;
+      } else { S.Ma[i] = S.Mobj[i - M.nrd] * warm()[i]; S.Mv_()[i] = S.Mobj[i - M.nrd] * S.as[i]; }
     }
     PAR(sl, nslot()) {
       const int b = body_of_slot(sl);
@@ -3226,12 +3253,12 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
           const real qw = warm()[e], qs = S.as[e];
           for (int i = 0; i < 6; i++) { vw[i] += S.cdof[e][i] * qw; vs[i] += S.cdof[e][i] * qs; }
         }
-        for (int i = 0; i < 6; i++) { S.tw[sl][i] = vw[i]; S.WB[sl][i] = vs[i]; }
+        for (int i = 0; i < 6; i++) { S.tw_()[sl][i] = vw[i]; S.WB[sl][i] = vs[i]; }
       } else {
         const int va = M.nrd + 6 * (b - M.nrd);
         m3 R; R.load(S.bmat[b]);
-        mul(R, v3(warm()[va + 3], warm()[va + 4], warm()[va + 5])).store(S.tw[sl]);
-        v3(warm()[va], warm()[va + 1], warm()[va + 2]).store(S.tw[sl] + 3);
+        mul(R, v3(warm()[va + 3], warm()[va + 4], warm()[va + 5])).store(S.tw_()[sl]);
+        v3(warm()[va], warm()[va + 1], warm()[va + 2]).store(S.tw_()[sl] + 3);
         mul(R, v3(S.as[va + 3], S.as[va + 4], S.as[va + 5])).store(S.WB[sl]);
         v3(S.as[va], S.as[va + 1], S.as[va + 2]).store(S.WB[sl] + 3);
       }
@@ -3244,10 +3271,10 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
         const bool hasA = S.cA[c] >= 0, hasB = S.cB[c] >= 0;
         const int slA = hasA ? slot_of(S.cA[c]) : 0, slB = hasB ? slot_of(S.cB[c]) : 0;
         real ew[NB], es[NB];
-        contact_image(c, S.tw[slA], S.tw[slB], hasA, hasB, ew);
+        contact_image(c, S.tw_()[slA], S.tw_()[slB], hasA, hasB, ew);
         contact_image(c, S.WB[slA], S.WB[slB], hasA, hasB, es);
 #pragma unroll
-        for (int k = 0; k < NB; k++) { ew[k] += S.ceoff[c][k]; es[k] += S.ceoff[c][k]; S.ce[c][k] = ew[k]; S.cde[c][k] = es[k]; }
+        for (int k = 0; k < NB; k++) { ew[k] += S.ceoff_()[c][k]; es[k] += S.ceoff_()[c][k]; S.ce[c][k] = ew[k]; S.cde_()[c][k] = es[k]; }
         const real D = S.cD[c];
         if (S.cdim[c] == 1) {
           if (ew[0] < 0) c_w += (real)0.5 * D * ew[0] * ew[0];
@@ -3281,8 +3308,8 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     if (cw < cs) cost = cw;
     else {
       cost = cs;
-      PAR(i, nv) { S.x[i] = S.as[i]; S.Ma[i] = S.Mv[i]; }
-      PAR(c, S.ncon) for (int k = 0; k < NB; k++) S.ce[c][k] = S.cde[c][k];
+      PAR(i, nv) { S.x[i] = S.as[i]; S.Ma[i] = S.Mv_()[i]; }
+      PAR(c, S.ncon) for (int k = 0; k < NB; k++) S.ce[c][k] = S.cde_()[c][k];
       PAR(s, S.nsr) S.sr_jar[s] = S.tmpv[s];
       SYNC();
     }
@@ -3299,11 +3326,11 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       if (it >= M.iterations) break;
       iters = it + 1;
       PROF_T0();
-      mat_vec_M(S.search, S.Mv);
-      images(S.search, false, S.cde, S.sr_jv);
+      mat_vec_M(S.search, S.Mv_());
+      images(S.search, false, S.cde_(), S.sr_jv_());
       PROF(PF_IMAGES);
       real q1 = 0, q2 = 0, sn = 0;
-      PAR(i, nv) { q1 += S.search[i] * (S.Ma[i] - S.fs[i]); q2 += S.search[i] * S.Mv[i]; sn += S.search[i] * S.search[i]; }
+      PAR(i, nv) { q1 += S.search[i] * (S.Ma[i] - S.fs[i]); q2 += S.search[i] * S.Mv_()[i]; sn += S.search[i] * S.search[i]; }
 #if !defined(UR5_EMUL) && UR5_NT > 64
       block_sum3(q1, q2, sn); sn = sqrt(sn);
 #else
@@ -3339,13 +3366,13 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
           if (c < S.ncon) {
             const int cdim = S.cdim[c];
             nk[t] = cdim == 1 ? 0 : cdim - 1;
-            e0[t] = S.ce[c][0]; j0[t] = S.cde[c][0]; Dc[t] = S.cD[c];
+            e0[t] = S.ce[c][0]; j0[t] = S.cde_()[c][0]; Dc[t] = S.cD[c];
 #pragma unroll
-            for (int k = 1; k < NB; k++) if (k < cdim) { const real mu = row_mu(c, k); ek[t][k - 1] = mu * S.ce[c][k]; jk[t][k - 1] = mu * S.cde[c][k]; }
+            for (int k = 1; k < NB; k++) if (k < cdim) { const real mu = row_mu(c, k); ek[t][k - 1] = mu * S.ce[c][k]; jk[t][k - 1] = mu * S.cde_()[c][k]; }
           }
         }
         const bool has_row = UR5_LANE < S.nsr;
-        const real r0 = has_row ? S.sr_jar[UR5_LANE] : (real)0, rv = has_row ? S.sr_jv[UR5_LANE] : (real)0, rD = has_row ? S.sr_D[UR5_LANE] : (real)0;
+        const real r0 = has_row ? S.sr_jar[UR5_LANE] : (real)0, rv = has_row ? S.sr_jv_()[UR5_LANE] : (real)0, rD = has_row ? S.sr_D[UR5_LANE] : (real)0;
         const bool r_uni = has_row && S.sr_uni[UR5_LANE] != 0;
         const int ncon = S.ncon;
         auto eval = [&](const real alpha, real& cc, real& g1, real& g2) {
@@ -3397,9 +3424,9 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
 #undef UR5_LS_SUM
       if (a <= 0) break;
       SYNC();
-      PAR(i, nv) { S.x[i] += a * S.search[i]; S.Ma[i] += a * S.Mv[i]; }
-      PAR(c, S.ncon) for (int k = 0; k < NB; k++) { S.ce[c][k] += a * S.cde[c][k]; S.cde[c][k] = 0; }
-      PAR(s, S.nsr) { S.sr_jar[s] += a * S.sr_jv[s]; S.sr_jv[s] = 0; }
+      PAR(i, nv) { S.x[i] += a * S.search[i]; S.Ma[i] += a * S.Mv_()[i]; }
+      PAR(c, S.ncon) for (int k = 0; k < NB; k++) { S.ce[c][k] += a * S.cde_()[c][k]; S.cde_()[c][k] = 0; }
+      PAR(s, S.nsr) { S.sr_jar[s] += a * S.sr_jv_()[s]; S.sr_jv_()[s] = 0; }
       SYNC();
       real newcost = gauss_cost(S.x, S.Ma) + ccost_a;
 #else
@@ -3418,9 +3445,9 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       }
       if (a <= 0) break;
       SYNC();
-      PAR(i, nv) { S.x[i] += a * S.search[i]; S.Ma[i] += a * S.Mv[i]; }
-      PAR(c, S.ncon) for (int k = 0; k < NB; k++) { S.ce[c][k] += a * S.cde[c][k]; S.cde[c][k] = 0; }
-      PAR(s, S.nsr) { S.sr_jar[s] += a * S.sr_jv[s]; S.sr_jv[s] = 0; }
+      PAR(i, nv) { S.x[i] += a * S.search[i]; S.Ma[i] += a * S.Mv_()[i]; }
+      PAR(c, S.ncon) for (int k = 0; k < NB; k++) { S.ce[c][k] += a * S.cde_()[c][k]; S.cde_()[c][k] = 0; }
+      PAR(s, S.nsr) { S.sr_jar[s] += a * S.sr_jv_()[s]; S.sr_jv_()[s] = 0; }
       SYNC();
       real newcost = gauss_cost(S.x, S.Ma) + constraint_cost(0).c;
 #endif
@@ -3444,7 +3471,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
 #ifdef UR5_EMUL
     chol_solve(&S.Ld[0][0], M.nrd, UR5_MAXRD + 1, S.tmpv);
 #else
-    {   // (Mr + h B) qacc' = Mr qacc: lanes 8-15 hold the rows of chol(Mr + h B); S.Ma..S.Mv are dead after the solve (scratch)
+    {   // (Mr + h B) qacc' = Mr qacc: lanes 8-15 hold the rows of chol(Mr + h B); S.Ma..S.Mv_() are dead after the solve (scratch)
       Blk b; b.base = fr.base; b.loc = fr.loc; b.size = fr.size;
       const int l8 = UR5_LANE - UR5_MAXRD;
       real rhs = (l8 >= 0 && l8 < M.nrd) ? S.tmpv[l8] : (real)0;
