@@ -138,6 +138,34 @@ def test_two_finger_six_object_scene_runs(model_2f, emul_lib):
     assert np.abs(np.linalg.norm(quats, axis=1) - 1).max() < 1e-12
 
 
+def test_six_object_grasps_through_the_coupled_hessian(model_2f, emul_lib):
+    """NV = 44: a held object couples robot and object dofs, so every closing / lifting step assembles, factors and solves with the full packed Hessian --
+    whose tail (behind the kinematic temporaries it shares its LDS with) also holds the body twists, the search direction's images, M search and the aref
+    offsets in this instantiation (Lds::TAIL, csrc/ur5_engine.h). A grasp that holds, one that loses the object on the way and a blocked descent: reward,
+    every phase's step count and result code equal the oracle's, the arm to 1e-9, the objects to 1e-6."""
+    m = model_2f
+    cases = [(20, 0, 0), (20, 2, 3), (20, 1, 3), (21, 3, 0)]          # (seed, object, wrist rotation)
+    sim = BatchSim(m, len(cases), lib_path=emul_lib)
+    sim.reset(np.array([c[0] for c in cases], dtype=np.uint64), 1, 1000.0)
+    q0 = sim.get_state()["qpos"]
+    acts = np.array([aimed_actions(q0[e][None], 6, first_id=c[1])[0] for e, c in enumerate(cases)])
+    rots = [c[2] for c in cases]
+    rew, ps, pr = sim.grasp_attempt(acts, rot=rots, check_mode=0)
+    q = sim.get_state()["qpos"]
+    seen = set()
+    for e, (seed, k, rot) in enumerate(cases):
+        o = Oracle(m)
+        o.reset(seed, 1, True)
+        assert np.abs(q0[e] - o.get_state()["qpos"]).max() < 1e-9
+        r, pso, pro = o.grasp_attempt(acts[e], rot, 0)
+        assert r == rew[e] and pso.tolist() == ps[e].tolist() and pro.tolist() == pr[e].tolist(), (e, pso, ps[e])
+        so = o.get_state()["qpos"]
+        assert np.abs(q[e][:8] - so[:8]).max() < 1e-9 and np.abs(q[e] - so).max() < 1e-6, e
+        seen.add((int(r), int(pro[5]), int(pso[9])))
+    assert sim.counters()["status"].max() == 0
+    assert any(s[0] == 1 for s in seen) and any(s[0] == 0 and s[1] == 1 for s in seen) and any(s[1] == 0 for s in seen), seen   # held / lost / blocked
+
+
 def test_broad_phase_pair_cache_serves_most_steps_with_the_full_scan_s_candidates(model_it1, emul_lib):
     """The broad phase keeps a superset of the pairs that can pass cull() while no moving geom has travelled more than 2 cm (csrc/ur5_engine.h
     collision_body); the test builds re-run the full scan next to every cached step and raise status bit 16 on any difference. A reset + settle + whole

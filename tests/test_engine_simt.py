@@ -79,6 +79,28 @@ def test_six_object_scene_and_failure_exits(model_2f, simt_lib):
     assert sim.counters()["status"].max() == 0
 
 
+def test_six_object_grasp_holds_through_the_device_code_s_coupled_hessian(model_2f, simt_lib):
+    """The DEVICE code path of the NV = 44 kernel with a held object: rows of the packed Hessian into the lanes' registers, factorisation by lane broadcasts, the
+    factor transposed through the Hessian's LDS -- the same LDS whose tail holds the twists, the search direction's images, M search and the aref offsets in this
+    instantiation (Lds::TAIL). One grasp that holds and one that loses the object: reward, phase step counts, result codes equal the oracle's."""
+    from conftest import aimed_actions
+    m = model_2f
+    cases = [(20, 0, 0), (20, 2, 3)]
+    sim = BatchSim(m, len(cases), lib_path=simt_lib)
+    sim.reset(np.array([c[0] for c in cases], dtype=np.uint64), 1, 1000.0)
+    q0 = sim.get_state()["qpos"]
+    acts = np.array([aimed_actions(q0[e][None], 6, first_id=c[1])[0] for e, c in enumerate(cases)])
+    rew, ps, pr = sim.grasp_attempt(acts, rot=[c[2] for c in cases], check_mode=0)
+    q = sim.get_state()["qpos"]
+    for e, (seed, k, rot) in enumerate(cases):
+        o = Oracle(m)
+        o.reset(seed, 1, True)
+        r, pso, pro = o.grasp_attempt(acts[e], rot, 0)
+        assert r == rew[e] and pso.tolist() == ps[e].tolist() and pro.tolist() == pr[e].tolist(), (e, pso, ps[e])
+        assert np.abs(q[e][:8] - o.qpos[:8]).max() < 1e-8 and np.abs(q[e] - o.qpos).max() < 1e-6, e
+    assert rew.tolist() == [1, 0] and sim.counters()["status"].max() == 0
+
+
 def test_ik_and_move_ee_through_the_device_path(model_it1, simt_lib):
     m = model_it1
     targets = np.array([[0.0, -0.6, 1.1], [0.2, -0.45, 0.95], [0.6, 0.1, 1.2], [2.0, 2.0, 2.0]])
