@@ -2362,10 +2362,10 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     PAR(i, M.nv) S.Mv_()[pdof(i)] = S.search[i];   // right-hand side in permuted order (search still holds the gradient)
     if (S.env_inlds) {
       if (refactor) { envelope_assemble<true>(); PROF(PF_HASM); envelope_factor<true>(); PROF(PF_CHOL); }
-      envelope_solve<true>(); PROF(PF_SOLVE);
+      envelope_solve<true>(refactor); PROF(PF_SOLVE);
     } else {
       if (refactor) { envelope_assemble<false>(); PROF(PF_HASM); envelope_factor<false>(); PROF(PF_CHOL); }
-      envelope_solve<false>(); PROF(PF_SOLVE);
+      envelope_solve<false>(refactor); PROF(PF_SOLVE);
     }
     return false;
 #else
@@ -3007,10 +3007,17 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     diag_factor<INLDS, W>(c0, d);
     if (r == 0) diag_store<W>(p2, d);
   }
-  template <bool INLDS, int W> UR5_FN void factor_panel_row(int i, int ii, int p2, int c0, bool inl) {
+  // The forward substitution of the solve that follows every factorisation rides along (b, y as in envelope_solve): the lane that has just computed row i's entries
+  // of block column p2 has the block's factor in registers, so y_blk = L_pp^-1 b_blk and b_i -= L_i,blk y_blk cost it a handful of multiply-adds instead of
+  // a second sweep over the levels (one barrier + the reload of every diagonal block and row per level). Same operands, same order as fwd_panel_row: same bits.
+  template <bool INLDS, int W> UR5_FN void factor_panel_row(int i, int ii, int p2, int c0, bool inl, real* b, real* y) {
     Diag<W> d;
     const bool prefactored = S.blk_first[p2] == p2;
     if (prefactored) diag_cached<W>(p2, d); else diag_factor<INLDS, W>(c0, d);
+    real yb[W];
+#pragma unroll
+    for (int k = 0; k < W; k++) yb[k] = b[c0 + k];
+    fwd_blk<W>(d, yb);
     real out[W];
     if (ii < W) {
 #pragma unroll
@@ -3021,6 +3028,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
         out[k] = v;
       }
       if (ii == 0 && !prefactored) diag_store<W>(p2, d);
+      y[i] = pick<W>(yb, ii);
     } else {
       const double* row = hptr<INLDS>(i, c0);
 #pragma unroll
@@ -3030,6 +3038,10 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
         for (int m = 0; m < k; m++) sacc -= out[m] * d.l[k][m];
         out[k] = sacc * d.inv[k];
       }
+      real sacc = 0;
+#pragma unroll
+      for (int k = 0; k < W; k++) sacc += (real)(double)out[k] * yb[k];
+      b[i] -= sacc;
     }
     if (ii >= W) {   // (the block's own rows live on in dcache; only the rows below it are read back by the trailing update)
       real* o = panel_at(i, ii - W, inl);
@@ -3055,7 +3067,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     const bool inl = panel_in_lds(w, nr);
     UR5_PLANE(t, w + nr) {
       const int i = t < w ? c0 + t : reach_row(p2, nrb, t - w);
-      if (p2 < M.nobj) factor_panel_row<INLDS, 6>(i, t, p2, c0, inl); else factor_panel_row<INLDS, UR5_MAXRD>(i, t, p2, c0, inl);
+      if (p2 < M.nobj) factor_panel_row<INLDS, 6>(i, t, p2, c0, inl, S.Mv_(), S.tmpv); else factor_panel_row<INLDS, UR5_MAXRD>(i, t, p2, c0, inl, S.Mv_(), S.tmpv);
     }
   }
   // A2: the finished column entries of the rows below go back to H (the block itself lives on in dcache);
@@ -3160,7 +3172,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       y[j] -= sacc;   // the lanes of this panel only read y inside the block, never left of it
     }
   }
-  template <bool INLDS> UR5_BIG void envelope_solve() {
+  template <bool INLDS> UR5_BIG void envelope_solve(bool forward_done) {   // forward_done: the factorisation that has just run did the forward sweep over the levels
     static_assert(sizeof(S.tmpv) / sizeof(real) >= (size_t)NV_, "tmpv holds a dof vector");
     real* b = S.Mv_();
     real* y = S.tmpv;
@@ -3170,6 +3182,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       if (!blk_single(p2)) continue;
       if (p2 < M.nobj) solve_single_row<6>(i, p2, b); else solve_single_row<UR5_MAXRD>(i, p2, b);
     }
+    if (!forward_done)
     for (int l = 0; l < S.nlvl; l++) {   // forward, column-oriented: y_blk = L_pp^-1 b_blk, then b_i -= L_i,blk y_blk for the rows below
       const int lp0 = S.lvl_ptr[l], np = S.lvl_ptr[l + 1] - lp0;
       for (int base = 0; base < np; base += UR5_PANELS_PER_PASS) {
