@@ -178,6 +178,18 @@ template <int W, class T> __device__ __forceinline__ T ur5_wave_max(T v) {   // 
 #define PROF_RE() ((void)0)
 #define PROF(id) ((void)0)
 #endif
+// -DUR5_PROFILE_LEVELS (many-object profile builds): the sub-interval slots x0..x5 book the level loops of the envelope factorisation / solves instead of the
+// sub-intervals of `rows` and of the narrow phase: x1 uncoupled + unreached blocks at once, x2 panel rows (A1, with the forward substitution) + barrier,
+// x3 write-back + trailing update + barrier, x4 terminal blocks, x5 forward sweep of the solves that reuse a factor, x0 backward sweep
+#if defined(UR5_PROFILE_LEVELS) && defined(UR5_MANY)
+#define PROFR(id) ((void)0)
+#define PROFL_T0() PROF_T0()
+#define PROFL(id) PROF(id)
+#else
+#define PROFR(id) PROF(id)
+#define PROFL_T0() ((void)0)
+#define PROFL(id) ((void)0)
+#endif
 enum { PF_KIN = 0, PF_CRB, PF_VEL, PF_BROAD, PF_NARROW, PF_ROWS, PF_NEWTON_INIT, PF_IMAGES, PF_LINESEARCH, PF_GRADG, PF_HASM, PF_CHOL, PF_SOLVE,
        PF_INTEGRATE, PF_PID, PF_IK, PF_CORECLK, PF_REALCLK, PF_X0, PF_X1, PF_X2, PF_X3, PF_X4, PF_X5, PF_X6, PF_X7, PF_COUNT };   // PF_X7: MPR pairs (count, not cycles)   // the last two: start / end of the scene's wave in 100 MHz ticks (s_memrealtime)
 
@@ -1497,7 +1509,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
           real depth;
           v3 nrm, pos;
           const bool hit = mpr<W>(sa, sb, &depth, &nrm, &pos, sl);
-#if defined(UR5_PROFILE)
+#if defined(UR5_PROFILE) && !(defined(UR5_PROFILE_LEVELS) && defined(UR5_MANY))
           if (sl == 0) UR5_ATOMIC_ADD(&S.prof[PF_X7], 1.0 + 1e-9 * (double)((sa.type == UR5_GEOM_MESH ? sa.vnum : 0) + (sb.type == UR5_GEOM_MESH ? sb.vnum : 0)));   // pairs + 1e-9 x hull vertices per support call
 #endif
           const real dist = margin - depth;
@@ -1666,7 +1678,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       }
     }
     SYNC();
-    PROF(PF_X0);   // profile builds: the one-candidate-per-lane pass (analytic pairs, box-box); PF_NARROW then is the cooperative MPR pass
+    PROFR(PF_X0);   // profile builds: the one-candidate-per-lane pass (analytic pairs, box-box); PF_NARROW then is the cooperative MPR pass
 #if !defined(UR5_EMUL)
     if constexpr (FLAT) mpr_pass_body(); else mpr_pass_fn();
 #endif
@@ -1905,7 +1917,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     }
 #endif
 #ifdef UR5_MANY
-    PROF(PF_X1);   // special rows (lane 0)
+    PROFR(PF_X1);   // special rows (lane 0)
 #endif
     PAR(c, S.ncon) {
       int g1 = S.cg1[c], g2 = S.cg2[c];
@@ -1939,7 +1951,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     }
     SYNC();
 #ifdef UR5_MANY
-    PROF(PF_X2);   // contact rows
+    PROFR(PF_X2);   // contact rows
 #endif
 #if !defined(UR5_EMUL) && !defined(UR5_MANY)
     {   // contacts between two movable bodies, compacted in contact order with a ballot; body / coupling masks with LDS atomics
@@ -2008,12 +2020,12 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
 #endif
     SYNC();
 #ifdef UR5_MANY
-    PROF(PF_X3);   // couple list
+    PROFR(PF_X3);   // couple list
     // (Round 3 tried to keep the envelope structure across steps -- it is a function of the set of coupled body pairs and of the objects' x-order. Measured on
     // piles: the pair set changes in > 95 % of the steps even after 2 s of settling, resting contacts sit within 1e-5 m of the margin at which they are detected
     // and come and go every step, so the structure is rebuilt every step: 130 k of the 154 k cycles of this phase.)
     envelope_structure();
-    PROF(PF_X5);   // envelope structure
+    PROFR(PF_X5);   // envelope structure
 #endif
   }
 
@@ -2650,9 +2662,9 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
   static constexpr int LPANEL_ROWS = 2 * UR5_MAXCON * 6 / (UR5_NT / 64) / 6;
   UR5_FN static bool panel_in_lds(int w, int nr) { return w == 6 && nr <= LPANEL_ROWS; }
 #ifdef UR5_EMUL
-  UR5_FN real* panel_at(int i, int c, bool inl) { return inl ? &S.stw[0][0] + 6 * c : panel_row(i); }
+  UR5_FN real* panel_at(int i, int c, bool inl, int) { return inl ? &S.stw[0][0] + 6 * c : panel_row(i); }
 #else
-  UR5_FN real* panel_at(int i, int c, bool inl) { return inl ? &S.stw[0][0] + (UR5_LANE >> 6) * (LPANEL_ROWS * 6) + 6 * c : panel_row(i); }
+  UR5_FN real* panel_at(int i, int c, bool inl, int owner) { return inl ? &S.stw[0][0] + owner * (LPANEL_ROWS * 6) + 6 * c : panel_row(i); }   // owner: the wavefront whose quarter holds the panel
 #endif
   template <bool INLDS> UR5_FN double* hptr(int I, int J) { return (INLDS ? S.henv : S.hess) + S.env_ptr[I] + (J - S.env_first[I]); }
   UR5_BIG void envelope_structure() {
@@ -3010,7 +3022,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
   // The forward substitution of the solve that follows every factorisation rides along (b, y as in envelope_solve): the lane that has just computed row i's entries
   // of block column p2 has the block's factor in registers, so y_blk = L_pp^-1 b_blk and b_i -= L_i,blk y_blk cost it a handful of multiply-adds instead of
   // a second sweep over the levels (one barrier + the reload of every diagonal block and row per level). Same operands, same order as fwd_panel_row: same bits.
-  template <bool INLDS, int W> UR5_FN void factor_panel_row(int i, int ii, int p2, int c0, bool inl, real* b, real* y) {
+  template <bool INLDS, int W> UR5_FN void factor_panel_row(int i, int ii, int p2, int c0, bool inl, int owner, real* b, real* y) {
     Diag<W> d;
     const bool prefactored = S.blk_first[p2] == p2;
     if (prefactored) diag_cached<W>(p2, d); else diag_factor<INLDS, W>(c0, d);
@@ -3044,7 +3056,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       b[i] -= sacc;
     }
     if (ii >= W) {   // (the block's own rows live on in dcache; only the rows below it are read back by the trailing update)
-      real* o = panel_at(i, ii - W, inl);
+      real* o = panel_at(i, ii - W, inl, owner);
 #pragma unroll
       for (int k = 0; k < W; k++) o[k] = out[k];
     }
@@ -3055,43 +3067,74 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
 #define UR5_PANELS_PER_PASS 1
 #define UR5_FOR_MY_PANELS(j, base, np) for (int j = (base); j < (base) + 1 && j < (np); j++)
 #define UR5_PLANE(t, n) for (int t = 0; t < (n); t++)
+#define UR5_PLANE_SHARED(t, n, sh) for (int t = 0; t < (n); t++)
 #else
 #define UR5_PANELS_PER_PASS (UR5_NT / 64)
 #define UR5_FOR_MY_PANELS(j, base, np) for (int j = (base) + (UR5_LANE >> 6), once_ = 1; once_ && j < (np); once_ = 0)
 #define UR5_PLANE(t, n) for (int t = UR5_LANE & 63; t < (n); t += 64)
+#define UR5_PLANE_SHARED(t, n, sh) for (int t = (UR5_LANE & 63) + 64 * (sh).part; t < (n); t += 64 * (sh).parts)
 #endif
+  // A pass of the factorisation holds cnt <= 4 panels. The profile (profiles/r04_ae_*) says a pile's levels are few (about four passes per factorisation) and WIDE (a
+  // panel's rows and row pairs take several trips of one wavefront): with fewer panels than wavefronts the spare wavefronts take a share of a panel's rows / pairs.
+  // Wavefront w works on panel q = w mod cnt of the pass, as part w / cnt of `parts`; the panel's rows sit in the LDS quarter of wavefront q. Every row / entry is
+  // still computed by exactly one lane from the same operands: same bits.
+  struct Share { int q, part, parts; };
+  UR5_FN static Share pass_share(int cnt) {
+    Share sh;
+#if defined(UR5_EMUL) || defined(UR5_NO_PANEL_SHARING)
+    sh.q = defined_wave(); sh.part = 0; sh.parts = 1; (void)cnt;
+#else
+    const int w = UR5_LANE >> 6;
+    sh.q = w % cnt; sh.part = w / cnt; sh.parts = (UR5_PANELS_PER_PASS - 1 - sh.q) / cnt + 1;
+#endif
+    return sh;
+  }
+  // the panel (index j in the level's list) this wavefront works on in the pass starting at `base`, and its share of it
+#if defined(UR5_EMUL) || defined(UR5_NO_PANEL_SHARING)
+#define UR5_FOR_MY_SHARE(sh, j, base, np) const Share sh = pass_share(1); UR5_FOR_MY_PANELS(j, base, np)
+#else
+#define UR5_FOR_MY_SHARE(sh, j, base, np) const Share sh = pass_share((np) - (base) < UR5_PANELS_PER_PASS ? (np) - (base) : UR5_PANELS_PER_PASS); for (int j = (base) + sh.q, once_ = 1; once_; once_ = 0)
+#endif
+  UR5_FN static int defined_wave() {
+#ifdef UR5_EMUL
+    return 0;
+#else
+    return UR5_LANE >> 6;
+#endif
+  }
   // A1: the panel's own rows and every reaching row compute their entries of the block column (LDS panel); H is only read
-  template <bool INLDS> UR5_FN void panel_factor_rows(int p2) {
+  template <bool INLDS> UR5_FN void panel_factor_rows(int p2, const Share& sh) {
     const int c0 = 6 * p2, w = blk_width(p2);
     const int nrb = S.reach_ptr[p2 + 1] - S.reach_ptr[p2], nr = reach_rows(p2, nrb);
     const bool inl = panel_in_lds(w, nr);
-    UR5_PLANE(t, w + nr) {
+    UR5_PLANE_SHARED(t, w + nr, sh) {
       const int i = t < w ? c0 + t : reach_row(p2, nrb, t - w);
-      if (p2 < M.nobj) factor_panel_row<INLDS, 6>(i, t, p2, c0, inl, S.Mv_(), S.tmpv); else factor_panel_row<INLDS, UR5_MAXRD>(i, t, p2, c0, inl, S.Mv_(), S.tmpv);
+      if (p2 < M.nobj) factor_panel_row<INLDS, 6>(i, t, p2, c0, inl, sh.q, S.Mv_(), S.tmpv); else factor_panel_row<INLDS, UR5_MAXRD>(i, t, p2, c0, inl, sh.q, S.Mv_(), S.tmpv);
     }
   }
   // A2: the finished column entries of the rows below go back to H (the block itself lives on in dcache);
   // B: trailing update of every pair of reaching rows below the block
-  template <bool INLDS> UR5_FN void panel_trailing_update(int p2) {
+  template <bool INLDS> UR5_FN void panel_trailing_update(int p2, const Share& sh) {
     const int c0 = 6 * p2, w = blk_width(p2);
     const int nrb = S.reach_ptr[p2 + 1] - S.reach_ptr[p2], nr = reach_rows(p2, nrb);
     const bool inl = panel_in_lds(w, nr);
-    UR5_PLANE(c, nr) {
+    UR5_PLANE_SHARED(c, nr, sh) {
       const int i = reach_row(p2, nrb, c);
       double* row = hptr<INLDS>(i, c0);
-      const real* pr = panel_at(i, c, inl);
+      const real* pr = panel_at(i, c, inl, sh.q);
       for (int k = 0; k < w; k++) row[k] = (double)pr[k];
     }
-    UR5_PLANE(idx, nr * nr) {
+    UR5_PLANE_SHARED(idx, nr * nr, sh) {
       const int ii = idx / nr, jj = idx - ii * nr;
       if (jj > ii) continue;
       const int i = reach_row(p2, nrb, ii), j = reach_row(p2, nrb, jj);
       real sacc = 0;
-      { const real* pi = panel_at(i, ii, inl); const real* pj = panel_at(j, jj, inl); for (int k = 0; k < w; k++) sacc += pi[k] * pj[k]; }
+      { const real* pi = panel_at(i, ii, inl, sh.q); const real* pj = panel_at(j, jj, inl, sh.q); for (int k = 0; k < w; k++) sacc += pi[k] * pj[k]; }
       *hptr<INLDS>(i, j) -= (double)sacc;
     }
   }
   template <bool INLDS> UR5_BIG void envelope_factor() {
+    PROFL_T0();
     // a block that reaches no earlier block gets no trailing update: its diagonal block is final after assembly, so all
     // of these (the uncoupled blocks among them) are factored at once, ahead of the sequential sweep
     PAR(i, M.nv) {
@@ -3100,14 +3143,31 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       if (p2 < M.nobj) factor_single_row<INLDS, 6>(i, p2); else factor_single_row<INLDS, UR5_MAXRD>(i, p2);
     }
     SYNC();
+    PROFL(PF_X1);
     // level by level; inside a level every wavefront takes one panel (lanes = rows / row pairs of that panel)
     for (int l = 0; l < S.nlvl; l++) {
       const int lp0 = S.lvl_ptr[l], np = S.lvl_ptr[l + 1] - lp0;
       for (int base = 0; base < np; base += UR5_PANELS_PER_PASS) {
-        UR5_FOR_MY_PANELS(j, base, np) panel_factor_rows<INLDS>(S.lvl_list[lp0 + j]);
+#if defined(UR5_EMUL) || defined(UR5_NO_PANEL_SHARING)
+        const Share sh = pass_share(1);
+        UR5_FOR_MY_PANELS(j, base, np) panel_factor_rows<INLDS>(S.lvl_list[lp0 + j], sh);
         SYNC();
-        UR5_FOR_MY_PANELS(j, base, np) panel_trailing_update<INLDS>(S.lvl_list[lp0 + j]);
+        PROFL(PF_X2);
+        UR5_FOR_MY_PANELS(j, base, np) panel_trailing_update<INLDS>(S.lvl_list[lp0 + j], sh);
         SYNC();
+#else
+        const Share sh = pass_share(np - base < UR5_PANELS_PER_PASS ? np - base : UR5_PANELS_PER_PASS);
+        const int p2s = S.lvl_list[lp0 + base + sh.q];
+        panel_factor_rows<INLDS>(p2s, sh);
+        SYNC();
+        PROFL(PF_X2);
+        panel_trailing_update<INLDS>(p2s, sh);
+        SYNC();
+#endif
+        PROFL(PF_X3);
+#if defined(UR5_PROFILE_LEVELS) && defined(UR5_PROFILE) && !defined(UR5_EMUL)
+        if (UR5_LANE == 0) S.prof[PF_X7] += 1.0;   // level passes (count)
+#endif
       }
     }
     PAR(i, M.nv) {   // terminal blocks: every trailing update has landed
@@ -3115,6 +3175,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       if (!blk_terminal(p2)) continue;
       if (p2 < M.nobj) factor_single_row<INLDS, 6>(i, p2); else factor_single_row<INLDS, UR5_MAXRD>(i, p2);
     }
+    PROFL(PF_X4);
   }
   // S.search = -H^-1 grad with the factor in place: b = S.Mv_() (permuted right-hand side, consumed), y = S.tmpv
   template <int W> UR5_FN void solve_single_row(int i, int p2, const real* b) {
@@ -3176,6 +3237,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     static_assert(sizeof(S.tmpv) / sizeof(real) >= (size_t)NV_, "tmpv holds a dof vector");
     real* b = S.Mv_();
     real* y = S.tmpv;
+    PROFL_T0();
     SYNC();   // dcache of the uncoupled blocks
     PAR(i, M.nv) {   // uncoupled blocks: the whole solve at once
       const int p2 = i < 6 * M.nobj ? i / 6 : M.nobj;
@@ -3186,11 +3248,11 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     for (int l = 0; l < S.nlvl; l++) {   // forward, column-oriented: y_blk = L_pp^-1 b_blk, then b_i -= L_i,blk y_blk for the rows below
       const int lp0 = S.lvl_ptr[l], np = S.lvl_ptr[l + 1] - lp0;
       for (int base = 0; base < np; base += UR5_PANELS_PER_PASS) {
-        UR5_FOR_MY_PANELS(j, base, np) {
+        UR5_FOR_MY_SHARE(sh, j, base, np) {   // (spare wavefronts take a share of a panel's rows, as in the factorisation)
           const int p2 = S.lvl_list[lp0 + j];
           const int c0 = 6 * p2, w = blk_width(p2);
           const int nrb = S.reach_ptr[p2 + 1] - S.reach_ptr[p2], nr = reach_rows(p2, nrb);
-          UR5_PLANE(t, w + nr) {
+          UR5_PLANE_SHARED(t, w + nr, sh) {
             const int i = t < w ? c0 + t : reach_row(p2, nrb, t - w);
             if (p2 < M.nobj) fwd_panel_row<INLDS, 6>(i, t, p2, c0, b, y); else fwd_panel_row<INLDS, UR5_MAXRD>(i, t, p2, c0, b, y);
           }
@@ -3198,6 +3260,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
         SYNC();
       }
     }
+    PROFL(PF_X5);
     PAR(t, M.nv) {   // terminal blocks: forward and backward substitution inside the block, then their share of y to the left
       const int p2 = t < 6 * M.nobj ? t / 6 : M.nobj;
       if (!blk_terminal(p2)) continue;
@@ -3216,14 +3279,15 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       }
     }
     SYNC();
+    PROFL(PF_X4);
     for (int l = S.nlvl - 1; l >= 0; l--) {   // backward, row-oriented: x_blk = L_pp^-T y_blk, then y_j -= L_blk,j^T x_blk for the columns left of it
       const int lp0 = S.lvl_ptr[l], np = S.lvl_ptr[l + 1] - lp0;
       for (int base = 0; base < np; base += UR5_PANELS_PER_PASS) {
-        UR5_FOR_MY_PANELS(j, base, np) {
+        UR5_FOR_MY_SHARE(sh, j, base, np) {
           const int p2 = S.lvl_list[lp0 + j];
           const int c0 = 6 * p2, w = blk_width(p2);
           const int f0 = S.env_first[c0];
-          UR5_PLANE(jj, c0 + w - f0) {
+          UR5_PLANE_SHARED(jj, c0 + w - f0, sh) {
             const int col = f0 + jj;
             if (p2 < M.nobj) bwd_panel_col<INLDS, 6>(col, p2, c0, y); else bwd_panel_col<INLDS, UR5_MAXRD>(col, p2, c0, y);
           }
@@ -3232,6 +3296,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       }
     }
     SYNC();   // S.search of the uncoupled blocks (there may be no sequential block at all)
+    PROFL(PF_X0);
   }
 #endif
 

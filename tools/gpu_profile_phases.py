@@ -37,6 +37,12 @@ c1 = sim.counters(); p = read(); steps = (c1["total_steps"] - c0["total_steps"])
 print("grasp: kernel %.1f ms, mean %d steps/env, success %.2f" % (sim.last_launch_ms(), steps.mean(), rew.mean()))
 for k, nm in enumerate(NAMES): print("  %-12s %10.0f" % (nm, (p[:, k] / steps).mean()))
 print("  sub-intervals x0..x6 (cycles/step): %s" % (p[:, 18:25] / steps[:, None]).mean(0).round(0).tolist())
+if os.environ.get("UR5_PROFILE_LEVELS"):   # library built with -DUR5_PROFILE_LEVELS: x0..x5 are parts of chol / solve (they are NOT taken out of those two lines), x7 counts level passes
+    x = (p[:, 18:26] / steps[:, None]).mean(0)
+    it = (c1["solver_iters"] - c0["solver_iters"]).sum() / steps.sum()
+    print("  level loops, cycles/step: factorisation = blocks factored at once %.0f + panel rows (A1, forward substitution inside) incl. barrier %.0f + write-back / trailing update incl. barrier %.0f"
+          " + terminal blocks (factor and solves) %.0f; solves = uncoupled blocks + forward sweep of factor-reusing iterations %.0f + backward sweep %.0f" % (x[1], x[2], x[3], x[4], x[5], x[0]))
+    print("  %.2f level passes per step = %.2f per Newton iteration (%.2f iterations/step): %.0f cycles per pass for A1, %.0f for the trailing update" % (x[7], x[7] / it, it, x[2] / x[7], x[3] / x[7]))
 npairs = np.floor(p[:, 25]); nverts = (p[:, 25] - npairs) * 1e9     # profile build: S.prof[PF_X7] += 1 + 1e-9 * (hull vertices of the pair) per cooperative MPR pair
 if not MANY: print("  cooperative MPR: %.3f pairs per step, %.1f hull vertices per pair (one support call scans that many)" % ((npairs / steps).mean(), nverts.sum() / max(npairs.sum(), 1)))
 print("  %-12s %10.0f  (%s; kernel %.2f ms)" % ("sum", (p[:, :16].sum(1) / steps).mean() + (p[:, 18:25].sum(1) / steps).mean(), life(p), sim.last_launch_ms()))
