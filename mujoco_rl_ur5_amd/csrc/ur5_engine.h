@@ -3124,9 +3124,13 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       const real* pr = panel_at(i, c, inl, sh.q);
       for (int k = 0; k < w; k++) row[k] = (double)pr[k];
     }
-    UR5_PLANE_SHARED(idx, nr * nr, sh) {
-      const int ii = idx / nr, jj = idx - ii * nr;
-      if (jj > ii) continue;
+    // the pairs (ii >= jj) of the lower triangle, folded into a rectangle so that no lane draws an empty (jj > ii) slot: row r of the rectangle holds row r of the
+    // triangle followed by row n - 1 - r (n = nr rounded up to even; the padding row is skipped) -- half the trips of an nr x nr sweep
+    const int nre = nr + (nr & 1), wid = nre + 1;
+    UR5_PLANE_SHARED(idx, (nre >> 1) * wid, sh) {
+      const int r = idx / wid, c = idx - r * wid;
+      const int ii = c <= r ? r : nre - 1 - r, jj = c <= r ? c : c - r - 1;
+      if (ii >= nr) continue;
       const int i = reach_row(p2, nrb, ii), j = reach_row(p2, nrb, jj);
       real sacc = 0;
       { const real* pi = panel_at(i, ii, inl, sh.q); const real* pj = panel_at(j, jj, inl, sh.q); for (int k = 0; k < w; k++) sacc += pi[k] * pj[k]; }
