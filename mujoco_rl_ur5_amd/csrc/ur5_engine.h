@@ -3079,12 +3079,19 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
   // Wavefront w works on panel q = w mod cnt of the pass, as part w / cnt of `parts`; the panel's rows sit in the LDS quarter of wavefront q. Every row / entry is
   // still computed by exactly one lane from the same operands: same bits.
   struct Share { int q, part, parts; };
+  UR5_FN static int own_wave() {
+#ifdef UR5_EMUL
+    return 0;
+#else
+    return UR5_LANE >> 6;
+#endif
+  }
   UR5_FN static Share pass_share(int cnt) {
     Share sh;
-#if defined(UR5_EMUL) || defined(UR5_NO_PANEL_SHARING)
-    sh.q = defined_wave(); sh.part = 0; sh.parts = 1; (void)cnt;
+#if defined(UR5_EMUL) || defined(UR5_NO_PANEL_SHARING)   // (build option: every wavefront keeps to its own panel, as before the sharing)
+    sh.q = own_wave(); sh.part = 0; sh.parts = 1; (void)cnt;
 #else
-    const int w = UR5_LANE >> 6;
+    const int w = own_wave();
     sh.q = w % cnt; sh.part = w / cnt; sh.parts = (UR5_PANELS_PER_PASS - 1 - sh.q) / cnt + 1;
 #endif
     return sh;
@@ -3095,13 +3102,6 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
 #else
 #define UR5_FOR_MY_SHARE(sh, j, base, np) const Share sh = pass_share((np) - (base) < UR5_PANELS_PER_PASS ? (np) - (base) : UR5_PANELS_PER_PASS); for (int j = (base) + sh.q, once_ = 1; once_; once_ = 0)
 #endif
-  UR5_FN static int defined_wave() {
-#ifdef UR5_EMUL
-    return 0;
-#else
-    return UR5_LANE >> 6;
-#endif
-  }
   // A1: the panel's own rows and every reaching row compute their entries of the block column (LDS panel); H is only read
   template <bool INLDS> UR5_FN void panel_factor_rows(int p2, const Share& sh) {
     const int c0 = 6 * p2, w = blk_width(p2);
