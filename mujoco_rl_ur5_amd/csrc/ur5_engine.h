@@ -2659,7 +2659,15 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
   // ... or, when the panel is an object's (6 columns) and at most LPANEL_ROWS rows reach it -- nearly always --, in the wavefront's quarter of the LDS area that the
   // staged wrench terms / body twists / kinematic temporaries use at other times (nothing else touches it during a factorisation), indexed by the row's position
   // among the reaching rows: the write -> barrier -> read of every level stays out of global memory
-  static constexpr int LPANEL_ROWS = 2 * UR5_MAXCON * 6 / (UR5_NT / 64) / 6;
+  // -DUR5_PANEL_SLOT=16 (experiment prepared at the end of round 4, NOT measured yet; default 64 = one wavefront per panel): settled piles have few levels (3.7) but 6-9 NARROW
+  // panels in the first (6 own + ~6 reaching rows, 21 row pairs: tools/pile_structure_stats.py, profiles/r04_pile_structure_stats_12piles.log), so a pass of four panels uses
+  // 48 of its 256 lanes and a factorisation takes 4.7 passes. With 16-lane slots a pass holds 16 panels (passes = levels); a wider panel's slot makes more trips.
+#ifndef UR5_PANEL_SLOT
+#define UR5_PANEL_SLOT 64
+#endif
+  static constexpr int PSLOT = UR5_PANEL_SLOT;       // lanes that work on one panel of a pass
+  static_assert(PSLOT == 64 || PSLOT == 32 || PSLOT == 16, "a panel slot is a whole wavefront or an aligned part of one");
+  static constexpr int LPANEL_ROWS = 2 * UR5_MAXCON * 6 / (UR5_NT / PSLOT) / 6;
   UR5_FN static bool panel_in_lds(int w, int nr) { return w == 6 && nr <= LPANEL_ROWS; }
 #ifdef UR5_EMUL
   UR5_FN real* panel_at(int i, int c, bool inl, int) { return inl ? &S.stw[0][0] + 6 * c : panel_row(i); }
@@ -3069,10 +3077,10 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
 #define UR5_PLANE(t, n) for (int t = 0; t < (n); t++)
 #define UR5_PLANE_SHARED(t, n, sh) for (int t = 0; t < (n); t++)
 #else
-#define UR5_PANELS_PER_PASS (UR5_NT / 64)
-#define UR5_FOR_MY_PANELS(j, base, np) for (int j = (base) + (UR5_LANE >> 6), once_ = 1; once_ && j < (np); once_ = 0)
-#define UR5_PLANE(t, n) for (int t = UR5_LANE & 63; t < (n); t += 64)
-#define UR5_PLANE_SHARED(t, n, sh) for (int t = (UR5_LANE & 63) + 64 * (sh).part; t < (n); t += 64 * (sh).parts)
+#define UR5_PANELS_PER_PASS (UR5_NT / PSLOT)
+#define UR5_FOR_MY_PANELS(j, base, np) for (int j = (base) + UR5_LANE / PSLOT, once_ = 1; once_ && j < (np); once_ = 0)
+#define UR5_PLANE(t, n) for (int t = UR5_LANE % PSLOT; t < (n); t += PSLOT)
+#define UR5_PLANE_SHARED(t, n, sh) for (int t = UR5_LANE % PSLOT + PSLOT * (sh).part; t < (n); t += PSLOT * (sh).parts)
 #endif
   // A pass of the factorisation holds cnt <= 4 panels. The profile (profiles/r04_ae_*) says a pile's levels are few (about four passes per factorisation) and WIDE (a
   // panel's rows and row pairs take several trips of one wavefront): with fewer panels than wavefronts the spare wavefronts take a share of a panel's rows / pairs.
@@ -3083,7 +3091,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
 #ifdef UR5_EMUL
     return 0;
 #else
-    return UR5_LANE >> 6;
+    return UR5_LANE / PSLOT;
 #endif
   }
   UR5_FN static Share pass_share(int cnt) {
