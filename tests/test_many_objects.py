@@ -72,6 +72,41 @@ def test_forward_quantities_match_oracle_in_a_settled_pile(model_many, emul_lib)
     assert sim.counters()["status"][0] == 0
 
 
+def test_envelope_structure_equals_its_numpy_restatement(model_many, emul_lib):
+    """csrc/ur5_engine.h envelope_structure() -- islands of the coupling graph, block order (island, then x, robot last), first coupled block of every block,
+    envelope size -- against tools/pile_structure_stats.py, a numpy restatement that only sees the oracle's contacts and body positions: coupled contacts,
+    coupled blocks and envelope doubles equal on piles at two stages of the drop. (The structure only decides where the Newton Hessian is stored and in
+    which order it is factored; that the factor is right is the qacc parity of the tests above.)"""
+    import ctypes as C, os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    import pile_structure_stats as P
+    from mujoco_rl_ur5_amd.native import _VARIANT
+    m = model_many
+    blk, nobj, obj_body = P.blocks_of_bodies(m)
+    assert nobj == 40 and (blk == nobj).sum() >= 8
+    sim = BatchSim(m, 1, lib_path=emul_lib)
+    stride = _VARIANT[sim.variant][1]
+    seen = 0
+    for seed, ms in ((20, 300.0), (23, 500.0)):
+        o = Oracle(m)
+        o.reset(seed, 1, False)
+        o.stay(ms)
+        o.forward()
+        st = o.get_state()
+        pairs = []
+        for c in o.contacts():
+            a, b = blk[int(m.geom_bodyid[int(c[7])])], blk[int(m.geom_bodyid[int(c[8])])]
+            if a >= 0 and b >= 0 and a != b:
+                pairs.append((a, b))
+        s = P.structure(nobj, o.body_xpos()[obj_body, 0], pairs)
+        sim.set_state(qpos=st["qpos"][None], qvel=st["qvel"][None], warmstart=st["warmstart"][None], pid=st["pid"][None])
+        out = np.zeros((1, stride))
+        assert sim.lib.ur5_forward_debug(sim._h, out.ctypes.data_as(C.POINTER(C.c_double))) == 0
+        assert (len(pairs), s["coupled"], s["env"]) == (int(out[0, 5]), int(out[0, 6]), int(out[0, 4])), (seed, ms, len(pairs), s["coupled"], s["env"], out[0, 4:7])
+        seen += len(pairs)
+    assert seen >= 8
+
+
 def test_envelope_in_global_memory_path(model_many):
     """Envelopes larger than UR5_HENV_CAP doubles run the same factorisation on the scene's global-memory scratch; a build
     with a tiny cap forces that path for every step."""
