@@ -509,7 +509,7 @@ def main():
                                  "launch per scene group and round, the groups' launches overlapping on their own HIP streams (avg_launch_ms = "
                                  "HIP-event duration of one launch; achieved = launch_concurrency x bytes per launch / avg_launch_ms up to the "
                                  "overlap at the region's ends). A scene stays in LDS for a whole launch, so the algorithmic figure is an accounting "
-                                 "unit, not the traffic: the step is latency / VALU-issue bound (DESIGN.md section 3)"},
+                                 "unit, not the traffic: the step is latency / VALU-issue bound (rocprofv3 SQ counters, profiles/r04_q_pmc.txt: the fp64 VALU pipe of a SIMD is busy 63 % of the time, 40 % of the lanes of an instruction active; DESIGN.md section 3)"},
         }
         if world == 1 and not args.no_extras:
             # second figure: SURVEY.md 8d's own action rule, same episode structure, a few rounds continuing from the current state
