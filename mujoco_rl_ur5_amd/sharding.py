@@ -91,7 +91,11 @@ def scene_uniform(seed, gids, round_index, stream, count, dtype=None):
     """U[0, 1) draws [len(gids), count] for the scenes with global ids ``gids`` (int64 tensor) in round ``round_index`` of random stream ``stream``."""
     import torch
     dtype = dtype or torch.float32
-    key = _mix64(gids.to(torch.int64) * _GOLD + (int(seed) * 0x632BE5AB + int(round_index)) * 0x1000003 + int(stream))       # one 64-bit key per scene
+    # the scalar part of the key is reduced modulo 2^64 and folded to a signed value first: python ints do not wrap, and an offset beyond 64 bits
+    # (any seed above ~600) cannot be added to an int64 tensor
+    off = ((int(seed) * 0x632BE5AB + int(round_index)) * 0x1000003 + int(stream)) & ((1 << 64) - 1)
+    off -= (off >> 63) << 64
+    key = _mix64(gids.to(torch.int64) * _GOLD + off)       # one 64-bit key per scene
     z = _mix64(key[:, None] + torch.arange(1, count + 1, dtype=torch.int64, device=gids.device)[None, :] * _GOLD)
     if dtype == torch.float64:
         return _lsr(z, 11).to(torch.float64) * (1.0 / 9007199254740992.0)

@@ -251,3 +251,23 @@ def test_scene_keyed_random_numbers_do_not_depend_on_the_shard():
     n = sharding.scene_normal(20, g, 0, 4, 50000)
     assert abs(float(n.mean())) < 5e-3 and abs(float(n.std()) - 1.0) < 5e-3 and torch.isfinite(n).all()
     assert torch.equal(sharding.scene_normal(20, g[2:4], 0, 4, 50000), n[2:4])
+
+
+def test_scene_keyed_random_numbers_accept_any_seed():
+    """Round-4 advice: the scalar part of the key used to be an unbounded python int, so any seed above ~600 raised OverflowError when it met the int64
+    scene ids (`BatchedGraspAgent(seed=1000)`, `generate_data.py --seed 12345`). The offset is reduced modulo 2^64 now: large seeds work, small seeds
+    draw exactly what they drew before, and a seed still selects its own stream."""
+    import torch
+    g = torch.arange(8)
+    small = sharding.scene_uniform(20, g, 3, 1, 64)
+    ref = sharding._lsr(sharding._mix64(sharding._mix64(g * sharding._GOLD + ((20 * 0x632BE5AB + 3) * 0x1000003 + 1))[:, None]
+                                        + torch.arange(1, 65)[None, :] * sharding._GOLD), 40).to(torch.float32) * (1.0 / 16777216.0)
+    assert torch.equal(small, ref)                                                              # the pre-fix formula where it did not overflow
+    seen = [small]
+    for seed in (1000, 12345, 2 ** 31, 2 ** 63 + 5, -7):
+        u = sharding.scene_uniform(seed, g, 10 ** 6, 7, 4096)
+        assert u.shape == (8, 4096) and float(u.min()) >= 0.0 and float(u.max()) < 1.0 and abs(float(u.mean()) - 0.5) < 0.02
+        assert torch.equal(sharding.scene_uniform(seed, g[2:5], 10 ** 6, 7, 4096), u[2:5])
+        assert all(not torch.equal(u[:, :64], s[:, :64]) for s in seen)
+        seen.append(u)
+        assert torch.isfinite(sharding.scene_normal(seed, g, 1, 2, 128)).all()
