@@ -84,3 +84,44 @@ def test_hip_engine_reproduces_the_recorded_arm_trajectory(model_it1):
     from mujoco_rl_ur5_amd.native import BatchSim
     q, total = _engine_trajectory(BatchSim, model_it1)
     _check_against_the_plot(q, total)
+
+
+# ---------------------------------------------------------------------------------------------- the plot's dashed lines are an ikpy output
+# media/plot_1.png was saved by a move_ee call: its dashed target lines are what ikpy [3P] returned for that call (MujocoController.py:498-500,
+# 509: angles[1:-2] become the arm targets). D3 replaces ikpy (scipy optimiser from the zero pose) by a Levenberg-Marquardt iteration from the home
+# pose; this is the one reference-held IK answer: the forward kinematics of the plotted angles, fed back through the IK, must return the plotted
+# angles -- same branch of the UR5's eight -- to well inside the 7-9 mrad digitisation (measured: 0.3 / 0.1 / 0.8 / 3.3 / 1.9 mrad).
+GRIPPER_CENTRE = np.array([0.0, -0.005, 0.16])                        # MujocoController.py:493
+
+
+def _ee_target_of_the_plotted_pose(model):
+    """World xyz that move_ee must have been called with: ee_link position at the plotted angles minus the gripper-centre offset (:487-493)."""
+    from oracle.oracle import Oracle
+    o = Oracle(model)
+    q = o.get_state()["qpos"].copy()
+    q[:6] = TARGET
+    o.set_state(qpos=q, qvel=np.zeros(model.nv), warmstart=np.zeros(model.nv))
+    o.forward()
+    return o.body_xpos()[model.body_name2id("ee_link")] - GRIPPER_CENTRE
+
+
+def test_oracle_ik_returns_the_plotted_ikpy_angles(model_2f):
+    from oracle.oracle import Oracle
+    ok, q5 = Oracle(model_2f).ik(_ee_target_of_the_plotted_pose(model_2f))
+    assert ok and np.abs(q5 - TARGET[:5]).max() < 0.01, q5 - TARGET[:5]
+
+
+def test_engine_source_ik_returns_the_plotted_ikpy_angles(model_it1, emul_lib):
+    from mujoco_rl_ur5_amd.native import BatchSim
+    q5, res = BatchSim(model_it1, 2, lib_path=emul_lib).ik(_ee_target_of_the_plotted_pose(model_it1))
+    assert (res == 0).all() and np.abs(q5 - TARGET[:5]).max() < 0.01, q5 - TARGET[:5]
+
+
+@pytest.mark.gpu
+def test_hip_ik_returns_the_plotted_ikpy_angles(model_it1):
+    from mujoco_rl_ur5_amd.native import BatchSim
+    from oracle.oracle import Oracle
+    x = _ee_target_of_the_plotted_pose(model_it1)
+    q5, res = BatchSim(model_it1, 4).ik(x)
+    assert (res == 0).all() and np.abs(q5 - TARGET[:5]).max() < 0.01, q5 - TARGET[:5]
+    assert np.abs(q5 - Oracle(model_it1).ik(x)[1]).max() < 1e-9
