@@ -280,13 +280,13 @@ class Job:
         for gr in self.groups:
             gr.sim.sync()
         c0, k0 = self.counters(), sum(gr.sim.kernel_ms_total() for gr in self.groups)
-        if self.world > 1:
+        if self.sharding.collectives_active():
             self.dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         g = self.run_rounds(r0, r1, wls)
         torch.cuda.synchronize()
-        if self.world > 1:
+        if self.sharding.collectives_active():
             self.dist.barrier()
         elapsed = time.perf_counter() - t0
         for gr in self.groups:
@@ -396,6 +396,8 @@ def main():
     ap.add_argument("--sub-rounds", type=int, default=None, help="with --sub: timed rounds")
     ap.add_argument("--sub-groups", type=int, default=2, help="with --sub-scenes / --sub-rounds: scene groups (handles + streams) of the sub-result")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for 2 ranks on one device)")
+    ap.add_argument("--collectives", action="store_true", help="N = 1 only: create a one-rank process group on --backend and issue every collective of an N-rank job "
+                    "(barriers, the per-round all_gather of outcome records, the final reductions) -- how the RCCL path is executed on a one-GPU box; results are unchanged")
     args = ap.parse_args()
 
     import torch
@@ -424,6 +426,11 @@ def main():
     dev = torch.device("cuda", dev_id)
     if world > 1:
         dist.init_process_group(args.backend, **({"device_id": dev} if args.backend == "nccl" else {}))
+    elif args.collectives:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+        dist.init_process_group(args.backend, rank=0, world_size=1, **({"device_id": dev} if args.backend == "nccl" else {}))
+        sharding.FORCE_COLLECTIVES = True
 
     subs = {"it4": lambda cpu: rendered_sub_result(torch, dist, sharding, dev, dev_id, "it4", 4096, 4, 1, cpu),
             "many": lambda cpu: rendered_sub_result(torch, dist, sharding, dev, dev_id, "many", 2048, 2, 1, cpu),   # BASELINE configs[3]: 16384 piles on 8 GPUs = 2048 per GPU
@@ -457,7 +464,7 @@ def main():
     per_round = reward[args.warmup:].double().mean(dim=1)
     elapsed_local = elapsed
     stats = torch.tensor([elapsed, float(steps_local), float(reward[args.warmup:].sum().item())], dtype=torch.float64, device=dev)
-    if world > 1:
+    if sharding.collectives_active():
         tmax = stats[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tot = stats[1:].clone()
@@ -498,7 +505,8 @@ def main():
                                 else "uniform: uniformly drawn table pixel, rotation 0 (SURVEY.md 8d / Grasping_Agent_multidiscrete.py:266-280)"),
                        "scenes_per_gpu": n_local, "scenes_total": n_total, "scene_groups_per_gpu": G, "solver": "Newton (MuJoCo default; north_star says PGS, see DESIGN.md D1), "
                        f"tolerance 1e-10, iteration cap {model.opt['iterations']}", "timestep_s": model.opt["timestep"],
-                       "parallelism": f"scenes sharded x{world}, 1 all_gather of 16 B outcome records per scene group and round"},
+                       "parallelism": f"scenes sharded x{world}, 1 all_gather of 16 B outcome records per scene group and round"
+                                      + (f"; --collectives: one-rank process group, backend {dist.get_backend()}, every collective issued" if world == 1 and sharding.collectives_active() else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                          "traffic_source": traffic_src, "kernel": "ur5_run_kernel<32>", "bytes_per_env_step": bytes_per_step,
                          "avg_launch_ms": kernel_ms / (args.steps * G), "launches_per_round": G, "launch_concurrency": G,
@@ -553,7 +561,7 @@ def main():
         out["roofline_frac"] = out["roofline"]["frac"]
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or sharding.collectives_active():
         dist.destroy_process_group()
 
 

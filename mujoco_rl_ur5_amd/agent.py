@@ -10,8 +10,12 @@ as one; per round only the 16-byte outcome records cross ranks (``sharding.gathe
 Several ranks = ONE agent (round 4): the job's scenes shard over the ranks, every random draw is keyed by global scene id and round
 (``sharding.scene_uniform``), action selection normalises every image by itself (``qnet.per_sample_statistics``), and the gathered outcome
 records drive one logical replay ring (``qnet.ReplayBuffer.push_shared``) from which every rank takes the same optimiser steps -- so N ranks
-with n scenes each hold bit-identical weights and produce the loss sequence of one rank with N n scenes (``tests/test_sharding.py``). The
-images of a sampled batch travel to the replicas in one all-reduce per optimiser step (12 x 640 KB); gradients never do.
+with n scenes each produce the outcome records, the loss sequence and the weights of one rank with N n scenes (``tests/test_sharding.py``). The
+images of a sampled batch travel to the replicas in one all-reduce per optimiser step (12 x 640 KB); gradients never do. That equality is EXACT on
+the CPU (gloo tests: sha256 of the weights). On GPUs the replicas' optimiser steps differ at rounding level (MIOpen's weight-gradient kernels
+accumulate with atomics; ``tests/test_sharding.py`` accepts 15 % on the per-rank losses within a round), so every round ends with one flattened
+broadcast of rank 0's weights, batch-norm buffers and Adam state (88 MB, ``sharding.broadcast_many_from_rank0``): the copies are re-identified once
+per round, they are not bit-identical in between.
 
 Differences that follow from batching, all deliberate: epsilon decays per transition (``steps_done`` advances by the job's scene count per round); colour
 jitter (torchvision's ColorJitter, :120-126) and the depth noise run on the device (``color_jitter`` below). Learning cadence: the reference
@@ -140,8 +144,9 @@ class Learner:
         Multi-rank jobs pass ``outcomes`` -- the all-gathered [n_total, 4] records {scene id, pixel, rotation, reward} of the round -- and the id
         of this rank's first scene: the round's n_total transitions then go through ONE logical ring in global scene order
         (``ReplayBuffer.push_shared``), every rank takes the SAME optimiser steps on the same batches (``sample`` assembles a batch from the
-        ranks that hold its images), and the replicas of ``policy_net`` stay bit-identical without any gradient traffic: one learner, as in the
-        reference, fed by all the shards."""
+        ranks that hold its images) without any gradient traffic: one learner, as in the reference, fed by all the shards. The replicas of
+        ``policy_net`` stay bit-identical on the CPU; on GPUs they agree to rounding within a round and are re-identified by the per-round broadcast
+        of ``BatchedGraspAgent.round`` (module docstring)."""
         shared = outcomes is not None and self.memory.shared
         n = int(outcomes.shape[0]) if shared else state.shape[0]
         k = max(self.transitions_per_update, -(-n // self.max_updates_per_round))
@@ -191,12 +196,13 @@ class BatchedGraspAgent:
         self.gids = self.first_scene_id + torch.arange(self.N, dtype=torch.int64, device=self.device)
         import torch.distributed as dist
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
-        if self.world > 1:
+        # several ranks -- or one rank told to take the collective path anyway (sharding.FORCE_COLLECTIVES: how RCCL is exercised on a one-GPU box)
+        self.shared = sharding.collectives_active()
+        if self.shared:
             if self.n_total != self.world * self.N or self.first_scene_id != dist.get_rank() * self.N:
                 raise ValueError("multi-rank agent: every rank simulates the contiguous shard sharding.shard_range(n_total, rank, world)")
             self.memory.make_shared()                                                   # one logical replay ring for the job (qnet.ReplayBuffer.push_shared)
-            for t in list(self.policy_net.parameters()) + list(self.policy_net.buffers()):   # one set of initial weights (29 MB, once): rank 0's
-                sharding.broadcast_from_rank0(t.data)
+            sharding.broadcast_many_from_rank0([t.data for t in list(self.policy_net.parameters()) + list(self.policy_net.buffers())])   # one set of initial weights (29 MB, once): rank 0's
 
     # ------------------------------------------------------------------ observation -> network input
     def transform_observation(self, observation, normalize=True, jitter_and_noise=True):
@@ -204,8 +210,8 @@ class BatchedGraspAgent:
         observation = {"rgb": uint8 [N,H,W,3], "depth": float32 [N,H,W]} device tensors -> float32 [N,4,H,W]."""
         depth = observation["depth"].to(self.device).float().clamp(max=self.depth_threshold)            # :311
         if normalize:
-            for i0 in range(0, self.N, 512):                                                             # :317 (whenever normalize=True); chunks bound the int64 temporaries
-                depth[i0:i0 + 512] += 0.001 * sharding.scene_normal(self.seed, self.gids[i0:i0 + 512], self.rounds_done, 4, self.H * self.W).view(-1, self.H, self.W)
+            for i0 in range(0, self.N, 128):                                                             # :317 (whenever normalize=True); chunks bound the int64 temporaries (128 x 80 000 x 8 B = 82 MB each)
+                depth[i0:i0 + 128] += 0.001 * sharding.scene_normal(self.seed, self.gids[i0:i0 + 128], self.rounds_done, 4, self.H * self.W).view(-1, self.H, self.W)
             depth = -depth
             dmin = depth.amin(dim=(1, 2), keepdim=True)
             dmax = depth.amax(dim=(1, 2), keepdim=True)
@@ -227,8 +233,8 @@ class BatchedGraspAgent:
         world = self.env.pixel_world_device(observation["depth"], self.device)                           # [N,H,W,3]
         on_table = (world[..., 2] >= self.env.TABLE_HEIGHT - 0.01).reshape(self.N, -1)
         on_table = torch.where(on_table.any(dim=1, keepdim=True), on_table, torch.ones_like(on_table))
-        cdf = on_table.cumsum(dim=1)                                                                     # uniform over the table pixels: inverse CDF of the draw
-        want = torch.floor(u[:, 1] * cdf[:, -1].double()).long() + 1                                     # the want-th table pixel, 1-based
+        cdf = on_table.cumsum(dim=1, dtype=torch.int32)                                                  # uniform over the table pixels: inverse CDF of the draw (int32: 40 000 pixels)
+        want = torch.floor(u[:, 1] * cdf[:, -1].double()).to(torch.int32) + 1                            # the want-th table pixel, 1-based
         pixel = torch.searchsorted(cdf, want[:, None]).squeeze(1).clamp(max=self.n_actions_1 - 1)
         rot = torch.floor(u[:, 2] * self.n_actions_2).long().clamp(max=self.n_actions_2 - 1)
         random_action = rot * self.n_actions_1 + pixel
@@ -274,19 +280,17 @@ class BatchedGraspAgent:
         reward, skipped = self.env.step_device(env_action, obs["depth"], self.device)
         rec = torch.stack([self.gids.int(), env_action[:, 0].int(), env_action[:, 1].int(), reward.int()], dim=1)
         outcomes = sharding.gather_outcomes(rec)                                                         # the round's only collective on the rollout side: 16 B per scene
-        losses, utd = self.learner.push_and_learn(state, action, reward, learn=learn, outcomes=outcomes if self.world > 1 else None,
+        losses, utd = self.learner.push_and_learn(state, action, reward, learn=learn, outcomes=outcomes if self.shared else None,
                                                   first_scene_id=self.first_scene_id, n_actions_1=self.n_actions_1)   # :551-556
         self.last_loss = losses[-1] if losses else None
-        if self.world > 1 and learn and losses:
+        if self.shared and learn and losses:
             # The replicas take identical steps on identical batches, but GPU kernels are not bit-reproducible across processes (MIOpen's weight-gradient kernels
             # accumulate with atomics): left alone the copies drift apart at rounding level. One broadcast of rank 0's weights, batch-norm buffers and Adam moments
-            # per round (88 MB over RCCL, against seconds of physics) makes "one agent" exact again; on the CPU it is a copy of equal values.
-            for t in list(self.policy_net.parameters()) + list(self.policy_net.buffers()):
-                sharding.broadcast_from_rank0(t.data)
-            for st in self.optimizer.state.values():
-                for v in st.values():
-                    if torch.is_tensor(v):
-                        sharding.broadcast_from_rank0(v)
+            # per round (88 MB over RCCL, against seconds of physics; flattened: one collective per dtype class, not one per tensor) makes "one agent" exact
+            # again; on the CPU it is a copy of equal values.
+            ts = [t.data for t in list(self.policy_net.parameters()) + list(self.policy_net.buffers())]
+            ts += [v for st in self.optimizer.state.values() for v in st.values() if torch.is_tensor(v)]
+            sharding.broadcast_many_from_rank0(ts)
         self.rounds_done += 1
         return {"observation": raw, "action": action, "reward": reward, "skipped": skipped, "greedy": greedy, "loss": self.last_loss if learn else None, "losses": losses,
                 "update_to_data": utd, "outcomes": outcomes, "epsilon": self.eps_threshold}

@@ -28,6 +28,20 @@ def pack_outcomes(env_ids, pixels, rots, rewards):
     return np.stack([np.asarray(env_ids), np.asarray(pixels), np.asarray(rots), np.asarray(rewards)], axis=1).astype(np.int32)
 
 
+# A process group of ONE rank normally skips every collective (there is nobody to talk to). FORCE_COLLECTIVES (or UR5_FORCE_COLLECTIVES=1 in the
+# environment) sends a one-rank job down the same RCCL calls as an N-rank job -- `gpurun` boxes have one GPU, and this is how the collective path
+# (RCCL init, all_gather_into_tensor of the int32 records, the broadcasts incl. the host-tensor detour, the replay's batch all-reduce) is executed
+# on a real MI355X at all (tests/test_sharding.py::test_rccl_collectives_execute_on_one_gpu, `bench.py --collectives`). Results are unchanged.
+import os as _os
+FORCE_COLLECTIVES = _os.environ.get("UR5_FORCE_COLLECTIVES", "0") not in ("", "0")
+
+
+def collectives_active():
+    """True when the calls below really go through torch.distributed: a process group exists and has peers (or FORCE_COLLECTIVES is set)."""
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES)
+
+
 def gather_outcomes(records, device=None):
     """all_gather of the per-rank outcome records -> int32 [n_total, 4] on every rank, ordered by rank (= by scene id).
 
@@ -39,7 +53,7 @@ def gather_outcomes(records, device=None):
     t = records if isinstance(records, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(records, dtype=np.int32))
     if device is not None:
         t = t.to(device)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not collectives_active():
         return t.clone()
     if dist.get_backend() != "nccl" and t.is_cuda:   # gloo (CPU tests, several ranks on one GPU): gather through host memory
         parts = [torch.empty(t.shape, dtype=t.dtype) for _ in range(dist.get_world_size())]
@@ -53,7 +67,7 @@ def gather_outcomes(records, device=None):
 def broadcast_from_rank0(t):
     """In-place broadcast of a tensor from rank 0 (no-op in a single process); gloo with CUDA tensors goes through host memory."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not collectives_active():
         return t
     if dist.get_backend() != "nccl" and t.is_cuda:
         h = t.cpu()
@@ -67,6 +81,27 @@ def broadcast_from_rank0(t):
     else:
         dist.broadcast(t, 0)
     return t
+
+
+def broadcast_many_from_rank0(tensors):
+    """In-place broadcast of a LIST of tensors from rank 0 as ONE collective per (dtype, host / device) class: the tensors are flattened into one buffer,
+    broadcast, and copied back. The agent's per-round weight / batch-norm / Adam-state refresh is ~400 tensors: one 88 MB broadcast instead of hundreds
+    of small ones (round-4 advice). Returns the number of collectives issued (0 in a single process)."""
+    import torch
+    if not collectives_active():
+        return 0
+    classes = {}
+    for t in tensors:
+        classes.setdefault((t.dtype, t.is_cuda), []).append(t)
+    for (_, _), ts in sorted(classes.items(), key=lambda kv: str(kv[0])):
+        flat = torch.cat([t.detach().reshape(-1) for t in ts]) if len(ts) > 1 else ts[0].detach().reshape(-1).clone()
+        broadcast_from_rank0(flat)
+        o = 0
+        for t in ts:
+            n = t.numel()
+            t.detach().copy_(flat[o:o + n].view(t.shape))
+            o += n
+    return len(classes)
 
 
 # ------------------------------------------------------------------ random numbers keyed by GLOBAL scene id
