@@ -196,6 +196,6 @@ struct Ur5Launch {
 #define UR5_SCR_STG (UR5_SCR_DCACHE + (UR5_MAXOBJ + 1) * 44)
 #define UR5_HESS_STRIDE ((UR5_SCR_STG + 2 * UR5_MAXCON * 21 + 63) / 64 * 64)
 #ifndef UR5_HENV_CAP
-#define UR5_HENV_CAP 8                             // envelopes up to this many doubles would stay in LDS: none does (kept as a switch: a build with a large cap puts them back)
+#define UR5_HENV_CAP (1 << 20)                     // envelopes up to min(this, Lds::HENV_DOUBLES = 2 384) doubles live in the LDS pool (round 5); -DUR5_HENV_CAP=8 forces the global-scratch path (tests)
 #endif
 #endif

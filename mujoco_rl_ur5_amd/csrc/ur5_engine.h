@@ -23,6 +23,7 @@
 // logic without a GPU. It is never loaded by the package (see DESIGN.md "Lane emulation").
 #pragma once
 #include <math.h>
+#include <stddef.h>
 #include "ur5_devmodel.h"
 
 #ifdef UR5_EMUL
@@ -196,6 +197,9 @@ enum { PF_KIN = 0, PF_CRB, PF_VEL, PF_BROAD, PF_NARROW, PF_ROWS, PF_NEWTON_INIT,
 #ifndef UR5_FORCE_GLOBAL_ENV
 #define UR5_FORCE_GLOBAL_ENV 0   // experiment: 1 = the envelope always lives in the scene's global-memory scratch (what a smaller LDS image would cost)
 #endif
+#ifndef UR5_DCACHE_LDS
+#define UR5_DCACHE_LDS 1         // 0 = the factored diagonal blocks stay in the global scratch even when the envelope is in LDS (A/B)
+#endif
 #ifndef UR5_SUP_K
 #define UR5_SUP_K 4   // hull vertices per lane and trip of the cooperative support scan
 #endif
@@ -364,8 +368,20 @@ template <class real, int NV_> struct Lds {
 #else
     real tw[NSLOT][6];                               // body twists of a dof vector: built and consumed inside images() / the Newton warm start
     real stw[2 * UR5_MAXCON][6];                     // staged wrench terms of the contact sides: built and consumed inside contact_gather(); the factorisation's panel rows
+    // Round 5: the envelope of the Newton Hessian / its factor is back in LDS -- in a POOL of arrays that are all dead between the gradient of a Newton
+    // iteration and the images of its search direction: the temporaries / twists / staged terms above, then the aref offsets (ceoff: consumed by the warm start
+    // before the first iteration) and the search direction's images (cde: written after the solve, dead once the step along the direction is taken).
+    // 2 384 doubles = 19 KB, no byte added to the image (two scenes per CU stay); every envelope of the sampled settle / grasp trajectories fits (max 1 776,
+    // tools/ + DESIGN.md), larger ones take the global-scratch path as before. The factor does not survive into the next iteration (images() and the gather
+    // write here), so an iteration whose active set did not change refactors instead of reusing it: same Hessian bits, same factor bits.
+    struct { real pool_kin_[KIN_DOUBLES]; real ceoff[UR5_MAXCON][NB], cde[UR5_MAXCON][NB]; };
+    double henv[KIN_DOUBLES + 2 * UR5_MAXCON * NB];
 #endif
   };
+#ifdef UR5_MANY
+  static constexpr int HENV_DOUBLES = KIN_DOUBLES + 2 * UR5_MAXCON * NB;
+  static_assert(sizeof(real) == sizeof(double) && KIN_DOUBLES >= 2 * UR5_MAXCON * 6 && KIN_DOUBLES >= NSLOT * 6, "the pool's head holds the union's other members");
+#endif
 #ifdef UR5_MANY
   // envelope (skyline) storage of the Newton Hessian in global memory, dofs permuted: objects sorted along x, robot last
   double* hess;
@@ -375,8 +391,7 @@ template <class real, int NV_> struct Lds {
   int island[UR5_MAXOBJ + 1];                        // island label of object k / of the robot (index nobj)
   int blk_first[UR5_MAXOBJ + 1], blk_ptr[UR5_MAXOBJ + 1];      // per block (sorted position; robot = block nobj): first coupled block (atomic min), envelope offset of its first row
   short blk_last[UR5_MAXOBJ + 1], lv[UR5_MAXOBJ + 1], reach_cnt[UR5_MAXOBJ + 1];   // last block reaching it, level of its panel (-1: none), blocks reaching it
-  double henv[UR5_HENV_CAP];                         // the envelope itself when it fits (it does for settled 40-object piles)
-  int env_inlds, nseq, act_changed, nskip;
+  int env_inlds, dc_inlds, nseq, act_changed, nskip; // env_inlds: this step's envelope fits the LDS pool (henv in the union above); dc_inlds: and so does the block cache
   static constexpr int REACH_CAP = (UR5_MAXOBJ + 1) * UR5_MAXOBJ / 4;                // half the worst case: 410 off-diagonal blocks = an envelope of > 15 k doubles
   short reach_ptr[UR5_MAXOBJ + 2], reach_list[REACH_CAP];                            // (settled piles: ~45 blocks, 2.5 k doubles); beyond it the scene is flagged
                                                                                      // per panel: the blocks below it whose rows reach it
@@ -430,7 +445,11 @@ template <class real, int NV_> struct Lds {
 #endif
   real cpos[UR5_MAXCON][3], cframe[UR5_MAXCON][6], cdist[UR5_MAXCON], cfri[UR5_MAXCON][NB > 4 ? 3 : 2];   // cframe: normal, tangent 1 (tangent 2 = n x t1)
   real cD[UR5_MAXCON];
+#ifndef UR5_MANY
   real ceoff[TAIL ? 1 : UR5_MAXCON][NB], ce[UR5_MAXCON][NB], cde[TAIL ? 1 : UR5_MAXCON][NB];   // ceoff: -aref in base space
+#else
+  real ce[UR5_MAXCON][NB];                           // (ceoff and cde live in the Hessian pool of the union above)
+#endif
 #ifdef UR5_EMUL
   real cfn[UR5_MAXCON];                              // normal force, test introspection only
 #endif
@@ -2168,8 +2187,9 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
   // wavefronts' timing; every entry of every slot is written, so nothing is zeroed first. Contacts are staged UR5_GCHUNK at a time (a settled pile has 40-80).
 #ifdef UR5_STG_LDS
   // experiment (round 4): the Hessian terms staged in LDS too, 21 contacts at a time (their 42 sides' 6 wrench + 21 Hessian terms fill the 9 KB staging area), instead of
-  // all at once in the scene's global scratch: no scratch traffic for the staging, two more barrier pairs and list walks per refactorisation
-  static constexpr int GCHUNK = 2 * UR5_MAXCON * 6 / 54;
+  // all at once in the scene's global scratch: no scratch traffic for the staging, two more barrier pairs and list walks per refactorisation: -7.5 %.
+  // Round 5: the staging area is the head of the 19 KB Hessian pool (dead at this point of an iteration: the envelope is rebuilt after the gather)
+  static constexpr int GCHUNK = L::HENV_DOUBLES / 54;   // round 5: the whole pool (44 contacts per round: most steps need one round, like the global staging)
   static constexpr bool STW_REL = true;
 #else
   static constexpr int GCHUNK = UR5_MAXCON;          // (the staging area in the scene's global scratch holds every side: one round)
@@ -2323,7 +2343,9 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
 #endif
     SYNC();
 #ifdef UR5_MANY
-    const bool refactor = S.act_changed != 0;
+    // (an envelope in the LDS pool does not outlive its iteration: images() and the staged gather write there. Such a step refactors in every iteration; with an
+    // unchanged active set that reproduces the same Hessian and factor bit for bit)
+    const bool refactor = S.act_changed != 0 || S.env_inlds;
 #else
     const bool refactor = true;
 #endif
@@ -2669,12 +2691,17 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
   static_assert(PSLOT == 64 || PSLOT == 32 || PSLOT == 16, "a panel slot is a whole wavefront or an aligned part of one");
   static constexpr int LPANEL_ROWS = 2 * UR5_MAXCON * 6 / (UR5_NT / PSLOT) / 6;
   UR5_FN static bool panel_in_lds(int w, int nr) { return w == 6 && nr <= LPANEL_ROWS; }
-#ifdef UR5_EMUL
-  UR5_FN real* panel_at(int i, int c, bool inl, int) { return inl ? &S.stw[0][0] + 6 * c : panel_row(i); }
-#else
-  UR5_FN real* panel_at(int i, int c, bool inl, int owner) { return inl ? &S.stw[0][0] + owner * (LPANEL_ROWS * 6) + 6 * c : panel_row(i); }   // owner: the wavefront whose quarter holds the panel
-#endif
   template <bool INLDS> UR5_FN double* hptr(int I, int J) { return (INLDS ? S.henv : S.hess) + S.env_ptr[I] + (J - S.env_first[I]); }
+  // ... and with the envelope itself in LDS (INLDS, round 5) there is no panel at all: a reaching row's finished entries of block column c0 go straight to their place
+  // H(i, c0..) -- during A1 only that row's own lane reads or writes them (the block's rows, which every lane reads, are not written) -- and the trailing update reads
+  // them there. (The staging area is part of the envelope's pool in that mode.)
+#ifdef UR5_EMUL
+  template <bool INLDS> UR5_FN real* panel_at(int i, int c, int c0, bool inl, int) { if constexpr (INLDS) return (real*)hptr<true>(i, c0); else return inl ? &S.stw[0][0] + 6 * c : panel_row(i); }
+#else
+  template <bool INLDS> UR5_FN real* panel_at(int i, int c, int c0, bool inl, int owner) {   // owner: the wavefront whose quarter holds the panel
+    if constexpr (INLDS) return (real*)hptr<true>(i, c0); else return inl ? &S.stw[0][0] + owner * (LPANEL_ROWS * 6) + 6 * c : panel_row(i);
+  }
+#endif
   UR5_BIG void envelope_structure() {
     static_assert(UR5_NT >= UR5_MAXNV, "one thread per Hessian row");
     const int nobj = M.nobj, nblk = nobj + 1, nv = M.nv;
@@ -2767,18 +2794,25 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     PAR(i, nv) {
       const int p2 = i < 6 * nobj ? i / 6 : nobj, j = i - 6 * p2, f = 6 * (p2 - S.blk_first[p2]);
       S.env_ptr[i] = (unsigned short)(S.blk_ptr[p2] + j * f + j * (j + 1) / 2);
-      if (i == nv - 1) { const int tot = S.env_ptr[i] + f + j + 1; S.env_ptr[nv] = (unsigned short)tot; S.env_inlds = tot <= UR5_HENV_CAP && !UR5_FORCE_GLOBAL_ENV; }
+      if (i == nv - 1) {
+        const int tot = S.env_ptr[i] + f + j + 1;
+        S.env_ptr[nv] = (unsigned short)tot;
+        S.env_inlds = tot <= UR5_HENV_CAP && tot <= L::HENV_DOUBLES && !UR5_FORCE_GLOBAL_ENV;
+        S.dc_inlds = S.env_inlds && tot + 44 * DC_POOL <= L::HENV_DOUBLES && UR5_DCACHE_LDS;
+      }
     }
     PAR(l, S.nlvl + 1) {   // panels with a lower level come first: lvl_ptr[l] = their number
       int o = 0;
       for (int p2 = 0; p2 < nblk; p2++) { const int v = S.lv[p2]; if (v >= 0 && v < l) o++; }
       S.lvl_ptr[l] = (short)o;
     }
-    PAR(p2, nblk) {       // exclusive prefix of the reach counts
-      int o = 0;
-      for (int q = 0; q < p2; q++) o += S.reach_cnt[q];
-      S.reach_ptr[p2] = (short)o;
-      if (p2 == nblk - 1) S.reach_ptr[nblk] = (short)(o + S.reach_cnt[p2]);
+    PAR(p2, nblk) {       // exclusive prefix of the reach counts, clamped to the list's capacity: when the lists overflow (flagged below) every later READ
+      int o = 0;          // reach_list[reach_ptr[p] + k] of the factorisation / the solves stays inside the array -- the flagged scene's numbers are wrong, its
+      for (int q = 0; q < p2; q++) o += S.reach_cnt[q];   // accesses are not (round-4 advice: the unclamped reads ran into the neighbouring LDS arrays)
+      const int e = o + S.reach_cnt[p2];
+      if (p2 == nblk - 1 && e > L::REACH_CAP) S.status |= UR5_ST_ROW_OVERFLOW;
+      S.reach_ptr[p2] = (short)(o < L::REACH_CAP ? o : L::REACH_CAP);
+      if (p2 == nblk - 1) S.reach_ptr[nblk] = (short)(e < L::REACH_CAP ? e : L::REACH_CAP);
     }
     SYNC();
     PAR(p2, nblk) {       // a panel's slot inside its level: panels of the same level in block order
@@ -2789,7 +2823,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
         S.lvl_list[o] = (short)p2;
       }
     }
-    if (S.reach_ptr[nblk] > L::REACH_CAP) S.status |= UR5_ST_ROW_OVERFLOW;   // (benign race: every lane ORs the same bit) the lists below are cut off: flagged, never silent
+    // (an overflow was flagged above: the lists below are cut off at the capacity, the pointers with them -- flagged, never silent, never out of bounds)
     PAR(p2, nblk) { int o = S.reach_ptr[p2]; for (int q = p2 + 1; q <= S.blk_last[p2]; q++) if (S.blk_first[q] <= p2) { if (o < L::REACH_CAP) S.reach_list[o] = (short)q; o++; } }
 #ifndef UR5_EMUL
     // the pair of Hessian blocks every coupled contact adds to (envelope_assemble: a block pair is owned by ONE wavefront)
@@ -2974,8 +3008,15 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     }
   }
   // factored blocks are kept packed (lower triangle, then 1 / diagonal) in S.dcache for the triangular solves
-  template <int W> UR5_FN void diag_store(int p2, const Diag<W>& d) {
-    real* c = S.hess + UR5_SCR_DCACHE + 44 * p2;
+  // Round 5: with the envelope in the LDS pool (env_inlds) the block cache is in LDS too whenever it fits (S.dc_inlds; it does for every sampled envelope below
+  // 1 856 doubles): the first DC_WBG blocks in the body accumulators WB | G -- dead from the end of the Hessian assembly to the next gather, which rewrites every
+  // entry --, the others behind the envelope in the pool. A level of the factorisation / the sweeps then touches no global memory at all. (Round 4 measured an LDS
+  // COPY of a global cache as slower: that was one more round trip per solve; this is the cache itself.)
+  static constexpr int DC_WBG = (int)((sizeof(L::WB) + sizeof(L::G)) / sizeof(real)) / 44;
+  static_assert(offsetof(L, G) == offsetof(L, WB) + sizeof(L::WB), "WB | G are one stretch of LDS");
+  static constexpr int DC_POOL = UR5_MAXOBJ + 1 > DC_WBG ? UR5_MAXOBJ + 1 - DC_WBG : 0;   // blocks cached behind the envelope
+  UR5_FN real* dc_lds(int p2) { return p2 < DC_WBG ? &S.WB[0][0] + 44 * p2 : (real*)S.henv + S.env_ptr[M.nv] + 44 * (p2 - DC_WBG); }
+  template <int W> UR5_FN static void diag_put(real* c, const Diag<W>& d) {
 #pragma unroll
     for (int a = 0; a < W; a++) {
 #pragma unroll
@@ -2983,14 +3024,19 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       c[36 + a] = d.inv[a];
     }
   }
-  template <int W> UR5_FN void diag_cached(int p2, Diag<W>& d) {
-    const real* c = S.hess + UR5_SCR_DCACHE + 44 * p2;
+  template <int W> UR5_FN static void diag_get(const real* c, Diag<W>& d) {
 #pragma unroll
     for (int a = 0; a < W; a++) {
 #pragma unroll
       for (int bb = 0; bb < W; bb++) d.l[a][bb] = bb <= a ? c[a * (a + 1) / 2 + bb] : (real)0;
       d.inv[a] = c[36 + a];
     }
+  }
+  template <int W> UR5_FN void diag_store(int p2, const Diag<W>& d) {
+    if (S.dc_inlds) diag_put<W>(dc_lds(p2), d); else diag_put<W>(S.hess + UR5_SCR_DCACHE + 44 * p2, d);   // (two code paths: an LDS and a global pointer must not meet in one select)
+  }
+  template <int W> UR5_FN void diag_cached(int p2, Diag<W>& d) {
+    if (S.dc_inlds) diag_get<W>(dc_lds(p2), d); else diag_get<W>(S.hess + UR5_SCR_DCACHE + 44 * p2, d);
   }
   // (Round 4 also tried an LDS copy of the factored diagonal blocks for the duration of every triangular solve -- 9 KB packed, one cooperative copy per solve into the
   // staging area: the solves got 8 % SLOWER (one more memory round trip and two barriers per solve; the per-level fetches hit the vector L1 anyway),
@@ -3064,7 +3110,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       b[i] -= sacc;
     }
     if (ii >= W) {   // (the block's own rows live on in dcache; only the rows below it are read back by the trailing update)
-      real* o = panel_at(i, ii - W, inl, owner);
+      real* o = panel_at<INLDS>(i, ii - W, c0, inl, owner);
 #pragma unroll
       for (int k = 0; k < W; k++) o[k] = out[k];
     }
@@ -3126,10 +3172,11 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     const int c0 = 6 * p2, w = blk_width(p2);
     const int nrb = S.reach_ptr[p2 + 1] - S.reach_ptr[p2], nr = reach_rows(p2, nrb);
     const bool inl = panel_in_lds(w, nr);
+    if constexpr (!INLDS)
     UR5_PLANE_SHARED(c, nr, sh) {
       const int i = reach_row(p2, nrb, c);
       double* row = hptr<INLDS>(i, c0);
-      const real* pr = panel_at(i, c, inl, sh.q);
+      const real* pr = panel_at<INLDS>(i, c, c0, inl, sh.q);
       for (int k = 0; k < w; k++) row[k] = (double)pr[k];
     }
     // the pairs (ii >= jj) of the lower triangle, folded into a rectangle so that no lane draws an empty (jj > ii) slot: row r of the rectangle holds row r of the
@@ -3141,7 +3188,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       if (ii >= nr) continue;
       const int i = reach_row(p2, nrb, ii), j = reach_row(p2, nrb, jj);
       real sacc = 0;
-      { const real* pi = panel_at(i, ii, inl, sh.q); const real* pj = panel_at(j, jj, inl, sh.q); for (int k = 0; k < w; k++) sacc += pi[k] * pj[k]; }
+      { const real* pi = panel_at<INLDS>(i, ii, c0, inl, sh.q); const real* pj = panel_at<INLDS>(j, jj, c0, inl, sh.q); for (int k = 0; k < w; k++) sacc += pi[k] * pj[k]; }
       *hptr<INLDS>(i, j) -= (double)sacc;
     }
   }
@@ -4176,6 +4223,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
 #ifdef UR5_MANY
     out[o++] = S.env_ptr[M.nv]; out[o++] = S.ncouple;   // envelope size (doubles), contacts between two movable bodies
     { int ns = 0; for (int p2 = 0; p2 <= M.nobj; p2++) if (S.blk_first[p2] != p2 || S.blk_last[p2] != p2) ns++; out[o++] = ns; }   // coupled blocks
+    out[UR5_DEBUG_STRIDE - UR5_MAXCAND - 2] = S.env_inlds; out[UR5_DEBUG_STRIDE - UR5_MAXCAND - 1] = S.dc_inlds;   // where this step's envelope / block cache lived
 #endif
     out[7] = S.ncand;
     for (int i = 0; i < S.ncand && i < UR5_MAXCAND; i++) out[UR5_DEBUG_STRIDE - UR5_MAXCAND + i] = S.cand[i];   // broad-phase survivors (pair indices)

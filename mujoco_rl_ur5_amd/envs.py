@@ -134,7 +134,33 @@ class GraspEnv(object):
         self.step_called += 1
         info["phase_steps"] = self._one(self.last_phase_steps)
         info["skipped"] = self._one(skip)
+        info["status"] = self._one(self.check_status())
         return self.current_observation, self._one(reward), done, info
+
+    # ------------------------------------------------------------------ soft failures of a scene (per-env status for soft failures)
+    STATUS_BITS = {1: "contact slots exhausted: contacts were dropped (UR5_ST_CONTACT_OVERFLOW; 30 slots per small scene, 96 per 40-object pile)",
+                   2: "a step produced a non-finite state: the scene was reset to qpos0 as mj_step does (UR5_ST_NAN)",
+                   4: "constraint-row / envelope lists exhausted (UR5_ST_ROW_OVERFLOW)", 8: "broad-phase candidate list exhausted: pairs were dropped (UR5_ST_CAND_OVERFLOW)"}
+
+    def scene_status(self):
+        """int64 [n_envs]: the engine's status bits of every scene, of its running episode and of episodes that ended inside a fused launch (0 = clean)."""
+        c = self.sim.counters()
+        return c["status"] | c["status_ended"]
+
+    def check_status(self):
+        """Reads the status words and warns ONCE per distinct bit when a scene is flagged: its rewards come from a simulation that dropped contacts / rows or was
+        reset, and what survives a contact-slot overflow depends on the order the slots were claimed in (round-4 advice). ``self.last_status`` keeps the words."""
+        st = self.scene_status()
+        self.last_status = st
+        seen = getattr(self, "_status_warned", 0)
+        new = int(np.bitwise_or.reduce(st)) & ~seen if len(st) else 0
+        if new:
+            import warnings
+            self._status_warned = seen | new
+            for bit, what in self.STATUS_BITS.items():
+                if new & bit:
+                    warnings.warn(f"GraspEnv: {int((st & bit != 0).sum())} of {self.n_envs} scenes flagged -- {what}; mask their rewards with env.last_status", RuntimeWarning)
+        return st
 
     def move_and_grasp(self, coordinates, rotation, render=False, record_grasps=False, markers=False, plot=False, skip=None):
         """GraspingEnv.py:205-386 for every scene at once; scenes flagged in ``skip`` (:124-131) sit the launch out."""
@@ -245,6 +271,7 @@ class GraspEnv(object):
         self.sim.grasp_attempt_dev(self._t_act.data_ptr(), self._t_rew.data_ptr(), check_mode=self.check_mode, table_height=self.TABLE_HEIGHT)
         self.sim.sync()
         self.step_called += 1
+        self.check_status()                                                                      # flagged scenes: warned about once, words in self.last_status
         return self._t_rew.clone(), skip
 
     def close(self):

@@ -292,4 +292,7 @@ class BatchSim:
         for k in ("qfrc_smooth", "qacc_smooth", "qacc"):
             d[k] = out[:, o:o + mv]; o += mv
         d["contacts"] = out[:, o:o + 10 * maxcon].reshape(self.n, maxcon, 10)
+        if self.variant == 1:                                    # the pile engine: envelope size, and whether envelope / block cache of the step lived in the LDS pool
+            d["envelope_doubles"] = out[:, 4].astype(int)
+            d["env_in_lds"], d["dcache_in_lds"] = out[:, stride - 512 - 2].astype(int), out[:, stride - 512 - 1].astype(int)
         return d

@@ -48,6 +48,10 @@ def lib():
         L.ur5o_set_ctrl.argtypes = [vp, dp]
         L.ur5o_get_ctrl.argtypes = [vp, dp]
         L.ur5o_forward.argtypes = [vp]
+        L.ur5o_newton_trace.argtypes = [vp, C.c_int]
+        L.ur5o_get_newton_trace.argtypes = [vp, vp, C.c_int]
+        L.ur5o_get_newton_trace.restype = C.c_int
+        L.ur5o_get_row_contacts.argtypes = [vp, vp]
         L.ur5o_step.argtypes = [vp, C.c_int]
         L.ur5o_reset.argtypes = [vp, C.c_uint64, C.c_int, C.c_int]
         L.ur5o_move_group.argtypes = [vp, C.c_uint, dp, C.c_double, C.c_int, ip]
@@ -272,3 +276,17 @@ class Oracle:
     @property
     def solver_iter_last(self):
         return lib().ur5o_solver_iter_last(self._h)
+
+    def newton_trace(self, on=True):
+        """Switch the recording of the Newton solve's active sets on / off (test hook of ur5_oracle.cpp newton_direction)."""
+        lib().ur5o_newton_trace(self._h, 1 if on else 0)
+
+    def get_newton_trace(self):
+        """(active uint8 [evaluations, rows], contact index of every row int32 [rows], -1 for equality / limit rows) of the LAST solve."""
+        ne = lib().ur5o_nefc(self._h)
+        n = lib().ur5o_get_newton_trace(self._h, None, 0)
+        out = np.zeros((max(n, 1), max(ne, 1)), dtype=np.uint8)
+        lib().ur5o_get_newton_trace(self._h, out.ctypes.data_as(C.c_void_p), n)
+        rc = np.zeros(max(ne, 1), dtype=np.int32)
+        lib().ur5o_get_row_contacts(self._h, rc.ctypes.data_as(C.c_void_p))
+        return out[:n, :ne], rc[:ne]

@@ -1192,7 +1192,16 @@ struct Sim {
     }
     return true;
   }
+  // test hook (ur5o_newton_trace): the active flag of every constraint row at each Hessian evaluation of the last solve -- what tools/newton_iteration_analysis.py
+  // reads to see how much of the Hessian really changes from one Newton iteration to the next
+  bool trace_newton = false;
+  std::vector<std::vector<unsigned char>> newton_trace;
   void newton_direction() {  // nsearch = -H^-1 grad at the current qacc (uses njar)
+    if (trace_newton) {
+      std::vector<unsigned char> a(rows.size());
+      for (size_t ri = 0; ri < rows.size(); ri++) a[ri] = !(rows[ri].unilateral && njar[ri] >= 0);
+      newton_trace.push_back(a);
+    }
     nH = Mm;
     for (size_t ri = 0; ri < rows.size(); ri++) {
       const Row& r = rows[ri];
@@ -1227,6 +1236,7 @@ struct Sim {
     for (size_t i = 0; i < ne; i++) njar[i] = row_jar(rows[i], qacc);
     double cost = std::min(cw, cs);
     double scale = 1.0 / (M.meaninertia * std::max(1, nv));
+    newton_trace.clear();
     newton_direction();
     for (int it = 0; it < solver_iterations(); it++) {
       // exact line search on phi(alpha) = cost(qacc + alpha * search)
@@ -1958,6 +1968,24 @@ void ur5o_render(void* h, int cam, int W, int H, int mode, unsigned char* rgb, f
 int ur5o_ncon(void* h) { return (int)((Sim*)h)->contacts.size(); }
 int ur5o_nefc(void* h) { return (int)((Sim*)h)->rows.size(); }
 int ur5o_solver_iter_last(void* h) { return ((Sim*)h)->solver_iter_last; }
+// Newton trace of the last solve: ur5o_newton_trace(h, 1) switches recording on; ur5o_get_newton_trace copies [evaluations][rows] active flags (returns the evaluations)
+void ur5o_newton_trace(void* h, int on) { ((Sim*)h)->trace_newton = on != 0; }
+int ur5o_get_newton_trace(void* h, unsigned char* out, int cap_evals) {
+  Sim* s = (Sim*)h;
+  const int ne = (int)s->rows.size(), n = (int)s->newton_trace.size();
+  for (int e = 0; e < n && e < cap_evals; e++) if (out && (int)s->newton_trace[e].size() == ne) memcpy(out + (size_t)e * ne, s->newton_trace[e].data(), ne);
+  return n;
+}
+// per row: the two dofs' bodies are not stored; the contact a row belongs to is (contact index) for contact rows and -1 for equality / limit rows
+void ur5o_get_row_contacts(void* h, int* out) {
+  Sim* s = (Sim*)h;
+  for (size_t i = 0; i < s->rows.size(); i++) out[i] = -1;
+  for (size_t ci = 0; ci < s->contacts.size(); ci++) {
+    const Contact& c = s->contacts[ci];
+    const int nr = c.dim == 1 ? 1 : 2 * (c.dim - 1);
+    if (c.efc_address >= 0) for (int k = 0; k < nr && c.efc_address + k < (int)s->rows.size(); k++) out[c.efc_address + k] = (int)ci;
+  }
+}
 // per contact: dist, pos[3], normal[3], geom1, geom2, dim, normal force (sum of pyramid row forces), color  -> 12 doubles
 void ur5o_get_contacts(void* h, double* out) {
   Sim* s = (Sim*)h;

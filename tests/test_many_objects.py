@@ -122,6 +122,28 @@ def test_envelope_in_global_memory_path(model_many):
     d = sim.forward_debug()
     qacc = o.vec("qacc")
     assert d["ncon"][0] >= 20 and np.abs(d["qacc"][0][:model_many.nv] - qacc).max() < 1e-6 * max(1.0, np.abs(qacc).max())
+    assert d["env_in_lds"][0] == 0 and d["dcache_in_lds"][0] == 0 and d["envelope_doubles"][0] > 8
+
+
+def test_envelope_and_block_cache_live_in_the_lds_pool(model_many, emul_lib):
+    """Round 5: the envelope of the Newton Hessian (and the cache of its factored diagonal blocks) sits in LDS arrays that are dead during assembly / factorisation /
+    solve -- kinematic temporaries | aref offsets | search-direction images, 2 384 doubles -- whenever it fits; it does for the whole drop and for the settled pile.
+    Same arithmetic as the global-scratch path: the two builds agree bit for bit, and both agree with the oracle."""
+    from conftest import build_emul
+    sims = [BatchSim(model_many, 1, lib_path=emul_lib), BatchSim(model_many, 1, lib_path=build_emul(("-DUR5_HENV_CAP=8",), "libur5sim_emul_globalenv.so"))]
+    modes = []
+    for sim in sims:
+        sim.reset([21], 1, 0.0)
+        m = []
+        for _ in range(6):
+            sim.step(100)
+            d = sim.forward_debug()
+            m.append((int(d["env_in_lds"][0]), int(d["dcache_in_lds"][0]), int(d["envelope_doubles"][0]), int(d["ncon"][0])))
+        modes.append(m)
+    a, b = sims[0].get_state(), sims[1].get_state()
+    assert all(np.array_equal(a[k], b[k]) for k in ("qpos", "qvel", "warmstart"))            # 600 steps, contacts from step ~200 on: identical bits
+    assert all(e == 1 and dc == 1 and 861 <= tot <= 1856 for e, dc, tot, _ in modes[0]) and all(e == 0 and dc == 0 for e, dc, _, _ in modes[1])
+    assert [x[2:] for x in modes[0]] == [x[2:] for x in modes[1]] and modes[0][-1][3] >= 20
 
 
 def test_render_with_cylinders_and_capsules(model_many, emul_lib):
