@@ -2681,11 +2681,12 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
   // ... or, when the panel is an object's (6 columns) and at most LPANEL_ROWS rows reach it -- nearly always --, in the wavefront's quarter of the LDS area that the
   // staged wrench terms / body twists / kinematic temporaries use at other times (nothing else touches it during a factorisation), indexed by the row's position
   // among the reaching rows: the write -> barrier -> read of every level stays out of global memory
-  // -DUR5_PANEL_SLOT=16 (experiment prepared at the end of round 4, NOT measured yet; default 64 = one wavefront per panel): settled piles have few levels (3.7) but 6-9 NARROW
-  // panels in the first (6 own + ~6 reaching rows, 21 row pairs: tools/pile_structure_stats.py, profiles/r04_pile_structure_stats_12piles.log), so a pass of four panels uses
-  // 48 of its 256 lanes and a factorisation takes 4.7 passes. With 16-lane slots a pass holds 16 panels (passes = levels); a wider panel's slot makes more trips.
+  // UR5_PANEL_SLOT: lanes that work on one panel of a pass. Settled piles have few levels (3.7) but 6-9 NARROW panels in the first (6 own + ~6 reaching rows, 21 row
+  // pairs: tools/pile_structure_stats.py, profiles/r04_pile_structure_stats_12piles.log), so with a wavefront per panel (64, rounds 3-4) a pass of four panels used 48 of
+  // its 256 lanes and a factorisation took 4.7 passes; with 32-lane slots a pass holds 8 panels (passes ~ levels), a wider panel's slot makes more trips. Same bits.
+  // Same-box A/B at 2048 piles with the envelope in LDS (profiles/r05_a_ab_many.log): 64 -> 559.9 k, 32 -> 576.0 k, 16 -> 574.5 k env-steps/s.
 #ifndef UR5_PANEL_SLOT
-#define UR5_PANEL_SLOT 64
+#define UR5_PANEL_SLOT 32
 #endif
   static constexpr int PSLOT = UR5_PANEL_SLOT;       // lanes that work on one panel of a pass
   static_assert(PSLOT == 64 || PSLOT == 32 || PSLOT == 16, "a panel slot is a whole wavefront or an aligned part of one");
