@@ -54,7 +54,7 @@ class It1Rounds:
 
     def __init__(self, torch, model, sim, dev, lo, n_local, n_total, rule, kind="it1"):
         from mujoco_rl_ur5_amd.controller import MJ_Controller
-        self.torch, self.sim, self.rule, self.n, self.n_total, self.kind = torch, sim, rule, n_local, n_total, kind
+        self.torch, self.sim, self.rule_name, self.n, self.n_total, self.kind = torch, sim, rule, n_local, n_total, kind
         self.gid = torch.arange(lo, lo + n_local, dtype=torch.int64, device=dev)
         self.state = sim.state_tensor(dev)                                        # [n, stride] f64, aliases the engine's records
         # objects: 3 slides + ball each (UR5gripper_2_finger.xml:233-239): world position = body_pos + slide offsets; free joints hold world coordinates
@@ -117,17 +117,40 @@ class It1Rounds:
         self._alive = (seeds, act, order)                                        # until the next round's launch is queued behind this one
         return act, pixel
 
+    def rule(self):
+        """The headline's aiming rule as the engine evaluates it in the kernel (include/ur5sim.h ur5_aim_rule, kind 1): exactly `actions()` below for rule "aimed"."""
+        from mujoco_rl_ur5_amd.native import AimRule
+        return AimRule(kind=1, episode_rounds=EP, first_scene_id=int(self.gid[0]), n_total=int(self.n_total), base_seed=BASE_SEED, plate_half_x=0.27, plate_centre_y=-0.6,
+                       plate_half_y=0.19, z_min=0.905, z_max=1.0, grasp_z=0.91, fallback_x=0.0, fallback_y=-0.6)
+
+    def launch_rounds(self, r0, k, reward_rows):
+        """Rounds r0 .. r0 + k - 1 of every scene in ONE launch, no lock step between scenes (ur5_grasp_rounds_dev): the scene aims by itself with rule(), attempts, and
+        resets + settles where its episode ends, then goes on to its next round. Per-scene results are bit-identical to k calls of launch() (tests/test_grasp_rounds.py).
+        reward_rows: int32 [k, n] (contiguous rows of the reward buffer). Returns (action records [k, n, 8], aimed pixels [k, n] int32)."""
+        torch = self.torch
+        assert self.kind == "it1" and self.rule_name == "aimed", "the in-kernel rule is the headline's (physics only, fixed grasp height)"
+        act = torch.zeros((k, self.n, 8), dtype=torch.float64, device=self.gid.device)
+        rr = torch.arange(r0, r0 + k, device=self.gid.device)
+        resets = (((self.gid[:, None] + rr[None, :] + 1) % EP) == 0).sum(dim=1)                      # episode ends of the scene inside the launch
+        order = torch.argsort(resets, descending=True, stable=True).to(torch.int32)                # the scenes with more settling to do first
+        self.sim.set_order_dev(order.data_ptr())
+        self.sim.grasp_rounds_dev(self.rule(), r0, k, reward_rows.data_ptr(), act.data_ptr(), check_mode=1, table_height=0.91, settle_ms=1000.0)
+        self._alive = (act, order, reward_rows)
+        px = ((act[..., 0] - self.px0[0]) / self.dxdpx).round().clamp(0, 199)
+        py = ((act[..., 1] - self.px0[1]) / self.dydpy).round().clamp(0, 199)
+        return act, (py * 200 + px).to(torch.int32)
+
     def actions(self, r):
         """[n, 8] f64 action records (x y z rot skip - - -), the aimed pixel index [n] int32 and whether a box is aimed at [n] bool, from the
         CURRENT state on the device."""
         torch = self.torch
         a = torch.zeros((self.n, 8), dtype=torch.float64, device=self.gid.device)
         a[:, 2] = 0.91
-        if self.rule == "aimed" and self.kind == "many":
+        if self.rule_name == "aimed" and self.kind == "many":
             xy, rot, any_on = self.pile_box_actions(r)
             a[:, :2] = xy
             a[:, 3] = rot.double()
-        elif self.rule == "aimed":
+        elif self.rule_name == "aimed":
             q = self.state[:, 8:8 + 7 * self.nobj].view(self.n, self.nobj, 7)[:, :, :3] + self.pos0      # [n, nobj, 3] world
             on = (q[:, :, 0].abs() <= 0.27) & ((q[:, :, 1] + 0.6).abs() <= 0.19) & (q[:, :, 2] >= 0.905) & (q[:, :, 2] <= 1.0)
             j = (self.gid + r) % EP
@@ -260,8 +283,23 @@ class Job:
         self.groups = [Group(g) for g in range(self.G)]
         torch.cuda.synchronize()
 
-    def run_rounds(self, r0, r1, wls=None):
+    def run_rounds(self, r0, r1, wls=None, fused=0):
+        """Rounds r0 .. r1 - 1. fused = K > 0 (headline workload only): K consecutive rounds per launch with the aiming rule evaluated in the kernel -- a scene does not
+        wait for the others between its rounds (ur5_grasp_rounds_dev), and the outcome records of the K rounds travel in ONE all_gather per launch."""
         torch, gathered = self.torch, None
+        self.launches = getattr(self, "launches", 0)
+        if fused > 0 and wls is None and self.kind == "it1":
+            r = r0
+            while r < r1:
+                k = min(fused, r1 - r)
+                for gr in self.groups:
+                    with torch.cuda.stream(gr.stream):
+                        act, pixel = gr.wl.launch_rounds(r, k, gr.reward[r:r + k])
+                        rec = torch.stack([gr.ids[None, :].expand(k, -1), pixel, act[..., 3].to(torch.int32), gr.reward[r:r + k]], dim=2).reshape(-1, 4)
+                        gathered = self.sharding.gather_outcomes(rec)              # [world * k * n_g, 4]: 16 B per scene and round, once per launch
+                        self.launches += 1
+                r += k
+            return gathered
         for r in range(r0, r1):
             for k, gr in enumerate(self.groups):
                 with torch.cuda.stream(gr.stream):
@@ -269,13 +307,14 @@ class Job:
                     act, pixel = wl.launch(r, gr.reward[r])                        # (observation +) attempt (+ reset_model for the scenes whose episode ends)
                     rec = torch.stack([gr.ids, pixel, act[:, 3].to(torch.int32), gr.reward[r]], dim=1)
                     gathered = self.sharding.gather_outcomes(rec)                  # the path's only collective: 16 B per scene per round
+                    self.launches += 1
         return gathered
 
     def counters(self):
         cs = [gr.sim.counters() for gr in self.groups]
         return {k: np.concatenate([c[k] for c in cs]) for k in cs[0]}
 
-    def timed(self, r0, r1, wls=None):
+    def timed(self, r0, r1, wls=None, fused=0):
         torch = self.torch
         for gr in self.groups:
             gr.sim.sync()
@@ -284,7 +323,9 @@ class Job:
             self.dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        g = self.run_rounds(r0, r1, wls)
+        l0 = getattr(self, "launches", 0)
+        g = self.run_rounds(r0, r1, wls, fused)
+        self.timed_launches = self.launches - l0
         torch.cuda.synchronize()
         if self.sharding.collectives_active():
             self.dist.barrier()
@@ -367,10 +408,10 @@ def strong_scaling_points(torch, dist, sharding, model, dev, dev_id, args):
     for n in (2048, 1024, 512):
         try:
             job = Job(torch, dist, sharding, model, "it1", "aimed", n, n, 0, 1, dev, dev_id, args.groups, 12)
-            job.run_rounds(0, 2)
-            dt, c0, c1, _, _ = job.timed(2, 10)
+            job.run_rounds(0, 2, None, args.fused_rounds)
+            dt, c0, c1, _, _ = job.timed(2, 10, None, args.fused_rounds)
             steps = int((c1["total_steps"] - c0["total_steps"]).sum())
-            pts.append({"scenes_per_gpu": n, "env_steps_per_s_per_gpu": steps / dt, "ms_per_round": 1e3 * dt / 8, "rounds": 8,
+            pts.append({"scenes_per_gpu": n, "env_steps_per_s_per_gpu": steps / dt, "ms_per_round": 1e3 * dt / 8, "rounds": 8, "rounds_per_launch": args.fused_rounds or 1,
                         "corresponds_to": f"{4096 // n} GPUs x {n} scenes"})
             job.close()
         except Exception as exc:  # noqa: BLE001
@@ -388,6 +429,8 @@ def main():
                     help="weak: 4096 scenes per GPU; strong: 4096 scenes in total, 4096 / N per GPU (SURVEY.md section 8e)")
     ap.add_argument("--rule", choices=("aimed", "uniform"), default="aimed", help="action rule of the timed rounds (see the module docstring)")
     ap.add_argument("--groups", type=int, default=2, help="scene groups per GPU, one engine handle + HIP stream each, rounds pipelined (1 = one handle)")
+    ap.add_argument("--fused-rounds", type=int, default=4, help="headline workload: K consecutive rounds of a scene per launch, the aiming rule evaluated in the kernel, no lock "
+                    "step between scenes (ur5_grasp_rounds_dev; per-scene results bit-identical to K lock-step rounds). 0 = one launch per round, re-aimed on the device by torch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the uniform-rule figure and the it4 / many sub-results (N = 1 only)")
     ap.add_argument("--sub", choices=("it4", "many", "many4096", "dqn", "dqn2048"), default=None,
@@ -456,9 +499,11 @@ def main():
     job = Job(torch, dist, sharding, model, "it1", args.rule, n_local, n_total, lo, world, dev, dev_id, args.groups, rounds + 8)
     groups, G, n_g, run_rounds, timed = job.groups, job.G, job.n_g, job.run_rounds, job.timed
 
-    run_rounds(0, args.warmup)
-    elapsed, c0, c1, kernel_ms, gathered = timed(args.warmup, rounds)
-    assert gathered.shape == (n_g * world, 4)
+    fused = args.fused_rounds if args.rule == "aimed" else 0
+    run_rounds(0, args.warmup, None, fused)
+    elapsed, c0, c1, kernel_ms, gathered = timed(args.warmup, rounds, None, fused)
+    launches = max(1, job.timed_launches)                                          # engine launches of the timed region on this rank (all scene groups)
+    assert gathered.shape[1] == 4 and gathered.shape[0] % (n_g * world) == 0
     reward = torch.cat([gr.reward[:rounds] for gr in groups], dim=1)
     steps_local = int((c1["total_steps"] - c0["total_steps"]).sum())
     per_round = reward[args.warmup:].double().mean(dim=1)
@@ -485,7 +530,7 @@ def main():
         if os.path.exists(tp):
             with open(tp) as f:
                 tj = json.load(f)
-            traffic = tj["hbm_bytes_per_env_step"] * steps_local / (args.steps * G)          # per launch, like algorithmic_bytes_per_launch below
+            traffic = tj["hbm_bytes_per_env_step"] * steps_local / launches                  # per launch, like algorithmic_bytes_per_launch below
             traffic_src = (f"from profiles/ ({tj.get('source', 'hbm_traffic_latest.json')}), NOT measured in this run: (2 x FETCH_SIZE + WRITE_SIZE) per "
                            "env-step of the rocprofv3 PMC passes of this command x env-steps of an average timed launch")
         out = {
@@ -503,15 +548,18 @@ def main():
                                    "(+ 1000 ms settle) for the quarter of the batch that starts an episode in the round",
                        "rule": ("aimed: current position of a box still on the pick plate, read from the state records on the device" if args.rule == "aimed"
                                 else "uniform: uniformly drawn table pixel, rotation 0 (SURVEY.md 8d / Grasping_Agent_multidiscrete.py:266-280)"),
-                       "scenes_per_gpu": n_local, "scenes_total": n_total, "scene_groups_per_gpu": G, "solver": "Newton (MuJoCo default; north_star says PGS, see DESIGN.md D1), "
+                       "scenes_per_gpu": n_local, "scenes_total": n_total, "scene_groups_per_gpu": G,
+                       "rounds_per_launch": (f"{fused}: the rule is evaluated in the kernel and a scene runs {fused} consecutive rounds (attempt, and reset_model + settle where its episode "
+                                             "ends) without waiting for the other scenes; per-scene results bit-identical to one launch per round (tests/test_grasp_rounds.py)") if fused else "1 (lock step: every scene waits for the round's slowest)",
+                       "solver": "Newton (MuJoCo default; north_star says PGS, see DESIGN.md D1), "
                        f"tolerance 1e-10, iteration cap {model.opt['iterations']}", "timestep_s": model.opt["timestep"],
                        "parallelism": f"scenes sharded x{world}, 1 all_gather of 16 B outcome records per scene group and round"
                                       + (f"; --collectives: one-rank process group, backend {dist.get_backend()}, every collective issued" if world == 1 and sharding.collectives_active() else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                          "traffic_source": traffic_src, "kernel": "ur5_run_kernel<32>", "bytes_per_env_step": bytes_per_step,
-                         "avg_launch_ms": kernel_ms / (args.steps * G), "launches_per_round": G, "launch_concurrency": G,
-                         "env_steps_per_launch": steps_local / (args.steps * G),
-                         "algorithmic_bytes_per_launch": bytes_per_step * steps_local / (args.steps * G),
+                         "avg_launch_ms": kernel_ms / launches, "launches_per_round": launches / args.steps, "launch_concurrency": G, "rounds_per_launch": args.steps * G / launches,
+                         "env_steps_per_launch": steps_local / launches,
+                         "algorithmic_bytes_per_launch": bytes_per_step * steps_local / launches,
                          "kernel_ms_per_round": 1e3 * elapsed_local / args.steps, "env_steps_per_round": steps_local / args.steps,
                          "note": "algorithmic state bytes x env-steps of the timed rounds / their wall time on rank 0: one attempt + episode-reset "
                                  "launch per scene group and round, the groups' launches overlapping on their own HIP streams (avg_launch_ms = "

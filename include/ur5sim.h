@@ -84,6 +84,27 @@ int ur5_grasp_attempt_dev(ur5_sim* h, const double* action_dev, int check_mode, 
    ur5_reset_dev do, then the scene settles for settle_ms. The reward is the attempt's. Saves the separate, poorly filled settle launch. */
 int ur5_grasp_attempt_reset_dev(ur5_sim* h, const double* action_dev, int check_mode, double table_height, int* reward_dev,
                                 const uint64_t* reset_seeds_dev, double settle_ms);
+/* K consecutive grasp rounds of every scene in ONE launch, with NO lock step between scenes (round 5). The reference's episode loop
+   (example_agent.py:15-27: action = policy(observation); env.step(action); reset every few steps) has no barrier between scenes because it has
+   one scene; a batch that waits for its slowest scene after every round idles most of the chip when the scenes are few (strong scaling: 512 per
+   GPU). For a SCRIPTED policy that reads only the scene's own state the engine can evaluate the policy itself: round k of the launch (= round
+   round0 + k of the job) aims with `rule`, runs GraspEnv.step (the script of ur5_grasp_attempt_dev) and, when the scene's episode ends with that
+   round, GraspEnv.reset_model (seed = base_seed + global scene id + n_total * episode, then settle_ms) -- then goes straight on to its next round.
+   rule kind 1 (bench.py It1Rounds, "aimed"): in round r scene g tries the boxes (g + (g + r) % episode_rounds + i) % nobj, i = 0.., and aims at
+   the first whose centre lies on the pick plate (|x| <= plate_half_x, |y - plate_centre_y| <= plate_half_y, z_min <= z <= z_max) at height
+   grasp_z with wrist rotation (g / episode_rounds + r) % 6; an empty plate gets an attempt at (fallback_x, fallback_y). Scene g's episode ends
+   after the rounds r with (r + 1 + g) % episode_rounds == 0. Every per-scene result is bit-identical to `rounds` launches of
+   ur5_grasp_attempt_reset_dev fed with the same rule's actions (tests/test_grasp_rounds.py). reward_dev [rounds][n] int32; action_out_dev
+   [rounds][n][8] doubles or NULL: the records the rule produced (x y z rot 0 box-found - -), for the caller's outcome records. Asynchronous;
+   wavefront-per-scene engine only (40-object piles are aimed from the rendered observation: UR5_ERR_MODEL). */
+typedef struct {
+  int kind, episode_rounds;
+  int64_t first_scene_id, n_total;
+  uint64_t base_seed;
+  double plate_half_x, plate_centre_y, plate_half_y, z_min, z_max, grasp_z, fallback_x, fallback_y;
+} ur5_aim_rule;
+int ur5_grasp_rounds_dev(ur5_sim* h, const ur5_aim_rule* rule, int round0, int rounds, int check_mode, double table_height, int* reward_dev,
+                         double* action_out_dev, double settle_ms);
 /* Dispatch order of the following grasp-attempt / settle launches: order_dev[n] int32 (HIP device pointer) is a permutation of the scene
    ids; the engine starts scenes in that order. The handle COPIES the list (device to device, on its stream, ordered with its launches): the
    caller's buffer may be reused or freed once work queued on that stream so far has run; a caller that filled it on another stream

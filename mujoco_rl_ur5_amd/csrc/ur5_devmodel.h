@@ -72,6 +72,8 @@ enum { UR5_KIND_STATIC = 0, UR5_KIND_ROBOT = 1, UR5_KIND_OBJECT = 2 };
 #define UR5_ST_CAND_OVERFLOW 8                       // more broad-phase survivors than UR5_MAXCAND: pairs were dropped
 #define UR5_ST_CACHE_MISMATCH 16                     // test builds only: the broad phase's pair cache disagreed with the full scan
 
+#include <stdint.h>
+#include <math.h>
 struct Ur5DevModel {
   int nrd, nobj, nv, nq, nu, ngeom, npair, neq, ndg, iterations, ee_cbody, nrg;
   int rd_gslot[UR5_MAXRD], rg_body[UR5_MAXRG];   // contact-accumulator slot of a robot cbody (-1: it has no collision geom) and back
@@ -113,8 +115,6 @@ struct Ur5DevModel {
   double timestep, tolerance, impratio, gravity[3], jnt_solref[2], jnt_solimp[5], meaninertia;
 };
 
-#include <stdint.h>
-#include <math.h>
 #if defined(__HIPCC__)
 #define UR5_HD __host__ __device__
 #else
@@ -182,6 +182,16 @@ struct Ur5Launch {
   const double* qpos0;          // model reference pose [nq] (device), needed with reset_seeds
   int reset_chunks;
   const int* order;             // optional [n] permutation: workgroup slot i simulates scene order[i] (longest-first dispatch, ur5_set_order_dev)
+  // GRASP, several consecutive rounds of a scene in ONE launch (ur5_grasp_rounds_dev; wavefront-per-scene engine): round k of the launch is round rule_r0 + k of the
+  // job. The action of a round is NOT an input: the scene aims by itself, from its own record, with the scripted rule below -- a function of that record only, so a
+  // scene never waits for the other scenes' round to end (example_agent.py:15-27 has no barrier between scenes either: it has one scene). result is [rounds][n].
+  int rounds;                   // 0 / 1: one round with the caller's action records (every other entry point)
+  int rule_kind;                // 0: none; 1: "first candidate box still on the pick plate" (bench.py It1Rounds, rule "aimed")
+  int rule_r0, rule_ep;         // first round of the launch, rounds per episode
+  long long rule_gid0, rule_ntotal;   // global id of scene 0 of this handle, scenes of the whole job (episode seeds: base + gid + ntotal * episode)
+  uint64_t rule_base_seed;
+  double rule_plate[8];         // plate: half width in x, centre y, half width in y, lowest / highest z of an object that counts as "on the plate"; grasp z; fallback x, y
+  double* action_out;           // optional [rounds][n][8]: the action records the rule produced (x y z rot skip box-found - -), for the caller's outcome records
 };
 #ifndef UR5_MANY
 #define UR5_DEBUG_STRIDE 2048

@@ -2834,15 +2834,46 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       static_assert(UR5_MAXCON <= UR5_NT, "one coupled contact per lane");
       constexpr int NW = UR5_NT / 64;
       const int q = UR5_LANE, wv = UR5_LANE >> 6, wl = UR5_LANE & 63;
-      int own = -1;
+      int own = -1, ky = -1;
       unsigned long long rec = 0;
       if (q < S.ncouple) {
         const int c = S.couple[q], A = S.cA[c], B = S.cB[c];
         const int pa = blk_of_body(A), pb = blk_of_body(B);
-        const int ky = pa < pb ? pa * 64 + pb : pb * 64 + pa;
+        ky = pa < pb ? pa * 64 + pb : pb * 64 + pa;
         own = (pa + pb + (pa < pb ? pa : pb)) & (NW - 1);
         rec = (unsigned long long)c | (unsigned long long)A << 8 | (unsigned long long)B << 16 | (unsigned long long)ky << 24 | (unsigned long long)(pa >= pb ? 1 : 0) << 40;
       }
+#ifndef UR5_HASHED_PAIR_OWNERS
+      // Round 5: block pairs are dealt to the wavefronts by LOAD, not by a hash. A wavefront walks its contacts one after the other in every Hessian assembly of the
+      // step (~10), so the busiest wavefront sets the time of the coupling loop; with ~13 coupled contacts hashed into four lists that was 5-6 against a mean of 3.
+      // Greedy, in contact order: the first contact of a pair (its leader) takes the least loaded wavefront for the whole pair (ties: the lowest), weighted with the
+      // pair's contact count. A function of the contact list alone -- no timing enters --, and an entry of H still gets its terms from ONE wavefront in contact order.
+      {
+        static_assert(4 * UR5_MAXCON <= UR5_MAXCAND, "scratch in the (dead) broad-phase candidate list");
+        short* const keys = S.cand, * const lead = S.cand + UR5_MAXCON, * const cntl = S.cand + 2 * UR5_MAXCON, * const ownl = S.cand + 3 * UR5_MAXCON;
+        if (q < S.ncouple) keys[q] = (short)ky;
+        SYNC();
+        if (q < S.ncouple) {
+          int ld = q, cnt = 0;
+          for (int o = S.ncouple - 1; o >= 0; o--) if (keys[o] == ky) { ld = o; cnt++; }
+          lead[q] = (short)ld; cntl[q] = (short)(ld == q ? cnt : 0);
+        }
+        SYNC();
+        if (UR5_LANE == 0) {
+          int load[NW];
+          for (int w = 0; w < NW; w++) load[w] = 0;
+          for (int o = 0; o < S.ncouple; o++) {
+            const int cnt = cntl[o];
+            if (cnt == 0) continue;
+            int best = 0;
+            for (int w = 1; w < NW; w++) if (load[w] < load[best]) best = w;
+            ownl[o] = (short)best; load[best] += cnt;
+          }
+        }
+        SYNC();
+        if (q < S.ncouple) own = ownl[lead[q]];
+      }
+#endif
       int rank = 0;
 #pragma unroll
       for (int w = 0; w < NW; w++) {
@@ -2876,8 +2907,16 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     const int tot = S.env_ptr[M.nv];
     PROF_T0();
     double* const hb = INLDS ? S.henv : S.hess;
-    PAR(idx, tot) hb[idx] = 0;
-    SYNC();
+    // Round 5: only the part of a row LEFT of its diagonal block is zeroed (that is where coupling blocks and fill land); the diagonal blocks are written, never added
+    // to, by the lanes below -- disjoint entries, so the barrier that used to separate the zeroing from them is gone. When the robot carries contacts its block is
+    // ~3 k cycles of work on wavefront 0: the object blocks then go to the other three wavefronts instead of queueing behind it.
+    (void)tot;
+    PAR(i, M.nv) {
+      const int p2 = i < 6 * M.nobj ? i / 6 : M.nobj;
+      const int n = 6 * p2 - S.env_first[i];
+      double* r = hb + S.env_ptr[i];
+      for (int k = 0; k < n; k++) r[k] = 0;
+    }
     PAR(idx, M.nrd * M.nrd) {   // robot block: Mr + sum_b cdof^T G_b cdof + equality / limit rows
       int d = idx / M.nrd, e = idx % M.nrd;
       if (e > d) continue;
@@ -2900,7 +2939,13 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       }
       *hptr<INLDS>(pdof(d), pdof(e)) = (double)v;
     }
+#if !defined(UR5_EMUL) && UR5_NT > 64
+    const bool robot_busy = (S.bodymask & ((1ull << M.nrd) - 1ull)) != 0;    // scene-uniform
+    const int obj_l0 = robot_busy ? 64 : 0;
+    for (int idx = UR5_LANE - obj_l0; idx >= 0 && idx < M.nobj * 21; idx += GS - obj_l0) {     // object blocks: M + T^T G T
+#else
     PAR(idx, M.nobj * 21) {     // object blocks: M + T^T G T
+#endif
       int k = idx / 21, ent = idx % 21, b = M.nrd + k;
       int i = 0;
       while ((i + 1) * (i + 2) / 2 <= ent) i++;
@@ -3068,11 +3113,25 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     }
   }
   // uncoupled blocks: every row factors its own diagonal block (redundantly per row); row 0 of the block files it in dcache
-  template <bool INLDS, int W> UR5_FN void factor_single_row(int i, int p2) {
+  // kind 0: the head of a chain (its factor goes to the block cache for the panel rows below it); kind 1: an uncoupled block; kind 2: a terminal block.
+  // Round 5: kinds 1 and 2 finish their part of the solve that follows every factorisation right here -- the lane has the block's factor in registers and the block's
+  // right-hand side is final (uncoupled: always; terminal: after the last level), so x_blk = L^-T L^-1 b_blk costs it two 6 x 6 substitutions instead of a store to the
+  // block cache, a barrier and a reload in envelope_solve. Same operands, same order as solve_single_row / terminal_fwd_bwd: same bits. (An envelope in global memory
+  // may be reused by a later iteration, so that path still files the factor.)
+  template <bool INLDS, int W> UR5_FN void factor_single_row(int i, int p2, int kind, const real* b, real* y) {
     const int c0 = 6 * p2, r = i - c0;
     Diag<W> d;
     diag_factor<INLDS, W>(c0, d);
-    if (r == 0) diag_store<W>(p2, d);
+    if (r == 0 && (kind == 0 || !INLDS)) diag_store<W>(p2, d);
+    if (kind == 0) return;
+    real t[W];
+#pragma unroll
+    for (int k = 0; k < W; k++) t[k] = b[c0 + k];
+    fwd_blk<W>(d, t);
+    bwd_blk<W>(d, t);
+    const real xi = pick<W>(t, r);
+    S.search[edof(i)] = -xi;
+    if (kind == 2) y[i] = xi;   // x of the block, for the update of the columns to its left
   }
   // The forward substitution of the solve that follows every factorisation rides along (b, y as in envelope_solve): the lane that has just computed row i's entries
   // of block column p2 has the block's factor in registers, so y_blk = L_pp^-1 b_blk and b_i -= L_i,blk y_blk cost it a handful of multiply-adds instead of
@@ -3200,7 +3259,8 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     PAR(i, M.nv) {
       const int p2 = i < 6 * M.nobj ? i / 6 : M.nobj;
       if (S.blk_first[p2] != p2) continue;
-      if (p2 < M.nobj) factor_single_row<INLDS, 6>(i, p2); else factor_single_row<INLDS, UR5_MAXRD>(i, p2);
+      const int kind = S.blk_last[p2] == p2 ? 1 : 0;
+      if (p2 < M.nobj) factor_single_row<INLDS, 6>(i, p2, kind, S.Mv_(), S.tmpv); else factor_single_row<INLDS, UR5_MAXRD>(i, p2, kind, S.Mv_(), S.tmpv);
     }
     SYNC();
     PROFL(PF_X1);
@@ -3230,10 +3290,10 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
 #endif
       }
     }
-    PAR(i, M.nv) {   // terminal blocks: every trailing update has landed
+    PAR(i, M.nv) {   // terminal blocks: every trailing update has landed, and so has every forward substitution into their right-hand side
       const int p2 = i < 6 * M.nobj ? i / 6 : M.nobj;
       if (!blk_terminal(p2)) continue;
-      if (p2 < M.nobj) factor_single_row<INLDS, 6>(i, p2); else factor_single_row<INLDS, UR5_MAXRD>(i, p2);
+      if (p2 < M.nobj) factor_single_row<INLDS, 6>(i, p2, 2, S.Mv_(), S.tmpv); else factor_single_row<INLDS, UR5_MAXRD>(i, p2, 2, S.Mv_(), S.tmpv);
     }
     PROFL(PF_X4);
   }
@@ -3298,8 +3358,9 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
     real* b = S.Mv_();
     real* y = S.tmpv;
     PROFL_T0();
-    SYNC();   // dcache of the uncoupled blocks
-    PAR(i, M.nv) {   // uncoupled blocks: the whole solve at once
+    SYNC();   // the terminal blocks' x (left in y by the factorisation); for a reused factor: nothing in flight
+    if (!forward_done)
+    PAR(i, M.nv) {   // uncoupled blocks: the whole solve at once (a fresh factorisation has done it, factor_single_row)
       const int p2 = i < 6 * M.nobj ? i / 6 : M.nobj;
       if (!blk_single(p2)) continue;
       if (p2 < M.nobj) solve_single_row<6>(i, p2, b); else solve_single_row<UR5_MAXRD>(i, p2, b);
@@ -3321,12 +3382,14 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       }
     }
     PROFL(PF_X5);
-    PAR(t, M.nv) {   // terminal blocks: forward and backward substitution inside the block, then their share of y to the left
-      const int p2 = t < 6 * M.nobj ? t / 6 : M.nobj;
-      if (!blk_terminal(p2)) continue;
-      if (p2 < M.nobj) terminal_fwd_bwd<6>(t, p2, b, y); else terminal_fwd_bwd<UR5_MAXRD>(t, p2, b, y);
+    if (!forward_done) {
+      PAR(t, M.nv) {   // terminal blocks: forward and backward substitution inside the block, then their share of y to the left
+        const int p2 = t < 6 * M.nobj ? t / 6 : M.nobj;
+        if (!blk_terminal(p2)) continue;
+        if (p2 < M.nobj) terminal_fwd_bwd<6>(t, p2, b, y); else terminal_fwd_bwd<UR5_MAXRD>(t, p2, b, y);
+      }
+      SYNC();
     }
-    SYNC();
     PAR(j, M.nv) {   // y_j -= L_blk,j^T x_blk for the columns j left of a terminal block (x_blk was left in y)
       const int pj = j < 6 * M.nobj ? j / 6 : M.nobj;
       for (int o = S.reach_ptr[pj]; o < S.reach_ptr[pj + 1]; o++) {   // the blocks whose rows reach column block pj
@@ -3826,134 +3889,202 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
   UR5_FN void write_kp0(real v) { SYNC(); if (UR5_LANE == 0) kp()[0] = v; SYNC(); }
   UR5_FN int stay_chunks_for(real ms) const { return (int)ceil(ms / (real)1000 / (real)M.timestep / (real)10 - (real)1e-9); }  // :621-636, H2
 
-  // One scene per wavefront (GS = 64): the script as nested loops -- its registers are wave-uniform (SGPRs) and are not live across step().
-  UR5_FN void run_nested(const Ur5Launch& P, int env) {
-    const int op = P.op;
+  // The scripted aiming rule of a multi-round launch (Ur5Launch::rule_*; bench.py It1Rounds.actions, rule "aimed"): in round r scene g tries the boxes
+  // (g + (g + r) % ep + i) % nobj, i = 0.., and aims at the first one that still lies on the pick plate, z = the fixed grasp height, wrist rotation (g / ep + r) % 6;
+  // an empty plate gets an attempt at the fallback point. Reads the scene's own record only. Also the seed of the episode the scene starts after the round (0: none).
+  struct Aim { v3 xyz; int rotation; bool found; unsigned long long seed; };
+  UR5_FN Aim aim_rule(const Ur5Launch& P, int env, int round) const {
+    Aim a;
+    const long long g = P.rule_gid0 + env;
+    const int r = P.rule_r0 + round, ep = P.rule_ep;
+    const int j = (int)((g + r) % ep);
+    real x = (real)P.rule_plate[6], y = (real)P.rule_plate[7];
+    a.found = false;
+    for (int i = 0; i < M.nobj && !a.found; i++) {
+      const int k = (int)((g + j + i) % M.nobj);
+      const real* q = S.rec + UR5_REC_QPOS + M.nrd + 7 * k;
+      const real px = M.obj_kind[k] == 0 ? q[0] + (real)M.obj_pos0[k][0] : q[0], py = M.obj_kind[k] == 0 ? q[1] + (real)M.obj_pos0[k][1] : q[1],
+                 pz = M.obj_kind[k] == 0 ? q[2] + (real)M.obj_pos0[k][2] : q[2];
+      if (fabs(px) <= (real)P.rule_plate[0] && fabs(py - (real)P.rule_plate[1]) <= (real)P.rule_plate[2] && pz >= (real)P.rule_plate[3] && pz <= (real)P.rule_plate[4]) { x = px; y = py; a.found = true; }
+    }
+    a.xyz = v3(x, y, (real)P.rule_plate[5]);
+    a.rotation = (int)((g / ep + r) % 6);
+    const long long kk = g + r + 1;
+    a.seed = kk % ep == 0 ? P.rule_base_seed + (unsigned long long)g + (unsigned long long)P.rule_ntotal * (unsigned long long)(kk / ep) : 0ull;
+    return a;
+  }
+  // ------------------------------------------------------------------ the scripts (one text for both interpreters below)
+  // State of a scene's script: program counter, the last primitive's outcome, and the grasp script's registers (GraspingEnv.py:205-386; mirrors oracle
+  // Sim::grasp_attempt). Wave-uniform: in the wavefront-per-scene kernel it lives in SGPRs.
+  struct Script {
     int pc = 0, result = RES_NONE, last_res = RES_NONE, last_n = 0;
-    // grasp-script registers (GraspingEnv.py:205-386; mirrors oracle Sim::grasp_attempt)
     v3 coord;
     int rotation = 0, result1 = RES_NONE, result_final = RES_NONE;
     bool result_grasp = false, grasped = false;
-    if (op == UR5_OP_GRASP || op == UR5_OP_MOVE_EE || op == UR5_OP_IK) coord = v3((real)P.target[8 * env], (real)P.target[8 * env + 1], (real)P.target[8 * env + 2]);
-    if (op == UR5_OP_GRASP) {
-      rotation = (int)P.target[8 * env + 3];
-      if (UR5_LANE == 0) for (int i = 0; i < 12; i++) { if (P.phase_steps) P.phase_steps[12 * env + i] = 0; if (P.phase_result) P.phase_result[12 * env + i] = -1; }
+    // several rounds of the scene in one launch (Ur5Launch::rounds): the round in flight, whether it skips, the seed of the episode that starts after it
+    int round = 0;
+    bool skip_round = false;
+    unsigned long long round_seed = 0;
+  };
+  UR5_FN static bool ruled(const Ur5Launch& P) { return P.op == UR5_OP_GRASP && P.rule_kind != 0; }
+  UR5_FN void record(const Ur5Launch& P, int env, int slot, int res, int n) {
+    if (UR5_LANE == 0) { if (P.phase_steps) P.phase_steps[12 * env + slot] = n; if (P.phase_result) P.phase_result[12 * env + slot] = res; }
+  }
+  // start of a grasp round: what save() + load() + the caller's action record do between two launches of the lock-step shape
+  UR5_FN void begin_round(const Ur5Launch& P, int env, Script& sc) {
+    SYNC();
+    if (ruled(P)) {
+      const Aim a = aim_rule(P, env, sc.round);
+      sc.coord = a.xyz; sc.rotation = a.rotation; sc.skip_round = false; sc.round_seed = a.seed;
+      if (UR5_LANE == 0 && P.action_out) {
+        double* o = P.action_out + ((size_t)sc.round * P.n_env + env) * 8;
+        o[0] = (double)a.xyz.x; o[1] = (double)a.xyz.y; o[2] = (double)a.xyz.z; o[3] = (double)a.rotation; o[4] = 0; o[5] = a.found ? 1.0 : 0.0; o[6] = 0; o[7] = 0;
+      }
+    } else {
+      sc.coord = v3((real)P.target[8 * env], (real)P.target[8 * env + 1], (real)P.target[8 * env + 2]);
+      sc.rotation = (int)P.target[8 * env + 3]; sc.skip_round = P.target[8 * env + 4] != 0;
+      sc.round_seed = P.reset_seeds ? P.reset_seeds[env] : 0ull;
     }
-    auto record = [&](int slot, int res, int n) {
-      if (UR5_LANE == 0) { if (P.phase_steps) P.phase_steps[12 * env + slot] = n; if (P.phase_result) P.phase_result[12 * env + slot] = res; }
-    };
+    sc.result1 = RES_NONE; sc.result_final = RES_NONE; sc.result_grasp = false; sc.grasped = false;
+    if (UR5_LANE == 0) for (int i = 0; i < 12; i++) { if (P.phase_steps) P.phase_steps[12 * env + i] = 0; if (P.phase_result) P.phase_result[12 * env + i] = -1; }
+    if (sc.round > 0) { if (UR5_LANE == 0) { S.last_steps = 0; S.ncon = 0; S.nsr = 0; invalidate_pair_cache(); } SYNC(); }   // load()'s fresh per-launch fields
+  }
+  UR5_FN void begin_script(const Ur5Launch& P, int env, Script& sc) {
+    if (P.op == UR5_OP_MOVE_EE || P.op == UR5_OP_IK) sc.coord = v3((real)P.target[8 * env], (real)P.target[8 * env + 1], (real)P.target[8 * env + 2]);
+    if (P.op == UR5_OP_GRASP) begin_round(P, env, sc);
+  }
+  // script logic: consume the previous primitive's result (sc.last_res / sc.last_n), choose the next primitive (pr; pr.done: the script is over, sc.result is its
+  // result) and the phase slot it reports into. Every operation of the C ABI is a short script over ONE blocking primitive.
+  UR5_FN void choose(const Ur5Launch& P, int env, Script& sc, Prim& pr, int& slot) {
+    const int op = P.op;
+    int& pc = sc.pc; int& result = sc.result; const int last_res = sc.last_res, last_n = sc.last_n;
+    v3& coord = sc.coord; int& rotation = sc.rotation; int& result1 = sc.result1; int& result_final = sc.result_final;
+    bool& result_grasp = sc.result_grasp; bool& grasped = sc.grasped;
+    const int nrounds = ruled(P) && P.rounds > 1 ? P.rounds : 1;
+    (void)rotation; (void)last_n;
+    if (op == UR5_OP_MOVE) {
+      if (pc == 0) {
+        pr.mask = P.group_mask[env];
+        SYNC();
+        if (UR5_LANE == 0 && P.target) {
+          int k = 0;
+          for (int a = 0; a < M.nu; a++) if (pr.mask >> a & 1u) { double t = P.target[8 * env + k++]; if (t == t) target()[a] = (real)t; }
+        }
+        SYNC();
+        pr.tol = (real)P.tol[env]; pr.max_steps = P.max_steps[env];
+      } else { result = last_res; pr.done = true; }
+    } else if (op == UR5_OP_STAY) {
+      if (pc == 0) { pr.mask = mask_all(); pr.tol = (real)1e-7; pr.max_steps = 10; pr.repeat = P.max_steps[env]; }
+      else { result = RES_SUCCESS; pr.done = true; }
+    } else if (op == UR5_OP_MOVE_EE) {
+      if (pc == 0) { pr.need_ik = true; pr.xyz = coord; pr.mask = 0x1fu; pr.tol = (real)P.tol[env]; pr.max_steps = P.max_steps[env]; }
+      else { result = last_res; pr.done = true; }
+    } else if (op == UR5_OP_GRASP) {
+      const real table_height = (real)P.table_height;
+      bool chosen = false;
+      while (!chosen) {
+        chosen = true;
+        switch (pc) {
+          case 0:   // GraspEnv.step's skip rule (GraspingEnv.py:124-131): the caller flags targets it must not act on
+            if (sc.skip_round) { result = 0; pr.done = true; break; }
+            // :212 move above the target
+            pr.need_ik = true; pr.xyz = v3(coord.x, coord.y, (real)1.1); pr.mask = 0x1fu; pr.tol = (real)0.05; pr.max_steps = 1000; slot = 0; break;
+          case 1:   // :227-239 centre fallback when the IK failed
+            result1 = last_res;
+            if (result1 == RES_IK_FAIL) { pr.need_ik = true; pr.xyz = v3(0, (real)-0.6, (real)1.1); pr.mask = 0x1fu; pr.tol = (real)0.05; pr.max_steps = 1000; slot = 0; }
+            else { pc = 3; chosen = false; }
+            break;
+          case 2: result1 = last_res; pc = 3; chosen = false; break;
+          case 3:   // :242 stuck -> skip the grasp; else :252 rotate the wrist
+            if (result1 == RES_MAX_STEPS) { pc = 9; chosen = false; break; }
+            {
+              const real rot_deg[6] = {0, 30, 60, 90, -30, -60};
+              real deg = rotation == 0 ? rot_deg[0] : rotation == 1 ? rot_deg[1] : rotation == 2 ? rot_deg[2] : rotation == 3 ? rot_deg[3] : rotation == 4 ? rot_deg[4] : rot_deg[5];
+              write_target(5, deg * (real)3.14159265358979323846 / (real)180);
+            }
+            pr.mask = mask_all(); pr.tol = (real)0.05; pr.max_steps = 500; slot = 1; break;
+          case 4:   // :255 open_gripper(half=True)
+            write_target(6, (real)0); pr.mask = 1u << 6; pr.tol = (real)0.05; pr.max_steps = 1000; slot = 2; break;
+          case 5:   // :258-269 descend
+            pr.need_ik = true; pr.xyz = v3(coord.x, coord.y, maxv(table_height, coord.z - (real)0.01)); pr.mask = 0x1fu; pr.tol = (real)0.01; pr.max_steps = 300; slot = 3; break;
+          case 6:   // :272-277 could not reach -> no grasp; else stay(100)
+            if (last_res == RES_MAX_STEPS) { pc = 9; chosen = false; break; }
+            pr.mask = mask_all(); pr.tol = (real)1e-7; pr.max_steps = 10; pr.repeat = stay_chunks_for(100); break;
+          case 7:   // :278 grasp() = close_gripper(max_steps=300)
+            write_target(6, (real)-0.4); pr.mask = 1u << 6; pr.tol = (real)0.01; pr.max_steps = 300; break;
+          case 8:
+            result_grasp = last_res != RES_SUCCESS;
+            record(P, env, 5, result_grasp ? RES_MAX_STEPS : RES_SUCCESS, last_n);
+            pc = 9; chosen = false; break;
+          case 9:   // :282
+            write_kp0(10);
+            if (P.check_mode == 1) { pr.need_ik = true; pr.xyz = v3(coord.x, coord.y, (real)1.1); pr.mask = 0x1fu; pr.tol = (real)0.05; pr.max_steps = 1000; slot = 6; }
+            else { pc = 12; chosen = false; }
+            break;
+          case 10:  // IT1 (README.md:20): 500-step closing check right after lifting
+            if (result_grasp) { write_target(6, (real)-0.4); pr.mask = 1u << 6; pr.tol = (real)0.01; pr.max_steps = 500; slot = 9; }
+            else { pc = 12; chosen = false; }
+            break;
+          case 11: result_final = last_res; pc = 12; chosen = false; break;
+          case 12:  // :285 back above the table centre
+            pr.need_ik = true; pr.xyz = v3(0, (real)-0.6, (real)1.1); pr.mask = 0x1fu; pr.tol = (real)0.05; pr.max_steps = 1000; slot = 7; break;
+          case 13:  // :297 to the drop position
+            pr.need_ik = true; pr.xyz = v3((real)0.6, 0, (real)1.15); pr.mask = 0x1fu; pr.tol = (real)0.01; pr.max_steps = 1200; slot = 8; break;
+          case 14:  // :312-321 closing check at the drop position
+            if (P.check_mode != 1 && result_grasp) { write_target(6, (real)-0.4); pr.mask = 1u << 6; pr.tol = (real)0.01; pr.max_steps = P.check_mode == 2 ? 100 : 1000; slot = 9; }   // check_mode 2 = demo_mode (:318-321)
+            else { pc = 16; chosen = false; }
+            break;
+          case 15: result_final = last_res; pc = 16; chosen = false; break;
+          case 16:  // :327, :338 open the gripper
+            grasped = (result_final == RES_MAX_STEPS) && result_grasp;
+            write_target(6, (real)0.4); pr.mask = 1u << 6; pr.tol = (real)0.05; pr.max_steps = 1000; slot = 10; break;
+          case 17:  // :341-342
+            if (grasped) { pr.mask = mask_all(); pr.tol = (real)1e-7; pr.max_steps = 10; pr.repeat = stay_chunks_for(200); }
+            else { pc = 18; chosen = false; }
+            break;
+          case 18:  // :345 rotate back
+            write_target(5, (real)0); pr.mask = mask_all(); pr.tol = (real)0.05; pr.max_steps = 500; slot = 11; break;
+          case 19:  // :347; then, for a scene whose episode ends here, GraspEnv.reset_model (GraspingEnv.py:409-477) inside the same launch
+            write_kp0(20);
+            result = grasped ? 1 : 0;
+            if (sc.round_seed != 0) {
+              SYNC();
+              if (UR5_LANE == 0) { const real ended = (real)((int)S.rec[UR5_REC_MISC + 7] | S.status); ur5_reset_record(M, P.qpos0, S.rec, sc.round_seed); S.rec[UR5_REC_MISC + 7] = ended; S.status = 0; invalidate_pair_cache(); }   // the attempt's status bits stay readable (counters: bits 8-15) after the episode reset that follows it in this launch
+              SYNC();
+              pr.mask = mask_all(); pr.tol = (real)1e-7; pr.max_steps = 10; pr.repeat = P.reset_chunks;   // :473 stay(1000)
+              if (pr.repeat <= 0) { pc = 20; chosen = false; }
+            } else { pc = 20; chosen = false; }
+            break;
+          case 20:  // the round is over: its reward; the scene's next round of this launch starts at once, whatever the other scenes are doing
+            if (UR5_LANE == 0 && P.result) P.result[(size_t)sc.round * P.n_env + env] = result;
+            sc.round++;
+            if (sc.round < nrounds) { begin_round(P, env, sc); pc = 0; chosen = false; } else pr.done = true;
+            break;
+          default: pr.done = true; break;
+        }
+      }
+    } else if (op == UR5_OP_STEP) {
+      if (pc == 0) { pr.mask = 0; pr.tol = (real)-1; pr.max_steps = P.max_steps[env]; pr.repeat = -1; }   // repeat < 0: raw sim.step() x max_steps
+      else { result = RES_SUCCESS; pr.done = true; }
+    } else if (op == UR5_OP_IK) {
+      if (pc == 0) { pr.need_ik = true; pr.xyz = coord; pr.repeat = 0; }
+      else { result = last_res; pr.done = true; }
+    } else {  // UR5_OP_FORWARD
+      if (pc == 0) pr.repeat = -2; else { result = RES_SUCCESS; pr.done = true; }
+    }
+  }
+  // One scene per wavefront (GS = 64): the script as nested loops -- its registers are wave-uniform (SGPRs) and are not live across step().
+  UR5_FN void run_nested(const Ur5Launch& P, int env) {
+    const int op = P.op;
+    Script sc;
+    begin_script(P, env, sc);
     for (;;) {
       Prim pr;
       pr.done = false; pr.need_ik = false; pr.repeat = 1; pr.mask = 0; pr.tol = 0; pr.max_steps = 0;
       int slot = -1;       // phase slot the primitive reports into (grasp script)
-      // ---------------- script logic: consume the previous result, choose the next primitive
-      if (op == UR5_OP_MOVE) {
-        if (pc == 0) {
-          pr.mask = P.group_mask[env];
-          SYNC();
-          if (UR5_LANE == 0 && P.target) {
-            int k = 0;
-            for (int a = 0; a < M.nu; a++) if (pr.mask >> a & 1u) { double t = P.target[8 * env + k++]; if (t == t) target()[a] = (real)t; }
-          }
-          SYNC();
-          pr.tol = (real)P.tol[env]; pr.max_steps = P.max_steps[env];
-        } else { result = last_res; pr.done = true; }
-      } else if (op == UR5_OP_STAY) {
-        if (pc == 0) { pr.mask = mask_all(); pr.tol = (real)1e-7; pr.max_steps = 10; pr.repeat = P.max_steps[env]; }
-        else { result = RES_SUCCESS; pr.done = true; }
-      } else if (op == UR5_OP_MOVE_EE) {
-        if (pc == 0) { pr.need_ik = true; pr.xyz = coord; pr.mask = 0x1fu; pr.tol = (real)P.tol[env]; pr.max_steps = P.max_steps[env]; }
-        else { result = last_res; pr.done = true; }
-      } else if (op == UR5_OP_GRASP) {
-        const real table_height = (real)P.table_height;
-        bool chosen = false;
-        while (!chosen) {
-          chosen = true;
-          switch (pc) {
-            case 0:   // GraspEnv.step's skip rule (GraspingEnv.py:124-131): the caller flags targets it must not act on
-              if (P.target[8 * env + 4] != 0) { result = 0; pr.done = true; break; }
-              // :212 move above the target
-              pr.need_ik = true; pr.xyz = v3(coord.x, coord.y, (real)1.1); pr.mask = 0x1fu; pr.tol = (real)0.05; pr.max_steps = 1000; slot = 0; break;
-            case 1:   // :227-239 centre fallback when the IK failed
-              result1 = last_res;
-              if (result1 == RES_IK_FAIL) { pr.need_ik = true; pr.xyz = v3(0, (real)-0.6, (real)1.1); pr.mask = 0x1fu; pr.tol = (real)0.05; pr.max_steps = 1000; slot = 0; }
-              else { pc = 3; chosen = false; }
-              break;
-            case 2: result1 = last_res; pc = 3; chosen = false; break;
-            case 3:   // :242 stuck -> skip the grasp; else :252 rotate the wrist
-              if (result1 == RES_MAX_STEPS) { pc = 9; chosen = false; break; }
-              {
-                const real rot_deg[6] = {0, 30, 60, 90, -30, -60};
-                real deg = rotation == 0 ? rot_deg[0] : rotation == 1 ? rot_deg[1] : rotation == 2 ? rot_deg[2] : rotation == 3 ? rot_deg[3] : rotation == 4 ? rot_deg[4] : rot_deg[5];
-                write_target(5, deg * (real)3.14159265358979323846 / (real)180);
-              }
-              pr.mask = mask_all(); pr.tol = (real)0.05; pr.max_steps = 500; slot = 1; break;
-            case 4:   // :255 open_gripper(half=True)
-              write_target(6, (real)0); pr.mask = 1u << 6; pr.tol = (real)0.05; pr.max_steps = 1000; slot = 2; break;
-            case 5:   // :258-269 descend
-              pr.need_ik = true; pr.xyz = v3(coord.x, coord.y, maxv(table_height, coord.z - (real)0.01)); pr.mask = 0x1fu; pr.tol = (real)0.01; pr.max_steps = 300; slot = 3; break;
-            case 6:   // :272-277 could not reach -> no grasp; else stay(100)
-              if (last_res == RES_MAX_STEPS) { pc = 9; chosen = false; break; }
-              pr.mask = mask_all(); pr.tol = (real)1e-7; pr.max_steps = 10; pr.repeat = stay_chunks_for(100); break;
-            case 7:   // :278 grasp() = close_gripper(max_steps=300)
-              write_target(6, (real)-0.4); pr.mask = 1u << 6; pr.tol = (real)0.01; pr.max_steps = 300; break;
-            case 8:
-              result_grasp = last_res != RES_SUCCESS;
-              record(5, result_grasp ? RES_MAX_STEPS : RES_SUCCESS, last_n);
-              pc = 9; chosen = false; break;
-            case 9:   // :282
-              write_kp0(10);
-              if (P.check_mode == 1) { pr.need_ik = true; pr.xyz = v3(coord.x, coord.y, (real)1.1); pr.mask = 0x1fu; pr.tol = (real)0.05; pr.max_steps = 1000; slot = 6; }
-              else { pc = 12; chosen = false; }
-              break;
-            case 10:  // IT1 (README.md:20): 500-step closing check right after lifting
-              if (result_grasp) { write_target(6, (real)-0.4); pr.mask = 1u << 6; pr.tol = (real)0.01; pr.max_steps = 500; slot = 9; }
-              else { pc = 12; chosen = false; }
-              break;
-            case 11: result_final = last_res; pc = 12; chosen = false; break;
-            case 12:  // :285 back above the table centre
-              pr.need_ik = true; pr.xyz = v3(0, (real)-0.6, (real)1.1); pr.mask = 0x1fu; pr.tol = (real)0.05; pr.max_steps = 1000; slot = 7; break;
-            case 13:  // :297 to the drop position
-              pr.need_ik = true; pr.xyz = v3((real)0.6, 0, (real)1.15); pr.mask = 0x1fu; pr.tol = (real)0.01; pr.max_steps = 1200; slot = 8; break;
-            case 14:  // :312-321 closing check at the drop position
-              if (P.check_mode != 1 && result_grasp) { write_target(6, (real)-0.4); pr.mask = 1u << 6; pr.tol = (real)0.01; pr.max_steps = P.check_mode == 2 ? 100 : 1000; slot = 9; }   // check_mode 2 = demo_mode (:318-321)
-              else { pc = 16; chosen = false; }
-              break;
-            case 15: result_final = last_res; pc = 16; chosen = false; break;
-            case 16:  // :327, :338 open the gripper
-              grasped = (result_final == RES_MAX_STEPS) && result_grasp;
-              write_target(6, (real)0.4); pr.mask = 1u << 6; pr.tol = (real)0.05; pr.max_steps = 1000; slot = 10; break;
-            case 17:  // :341-342
-              if (grasped) { pr.mask = mask_all(); pr.tol = (real)1e-7; pr.max_steps = 10; pr.repeat = stay_chunks_for(200); }
-              else { pc = 18; chosen = false; }
-              break;
-            case 18:  // :345 rotate back
-              write_target(5, (real)0); pr.mask = mask_all(); pr.tol = (real)0.05; pr.max_steps = 500; slot = 11; break;
-            case 19:  // :347; then, for a scene whose episode ends here, GraspEnv.reset_model (GraspingEnv.py:409-477) inside the same launch
-              write_kp0(20);
-              result = grasped ? 1 : 0;
-              if (P.reset_seeds && P.reset_seeds[env] != 0) {
-                SYNC();
-                if (UR5_LANE == 0) { const real ended = (real)((int)S.rec[UR5_REC_MISC + 7] | S.status); ur5_reset_record(M, P.qpos0, S.rec, P.reset_seeds[env]); S.rec[UR5_REC_MISC + 7] = ended; S.status = 0; invalidate_pair_cache(); }   // the attempt's status bits stay readable (counters: bits 8-15) after the episode reset that follows it in this launch
-                SYNC();
-                pr.mask = mask_all(); pr.tol = (real)1e-7; pr.max_steps = 10; pr.repeat = P.reset_chunks;   // :473 stay(1000)
-                if (pr.repeat <= 0) pr.done = true;
-              } else pr.done = true;
-              break;
-            default: pr.done = true; break;
-          }
-        }
-      } else if (op == UR5_OP_STEP) {
-        if (pc == 0) { pr.mask = 0; pr.tol = (real)-1; pr.max_steps = P.max_steps[env]; pr.repeat = -1; }   // repeat < 0: raw sim.step() x max_steps
-        else { result = RES_SUCCESS; pr.done = true; }
-      } else if (op == UR5_OP_IK) {
-        if (pc == 0) { pr.need_ik = true; pr.xyz = coord; pr.repeat = 0; }
-        else { result = last_res; pr.done = true; }
-      } else {  // UR5_OP_FORWARD
-        if (pc == 0) pr.repeat = -2; else { result = RES_SUCCESS; pr.done = true; }
-      }
+      choose(P, env, sc, pr, slot);
       if (pr.done) break;
-      pc++;
+      sc.pc++;
       // ---------------- the primitive
       int res = RES_NONE, steps = 0;
       bool ikfail = false;
@@ -3994,11 +4125,11 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       SYNC();
       if (UR5_LANE == 0) S.last_steps = steps;
       SYNC();
-      last_res = res; last_n = steps;
-      if (slot >= 0) record(slot, res, steps);
+      sc.last_res = res; sc.last_n = steps;
+      if (slot >= 0) record(P, env, slot, res, steps);
     }
     if (UR5_LANE == 0) {
-      if (P.result) P.result[env] = result;
+      if (P.result && !ruled(P)) P.result[env] = sc.result;   // (a ruled launch has filed every round's reward in its [rounds][n] array)
       if (P.steps) P.steps[env] = S.last_steps;
     }
   }
@@ -4018,19 +4149,8 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
   }
   UR5_FN void run_flat(const Ur5Launch& P, int env, bool live) {
     const int op = P.op;
-    int pc = 0, result = RES_NONE, last_res = RES_NONE, last_n = 0;
-    // grasp-script registers (GraspingEnv.py:205-386; mirrors oracle Sim::grasp_attempt)
-    v3 coord;
-    int rotation = 0, result1 = RES_NONE, result_final = RES_NONE;
-    bool result_grasp = false, grasped = false;
-    if (live && (op == UR5_OP_GRASP || op == UR5_OP_MOVE_EE || op == UR5_OP_IK)) coord = v3((real)P.target[8 * env], (real)P.target[8 * env + 1], (real)P.target[8 * env + 2]);
-    if (live && op == UR5_OP_GRASP) {
-      rotation = (int)P.target[8 * env + 3];
-      if (UR5_LANE == 0) for (int i = 0; i < 12; i++) { if (P.phase_steps) P.phase_steps[12 * env + i] = 0; if (P.phase_result) P.phase_result[12 * env + i] = -1; }
-    }
-    auto record = [&](int slot, int res, int n) {
-      if (UR5_LANE == 0) { if (P.phase_steps) P.phase_steps[12 * env + slot] = n; if (P.phase_result) P.phase_result[12 * env + slot] = res; }
-    };
+    Script sc;
+    if (live) begin_script(P, env, sc);
     // the primitive in flight
     Prim pr;
     pr.done = false; pr.need_ik = false; pr.repeat = 1; pr.mask = 0; pr.tol = 0; pr.max_steps = 0;
@@ -4042,8 +4162,8 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       SYNC();
       if (UR5_LANE == 0) S.last_steps = steps;
       SYNC();
-      last_res = res; last_n = steps;
-      if (slot >= 0) record(slot, res, steps);
+      sc.last_res = res; sc.last_n = steps;
+      if (slot >= 0) record(P, env, slot, res, steps);
       need_new = true;
     };
     // one repetition of the move loop ended (converged, or out of steps): start the next one (stay: chunks of 10 steps) or finish
@@ -4058,114 +4178,9 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
         if (need_new) {
           pr.done = false; pr.need_ik = false; pr.repeat = 1; pr.mask = 0; pr.tol = 0; pr.max_steps = 0;
           slot = -1;
-          // ---------------- script logic: consume the previous result, choose the next primitive
-          if (op == UR5_OP_MOVE) {
-            if (pc == 0) {
-              pr.mask = P.group_mask[env];
-              SYNC();
-              if (UR5_LANE == 0 && P.target) {
-                int k = 0;
-                for (int a = 0; a < M.nu; a++) if (pr.mask >> a & 1u) { double t = P.target[8 * env + k++]; if (t == t) target()[a] = (real)t; }
-              }
-              SYNC();
-              pr.tol = (real)P.tol[env]; pr.max_steps = P.max_steps[env];
-            } else { result = last_res; pr.done = true; }
-          } else if (op == UR5_OP_STAY) {
-            if (pc == 0) { pr.mask = mask_all(); pr.tol = (real)1e-7; pr.max_steps = 10; pr.repeat = P.max_steps[env]; }
-            else { result = RES_SUCCESS; pr.done = true; }
-          } else if (op == UR5_OP_MOVE_EE) {
-            if (pc == 0) { pr.need_ik = true; pr.xyz = coord; pr.mask = 0x1fu; pr.tol = (real)P.tol[env]; pr.max_steps = P.max_steps[env]; }
-            else { result = last_res; pr.done = true; }
-          } else if (op == UR5_OP_GRASP) {
-            const real table_height = (real)P.table_height;
-            bool chosen = false;
-            while (!chosen) {
-              chosen = true;
-              switch (pc) {
-                case 0:   // GraspEnv.step's skip rule (GraspingEnv.py:124-131): the caller flags targets it must not act on
-                  if (P.target[8 * env + 4] != 0) { result = 0; pr.done = true; break; }
-                  // :212 move above the target
-                  pr.need_ik = true; pr.xyz = v3(coord.x, coord.y, (real)1.1); pr.mask = 0x1fu; pr.tol = (real)0.05; pr.max_steps = 1000; slot = 0; break;
-                case 1:   // :227-239 centre fallback when the IK failed
-                  result1 = last_res;
-                  if (result1 == RES_IK_FAIL) { pr.need_ik = true; pr.xyz = v3(0, (real)-0.6, (real)1.1); pr.mask = 0x1fu; pr.tol = (real)0.05; pr.max_steps = 1000; slot = 0; }
-                  else { pc = 3; chosen = false; }
-                  break;
-                case 2: result1 = last_res; pc = 3; chosen = false; break;
-                case 3:   // :242 stuck -> skip the grasp; else :252 rotate the wrist
-                  if (result1 == RES_MAX_STEPS) { pc = 9; chosen = false; break; }
-                  {
-                    const real rot_deg[6] = {0, 30, 60, 90, -30, -60};
-                    real deg = rotation == 0 ? rot_deg[0] : rotation == 1 ? rot_deg[1] : rotation == 2 ? rot_deg[2] : rotation == 3 ? rot_deg[3] : rotation == 4 ? rot_deg[4] : rot_deg[5];
-                    write_target(5, deg * (real)3.14159265358979323846 / (real)180);
-                  }
-                  pr.mask = mask_all(); pr.tol = (real)0.05; pr.max_steps = 500; slot = 1; break;
-                case 4:   // :255 open_gripper(half=True)
-                  write_target(6, (real)0); pr.mask = 1u << 6; pr.tol = (real)0.05; pr.max_steps = 1000; slot = 2; break;
-                case 5:   // :258-269 descend
-                  pr.need_ik = true; pr.xyz = v3(coord.x, coord.y, maxv(table_height, coord.z - (real)0.01)); pr.mask = 0x1fu; pr.tol = (real)0.01; pr.max_steps = 300; slot = 3; break;
-                case 6:   // :272-277 could not reach -> no grasp; else stay(100)
-                  if (last_res == RES_MAX_STEPS) { pc = 9; chosen = false; break; }
-                  pr.mask = mask_all(); pr.tol = (real)1e-7; pr.max_steps = 10; pr.repeat = stay_chunks_for(100); break;
-                case 7:   // :278 grasp() = close_gripper(max_steps=300)
-                  write_target(6, (real)-0.4); pr.mask = 1u << 6; pr.tol = (real)0.01; pr.max_steps = 300; break;
-                case 8:
-                  result_grasp = last_res != RES_SUCCESS;
-                  record(5, result_grasp ? RES_MAX_STEPS : RES_SUCCESS, last_n);
-                  pc = 9; chosen = false; break;
-                case 9:   // :282
-                  write_kp0(10);
-                  if (P.check_mode == 1) { pr.need_ik = true; pr.xyz = v3(coord.x, coord.y, (real)1.1); pr.mask = 0x1fu; pr.tol = (real)0.05; pr.max_steps = 1000; slot = 6; }
-                  else { pc = 12; chosen = false; }
-                  break;
-                case 10:  // IT1 (README.md:20): 500-step closing check right after lifting
-                  if (result_grasp) { write_target(6, (real)-0.4); pr.mask = 1u << 6; pr.tol = (real)0.01; pr.max_steps = 500; slot = 9; }
-                  else { pc = 12; chosen = false; }
-                  break;
-                case 11: result_final = last_res; pc = 12; chosen = false; break;
-                case 12:  // :285 back above the table centre
-                  pr.need_ik = true; pr.xyz = v3(0, (real)-0.6, (real)1.1); pr.mask = 0x1fu; pr.tol = (real)0.05; pr.max_steps = 1000; slot = 7; break;
-                case 13:  // :297 to the drop position
-                  pr.need_ik = true; pr.xyz = v3((real)0.6, 0, (real)1.15); pr.mask = 0x1fu; pr.tol = (real)0.01; pr.max_steps = 1200; slot = 8; break;
-                case 14:  // :312-321 closing check at the drop position
-                  if (P.check_mode != 1 && result_grasp) { write_target(6, (real)-0.4); pr.mask = 1u << 6; pr.tol = (real)0.01; pr.max_steps = P.check_mode == 2 ? 100 : 1000; slot = 9; }   // check_mode 2 = demo_mode (:318-321)
-                  else { pc = 16; chosen = false; }
-                  break;
-                case 15: result_final = last_res; pc = 16; chosen = false; break;
-                case 16:  // :327, :338 open the gripper
-                  grasped = (result_final == RES_MAX_STEPS) && result_grasp;
-                  write_target(6, (real)0.4); pr.mask = 1u << 6; pr.tol = (real)0.05; pr.max_steps = 1000; slot = 10; break;
-                case 17:  // :341-342
-                  if (grasped) { pr.mask = mask_all(); pr.tol = (real)1e-7; pr.max_steps = 10; pr.repeat = stay_chunks_for(200); }
-                  else { pc = 18; chosen = false; }
-                  break;
-                case 18:  // :345 rotate back
-                  write_target(5, (real)0); pr.mask = mask_all(); pr.tol = (real)0.05; pr.max_steps = 500; slot = 11; break;
-                case 19:  // :347; then, for a scene whose episode ends here, GraspEnv.reset_model (GraspingEnv.py:409-477) inside the same launch
-                  write_kp0(20);
-                  result = grasped ? 1 : 0;
-                  if (P.reset_seeds && P.reset_seeds[env] != 0) {
-                    SYNC();
-                    if (UR5_LANE == 0) { const real ended = (real)((int)S.rec[UR5_REC_MISC + 7] | S.status); ur5_reset_record(M, P.qpos0, S.rec, P.reset_seeds[env]); S.rec[UR5_REC_MISC + 7] = ended; S.status = 0; invalidate_pair_cache(); }   // the attempt's status bits stay readable (counters: bits 8-15) after the episode reset that follows it in this launch
-                    SYNC();
-                    pr.mask = mask_all(); pr.tol = (real)1e-7; pr.max_steps = 10; pr.repeat = P.reset_chunks;   // :473 stay(1000)
-                    if (pr.repeat <= 0) pr.done = true;
-                  } else pr.done = true;
-                  break;
-                default: pr.done = true; break;
-              }
-            }
-          } else if (op == UR5_OP_STEP) {
-            if (pc == 0) { pr.mask = 0; pr.tol = (real)-1; pr.max_steps = P.max_steps[env]; pr.repeat = -1; }   // repeat < 0: raw sim.step() x max_steps
-            else { result = RES_SUCCESS; pr.done = true; }
-          } else if (op == UR5_OP_IK) {
-            if (pc == 0) { pr.need_ik = true; pr.xyz = coord; pr.repeat = 0; }
-            else { result = last_res; pr.done = true; }
-          } else {  // UR5_OP_FORWARD
-            if (pc == 0) pr.repeat = -2; else { result = RES_SUCCESS; pr.done = true; }
-          }
+          choose(P, env, sc, pr, slot);
           if (pr.done) { done = true; break; }
-          pc++;
+          sc.pc++;
           // ---------------- the primitive
           res = RES_NONE; steps = 0;
           bool ikfail = false;
@@ -4208,7 +4223,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
       }
     }
     if (live && UR5_LANE == 0) {
-      if (P.result) P.result[env] = result;
+      if (P.result && !ruled(P)) P.result[env] = sc.result;
       if (P.steps) P.steps[env] = S.last_steps;
     }
   }

@@ -26,6 +26,8 @@
 #define ur5_grasp_attempt ur5m_grasp_attempt
 #define ur5_grasp_attempt_dev ur5m_grasp_attempt_dev
 #define ur5_grasp_attempt_reset_dev ur5m_grasp_attempt_reset_dev
+#define ur5_grasp_rounds_dev ur5m_grasp_rounds_dev
+#define ur5_aim_rule ur5m_aim_rule
 #define ur5_sync ur5m_sync
 #define ur5_set_order_dev ur5m_set_order_dev
 #define ur5_set_stream ur5m_set_stream

@@ -760,6 +760,33 @@ int ur5_grasp_attempt_reset_dev(ur5_sim* h, const double* action_dev, int check_
   }
   return be_launch(h, P);
 }
+int ur5_grasp_rounds_dev(ur5_sim* h, const ur5_aim_rule* rule, int round0, int rounds, int check_mode, double table_height, int* reward_dev,
+                         double* action_out_dev, double settle_ms) {
+  using namespace ur5host;
+  if (!h) return fail(UR5_ERR_ARG, "ur5_grasp_rounds_dev: NULL handle");
+#ifndef UR5_MANY
+  if (h->variant == 1) return fail(UR5_ERR_MODEL, "ur5_grasp_rounds_dev: the scripted rule reads box positions on the pick plate; 40-object piles are aimed from the rendered observation (ur5_grasp_attempt_reset_dev)");
+#endif
+  if (!rule || !reward_dev || rounds < 1 || rule->kind != 1 || rule->episode_rounds < 1 || rule->n_total < 1 || rule->first_scene_id < 0)
+    return fail(UR5_ERR_ARG, "ur5_grasp_rounds_dev: rule (kind 1), reward_dev and rounds >= 1 are required");
+#if defined(UR5_MANY) || (defined(UR5_SMALL_GS) && UR5_SMALL_GS != 64)
+  return fail(UR5_ERR_MODEL, "ur5_grasp_rounds_dev: wavefront-per-scene engine only");
+#else
+  Ur5Launch P = base_launch(h, UR5_OP_GRASP);
+  P.check_mode = check_mode; P.table_height = table_height;
+  P.result = reward_dev; P.steps = h->d_steps; P.phase_steps = h->d_ps; P.phase_result = h->d_pr;
+  int rc = ensure_qpos0(h);
+  if (rc) return rc;
+  P.qpos0 = h->d_qpos0;
+  P.reset_chunks = settle_ms > 0 ? (int)std::ceil(settle_ms / 1000.0 / h->hm.timestep / 10.0 - 1e-9) : 0;
+  P.rounds = rounds; P.rule_kind = rule->kind; P.rule_r0 = round0; P.rule_ep = rule->episode_rounds;
+  P.rule_gid0 = rule->first_scene_id; P.rule_ntotal = rule->n_total; P.rule_base_seed = rule->base_seed;
+  const double plate[8] = {rule->plate_half_x, rule->plate_centre_y, rule->plate_half_y, rule->z_min, rule->z_max, rule->grasp_z, rule->fallback_x, rule->fallback_y};
+  for (int k = 0; k < 8; k++) P.rule_plate[k] = plate[k];
+  P.action_out = action_out_dev;
+  return be_launch(h, P);
+#endif
+}
 int ur5_grasp_attempt_dev(ur5_sim* h, const double* action_dev, int check_mode, double table_height, int* reward_dev) {
   return ur5_grasp_attempt_reset_dev(h, action_dev, check_mode, table_height, reward_dev, nullptr, 0.0);
 }

@@ -19,13 +19,20 @@ RES_NONE, RES_SUCCESS, RES_MAX_STEPS, RES_IK_FAIL = -1, 0, 1, 2
 _VARIANT = {0: (6, 2048, 192, 30), 1: (40, 4096, 832, 96)}
 EXPORTS = ["ur5_last_error", "ur5_create", "ur5_destroy", "ur5_num_envs", "ur5_nq", "ur5_nv", "ur5_nu", "ur5_reset", "ur5_reset_dev", "ur5_kernel_ms_total",
            "ur5_set_state", "ur5_get_state", "ur5_set_ctrl", "ur5_get_ctrl", "ur5_step", "ur5_move_group", "ur5_stay",
-           "ur5_move_ee", "ur5_ik", "ur5_grasp_attempt", "ur5_grasp_attempt_dev", "ur5_grasp_attempt_reset_dev", "ur5_sync", "ur5_set_stream", "ur5_set_order_dev", "ur5_last_launch_ms",
+           "ur5_move_ee", "ur5_ik", "ur5_grasp_attempt", "ur5_grasp_attempt_dev", "ur5_grasp_attempt_reset_dev", "ur5_grasp_rounds_dev", "ur5_sync", "ur5_set_stream", "ur5_set_order_dev", "ur5_last_launch_ms",
            "ur5_get_counters", "ur5_body_xpos", "ur5_render", "ur5_render_dev", "ur5_state_device_ptr"]
 TEST_EXPORTS = ["ur5_forward_debug"]   # include/ur5sim_test.h: introspection for tests/ and tools/, not part of the boundary
 
 
 class Config(C.Structure):
     _fields_ = [("ee_body", C.c_int), ("contacts_enabled", C.c_int), ("pid_dt", C.c_double)]
+
+
+class AimRule(C.Structure):
+    """ur5_aim_rule of include/ur5sim.h: the scripted aiming rule a multi-round launch evaluates in the kernel (ur5_grasp_rounds_dev)."""
+    _fields_ = [("kind", C.c_int), ("episode_rounds", C.c_int), ("first_scene_id", C.c_int64), ("n_total", C.c_int64), ("base_seed", C.c_uint64),
+                ("plate_half_x", C.c_double), ("plate_centre_y", C.c_double), ("plate_half_y", C.c_double), ("z_min", C.c_double), ("z_max", C.c_double),
+                ("grasp_z", C.c_double), ("fallback_x", C.c_double), ("fallback_y", C.c_double)]
 
 
 _libs = {}
@@ -65,6 +72,8 @@ def load(path=None):
     L.ur5_grasp_attempt.argtypes = [vp, dp, C.POINTER(C.c_uint8), C.c_int, C.c_double, ip, ip, ip]
     L.ur5_grasp_attempt_dev.argtypes = [vp, vp, C.c_int, C.c_double, vp]
     L.ur5_grasp_attempt_reset_dev.argtypes = [vp, vp, C.c_int, C.c_double, vp, vp, C.c_double]
+    if hasattr(L, "ur5_grasp_rounds_dev"):
+        L.ur5_grasp_rounds_dev.argtypes = [vp, C.POINTER(AimRule), C.c_int, C.c_int, C.c_int, C.c_double, vp, vp, C.c_double]
     L.ur5_last_launch_ms.argtypes = [vp]
     L.ur5_last_launch_ms.restype = C.c_double
     L.ur5_get_counters.argtypes = [vp, C.POINTER(C.c_int64)]
@@ -224,6 +233,12 @@ class BatchSim:
         self._check(self.lib.ur5_grasp_attempt_reset_dev(self._h, C.c_void_p(action_ptr), int(check_mode), float(table_height), C.c_void_p(reward_ptr),
                                                          C.c_void_p(reset_seeds_ptr) if reset_seeds_ptr else None, float(settle_ms)),
                     "ur5_grasp_attempt_reset_dev")
+
+    def grasp_rounds_dev(self, rule, round0, rounds, reward_ptr, action_out_ptr=None, check_mode=1, table_height=0.91, settle_ms=1000.0):
+        """``rounds`` consecutive grasp rounds (+ episode resets) of every scene in ONE launch, aimed in the kernel by the scripted ``rule`` (an AimRule); no scene
+        waits for another one's round. reward_ptr -> int32 [rounds][n], action_out_ptr -> float64 [rounds][n][8] or None (device pointers). Asynchronous."""
+        self._check(self.lib.ur5_grasp_rounds_dev(self._h, C.byref(rule), int(round0), int(rounds), int(check_mode), float(table_height), C.c_void_p(reward_ptr),
+                                                  C.c_void_p(action_out_ptr) if action_out_ptr else None, float(settle_ms)), "ur5_grasp_rounds_dev")
 
     def sync(self):
         self._check(self.lib.ur5_sync(self._h), "ur5_sync")
