@@ -197,6 +197,9 @@ enum { PF_KIN = 0, PF_CRB, PF_VEL, PF_BROAD, PF_NARROW, PF_ROWS, PF_NEWTON_INIT,
 #ifndef UR5_FORCE_GLOBAL_ENV
 #define UR5_FORCE_GLOBAL_ENV 0   // experiment: 1 = the envelope always lives in the scene's global-memory scratch (what a smaller LDS image would cost)
 #endif
+#ifndef UR5_STG_LDS
+#define UR5_STG_LDS 1            // 0 = the contact sides' wrench / Hessian terms are staged in the global scratch even when they fit the LDS pool (A/B)
+#endif
 #ifndef UR5_DCACHE_LDS
 #define UR5_DCACHE_LDS 1         // 0 = the factored diagonal blocks stay in the global scratch even when the envelope is in LDS (A/B)
 #endif
@@ -408,6 +411,7 @@ template <class real, int NV_> struct Lds {
   // results then do not depend on how its wavefronts are scheduled (MujocoController.py:379 is one deterministic thread).
   short csl[UR5_MAXCON][2];                          // accumulator slot of a contact's two bodies (-1: static side); flat index = side id 2 c + side
   short side_list[2 * UR5_MAXCON], slot_ptr[NSLOT + 1];
+  short side_pos[2 * UR5_MAXCON];                    // a side's position in side_list (sides of static bodies have none): where its staged terms go
   unsigned char slot_cnt[UR5_NT / 64][NSLOT + 1];    // sides of a slot held by the lanes of each wavefront (list construction)
   unsigned long long wrec[UR5_MAXCON];               // the coupled contacts grouped by the wavefront that owns their block pair, contact order inside a group:
   short wptr[UR5_NT / 64 + 1];                       // one packed record each (contact | body A << 8 | body B << 16 | block pair << 24 | A-owns-the-row-block << 40)
@@ -1807,6 +1811,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
         int o = S.slot_ptr[my] + carry_round + rank;
         for (int w = 0; w < wv; w++) o += S.slot_cnt[w][my];
         S.side_list[o] = (short)sd;
+        S.side_pos[sd] = (short)o;
       }
       if (r0 + UR5_NT >= ns2) break;
       SYNC();
@@ -2185,85 +2190,80 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
   // per side -- wrench terms [side][6] in the panel area (only the factorisation uses it), Hessian terms [side][21] in the envelope area (G is only built when the
   // envelope is about to be re-assembled) --, then lane (slot, entry) adds its slot's sides in list order = contact order. No float atomic, no dependence on the
   // wavefronts' timing; every entry of every slot is written, so nothing is zeroed first. Contacts are staged UR5_GCHUNK at a time (a settled pile has 40-80).
-#ifdef UR5_STG_LDS
-  // experiment (round 4): the Hessian terms staged in LDS too, 21 contacts at a time (their 42 sides' 6 wrench + 21 Hessian terms fill the 9 KB staging area), instead of
-  // all at once in the scene's global scratch: no scratch traffic for the staging, two more barrier pairs and list walks per refactorisation: -7.5 %.
-  // Round 5: the staging area is the head of the 19 KB Hessian pool (dead at this point of an iteration: the envelope is rebuilt after the gather)
-  static constexpr int GCHUNK = L::HENV_DOUBLES / 54;   // round 5: the whole pool (44 contacts per round: most steps need one round, like the global staging)
-  static constexpr bool STW_REL = true;
-#else
-  static constexpr int GCHUNK = UR5_MAXCON;          // (the staging area in the scene's global scratch holds every side: one round)
-  static constexpr bool STW_REL = false;
-#endif
-  UR5_FN void contact_gather(const bool doW, const bool doG) {
-    real* const stW = &S.stw[0][0];
-#ifdef UR5_STG_LDS
-    real* const stG = &S.stw[0][0] + 12 * GCHUNK;
-#else
-    real* const stG = S.hess + UR5_SCR_STG;
-#endif
-    const int chunk = doG ? GCHUNK : UR5_MAXCON;
-    for (int c0 = 0; c0 == 0 || c0 < S.ncon; c0 += chunk) {
-      const int c1 = c0 + chunk < S.ncon ? c0 + chunk : S.ncon;
-      for (int sd = 2 * c0 + UR5_LANE; sd < 2 * c1; sd += GS) {          // one lane per SIDE: the two sides of a contact recompute its weights, and finish in half the time
-        const int c = sd >> 1, side = sd & 1;
-        const int b = side == 0 ? S.cA[c] : S.cB[c];
-        if (b < 0) continue;
-        v3 ax[3] = {v3(S.cframe[c]), v3(S.cframe[c] + 3), cross(v3(S.cframe[c]), v3(S.cframe[c] + 3))};
-        real fb[NB], w[2 * NB - 1];
-        contact_weights(c, fb, w);
-        const real sg = side == 0 ? (real)-1 : (real)1;
-        const v3 r = v3(S.cpos[c]) - body_ref(b);
-        if (doW) {
-          v3 F = ax[0] * fb[0] + ax[1] * fb[1] + ax[2] * fb[2];
-          v3 T = ax[0] * fb[3];
-          if constexpr (NB > 4) T = T + ax[1] * fb[NB - 2] + ax[2] * fb[NB - 1];
-          const v3 Mo = cross(r, F) + T;
-          real* o = stW + 6 * (STW_REL ? sd - 2 * c0 : sd);
-          o[0] = sg * Mo.x; o[1] = sg * Mo.y; o[2] = sg * Mo.z; o[3] = sg * F.x; o[4] = sg * F.y; o[5] = sg * F.z;
-        }
-        if (!doG) continue;
-        // F_k (6-vector [rot; lin]): k<3 -> [r x a_k ; a_k], k>=3 -> [a_{k-3} ; 0];  G += sum_kl W_kl F_k F_l^T (arrow-shaped W)
-        real Fk[NB][6];
-        for (int k = 0; k < 3; k++) {
-          v3 ra = cross(r, ax[k]);
-          Fk[k][0] = ra.x; Fk[k][1] = ra.y; Fk[k][2] = ra.z; Fk[k][3] = ax[k].x; Fk[k][4] = ax[k].y; Fk[k][5] = ax[k].z;
-          if (3 + k < NB) { Fk[3 + k][0] = ax[k].x; Fk[3 + k][1] = ax[k].y; Fk[3 + k][2] = ax[k].z; Fk[3 + k][3] = 0; Fk[3 + k][4] = 0; Fk[3 + k][5] = 0; }
-        }
-        real* o = stG + 21 * (sd - 2 * c0);
-        int ent = 0;
-        for (int gi = 0; gi < 6; gi++)
-          for (int gj = 0; gj <= gi; gj++, ent++) {
-            real v = w[0] * Fk[0][gi] * Fk[0][gj];
-            for (int k = 1; k < NB; k++) v += w[k] * (Fk[0][gi] * Fk[k][gj] + Fk[k][gi] * Fk[0][gj]) + w[NB - 1 + k] * Fk[k][gi] * Fk[k][gj];
-            o[ent] = v;
-          }
+  // Round 5: the staging area is LDS whenever it fits. A side's 6 wrench + 21 Hessian terms are filed at the side's POSITION in the slot lists (sides of static
+  // bodies are not staged at all), wrench terms first: 27 doubles x (contacts + contacts between two movable bodies) <= the 2 384 doubles of the Hessian pool, which
+  // is dead at this point of an iteration (the envelope is rebuilt after the gather). The second phase then reads a slot's terms from consecutive LDS words instead
+  // of from the scene's global scratch -- five trips of (slot, entry) lanes, each of which used to wait for a global-memory round trip. A scene with more sides than
+  // fit (never seen: 88) stages in the global scratch as before. (Round 4's chunked LDS staging, 21 and then 44 contacts per round, lost 7.5 % / 5 %: every extra
+  // round repeats the five trips. This one never needs a second round.) Same terms, same order of every sum: same bits.
+  template <bool STL> UR5_FN void contact_gather_in(const bool doW, const bool doG) {
+    const int nsides = S.slot_ptr[nslot()];
+    real* const stW = STL ? (real*)S.henv : &S.stw[0][0];
+    real* const stG = STL ? (real*)S.henv + 6 * nsides : S.hess + UR5_SCR_STG;
+    for (int sd = UR5_LANE; sd < 2 * S.ncon; sd += GS) {          // one lane per SIDE: the two sides of a contact recompute its weights, and finish in half the time
+      const int c = sd >> 1, side = sd & 1;
+      const int b = side == 0 ? S.cA[c] : S.cB[c];
+      if (b < 0) continue;
+      const int at = STL ? (int)S.side_pos[sd] : sd;               // where the side's terms are filed
+      v3 ax[3] = {v3(S.cframe[c]), v3(S.cframe[c] + 3), cross(v3(S.cframe[c]), v3(S.cframe[c] + 3))};
+      real fb[NB], w[2 * NB - 1];
+      contact_weights(c, fb, w);
+      const real sg = side == 0 ? (real)-1 : (real)1;
+      const v3 r = v3(S.cpos[c]) - body_ref(b);
+      if (doW) {
+        v3 F = ax[0] * fb[0] + ax[1] * fb[1] + ax[2] * fb[2];
+        v3 T = ax[0] * fb[3];
+        if constexpr (NB > 4) T = T + ax[1] * fb[NB - 2] + ax[2] * fb[NB - 1];
+        const v3 Mo = cross(r, F) + T;
+        real* o = stW + 6 * at;
+        o[0] = sg * Mo.x; o[1] = sg * Mo.y; o[2] = sg * Mo.z; o[3] = sg * F.x; o[4] = sg * F.y; o[5] = sg * F.z;
       }
-      SYNC();
-      PAR(idx, nslot() * 27) {
-        const int sl = idx / 27, ent = idx - 27 * sl;
-        if (ent < 6 ? !doW : !doG) continue;
-        real acc = c0 == 0 ? (real)0 : (ent < 6 ? S.WB[sl][ent] : S.G[sl][ent - 6]);      // later rounds continue the sum where the previous one stopped
-        const int o1 = S.slot_ptr[sl + 1];
-        const real* const st = ent < 6 ? stW + ent - (STW_REL ? 12 * c0 : 0) : stG + (ent - 6) - 42 * c0;
-        const int stride = ent < 6 ? 6 : 21;
-        // a slot's list is in contact order and the rounds take consecutive runs of it; four sides per trip, their loads issued together (the sum keeps list order:
-        // a side outside the round or past the end contributes an exact zero)
-        for (int o = S.slot_ptr[sl]; o < o1; o += 4) {
+      if (!doG) continue;
+      // F_k (6-vector [rot; lin]): k<3 -> [r x a_k ; a_k], k>=3 -> [a_{k-3} ; 0];  G += sum_kl W_kl F_k F_l^T (arrow-shaped W)
+      real Fk[NB][6];
+      for (int k = 0; k < 3; k++) {
+        v3 ra = cross(r, ax[k]);
+        Fk[k][0] = ra.x; Fk[k][1] = ra.y; Fk[k][2] = ra.z; Fk[k][3] = ax[k].x; Fk[k][4] = ax[k].y; Fk[k][5] = ax[k].z;
+        if (3 + k < NB) { Fk[3 + k][0] = ax[k].x; Fk[3 + k][1] = ax[k].y; Fk[3 + k][2] = ax[k].z; Fk[3 + k][3] = 0; Fk[3 + k][4] = 0; Fk[3 + k][5] = 0; }
+      }
+      real* o = stG + 21 * at;
+      int ent = 0;
+      for (int gi = 0; gi < 6; gi++)
+        for (int gj = 0; gj <= gi; gj++, ent++) {
+          real v = w[0] * Fk[0][gi] * Fk[0][gj];
+          for (int k = 1; k < NB; k++) v += w[k] * (Fk[0][gi] * Fk[k][gj] + Fk[k][gi] * Fk[0][gj]) + w[NB - 1 + k] * Fk[k][gi] * Fk[k][gj];
+          o[ent] = v;
+        }
+    }
+    SYNC();
+    PAR(idx, nslot() * 27) {
+      const int sl = idx / 27, ent = idx - 27 * sl;
+      if (ent < 6 ? !doW : !doG) continue;
+      real acc = 0;
+      const int o1 = S.slot_ptr[sl + 1];
+      const real* const st = ent < 6 ? stW + ent : stG + (ent - 6);
+      const int stride = ent < 6 ? 6 : 21;
+      // a slot's list is in contact order; four sides per trip, their loads issued together (the sum keeps list order: a side past the end contributes an exact zero)
+      for (int o = S.slot_ptr[sl]; o < o1; o += 4) {
+        real v[4];
+        if constexpr (STL) {
+#pragma unroll
+          for (int k = 0; k < 4; k++) v[k] = o + k < o1 ? st[stride * (o + k)] : (real)0;
+        } else {
           int sd[4];
-          real v[4];
 #pragma unroll
           for (int k = 0; k < 4; k++) sd[k] = S.side_list[o + k < o1 ? o + k : o1 - 1];
 #pragma unroll
-          for (int k = 0; k < 4; k++) { const int c = sd[k] >> 1; v[k] = (o + k < o1 && c >= c0 && c < c1) ? st[stride * sd[k]] : (real)0; }
-          acc = ((acc + v[0]) + v[1]) + v[2];
-          acc += v[3];
+          for (int k = 0; k < 4; k++) v[k] = o + k < o1 ? st[stride * sd[k]] : (real)0;
         }
-        if (ent < 6) S.WB[sl][ent] = acc; else S.G[sl][ent - 6] = acc;
+        acc = ((acc + v[0]) + v[1]) + v[2];
+        acc += v[3];
       }
-      if (c1 >= S.ncon) break;
-      SYNC();
+      if (ent < 6) S.WB[sl][ent] = acc; else S.G[sl][ent - 6] = acc;
     }
+  }
+  UR5_FN void contact_gather(const bool doW, const bool doG) {
+    if (27 * (int)S.slot_ptr[nslot()] <= L::HENV_DOUBLES && UR5_STG_LDS) contact_gather_in<true>(doW, doG); else contact_gather_in<false>(doW, doG);
   }
 #endif
   // every contact lane scatters its two sides: doW -> body wrenches WB (the gradient), doG -> twist-space Hessians G
