@@ -370,19 +370,21 @@ def rendered_sub_result(torch, dist, sharding, dev, dev_id, workload, n, rounds,
     return out
 
 
-def dqn_sub_result(torch, dev, dev_id, n, rounds, warmup):
+def dqn_sub_result(torch, dev, dev_id, n, rounds, warmup, groups=2):
     """BASELINE.json configs[4] shape on one GPU (the 8-GPU version shards the scenes and all-gathers the 16-byte outcome records,
     mujoco_rl_ur5_amd/agent.py): per round render -> transform_observation (+ colour jitter) -> pixel-wise grasp-Q CNN forward for every scene
     (Modules.py MULTIDISCRETE_RESNET, fp32) -> epsilon-greedy action -> grasp script -> replay push + optimiser steps, all device-resident."""
     from mujoco_rl_ur5_amd.agent import BatchedGraspAgent
-    from mujoco_rl_ur5_amd.envs import GraspEnv
-    env = GraspEnv(n_envs=n, show_obs=False, observation="render", device_id=dev_id)
-    env.reset()
-    agent = BatchedGraspAgent(env=env, device=dev, max_updates_per_round=16)
+    # two scene groups per rank (round 5): group 1's render -> CNN forward -> action selection runs under group 0's grasp launch, a group's replay pushes and
+    # optimiser steps under the next group's launch; the transitions, batches and optimiser steps are those of the unpipelined loop (tests/test_agent.py)
+    agent = BatchedGraspAgent(n_envs=n, device=dev, max_updates_per_round=16, pipeline_groups=groups, device_id=dev_id)
+    for e in agent.envs:
+        e.reset()
+    total = lambda: sum(int(e.sim.counters()["total_steps"].sum()) for e in agent.envs)
     for _ in range(warmup):
         agent.round()
     torch.cuda.synchronize()
-    c0 = env.sim.counters()["total_steps"].sum()
+    c0 = total()
     u0, t0 = agent.learner.updates_done, time.perf_counter()
     rew = 0.0
     for _ in range(rounds):
@@ -390,13 +392,16 @@ def dqn_sub_result(torch, dev, dev_id, n, rounds, warmup):
         rew += float(out["reward"].float().mean())
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    steps = int(env.sim.counters()["total_steps"].sum() - c0)
+    steps = total() - c0
     res = {"workload": "BASELINE.json configs[4] shape on 1 GPU: 40-object piles, 200x200 RGB-D render, grasp-Q CNN (7.32 M parameters, fp32) forward for every scene, "
                        "epsilon-greedy pixel + rotation, grasp script, replay push + optimiser steps (batch 12), device-resident",
-           "scenes": n, "rounds": rounds, "warmup": warmup, "grasp_attempts_per_s": rounds * n / dt, "env_steps_per_s": steps / dt, "ms_per_round": 1e3 * dt / rounds,
+           "scenes": n, "rounds": rounds, "warmup": warmup, "pipelined_scene_groups": groups, "grasp_attempts_per_s": rounds * n / dt, "env_steps_per_s": steps / dt, "ms_per_round": 1e3 * dt / rounds,
            "optimiser_steps_per_round": (agent.learner.updates_done - u0) / rounds, "update_to_data": out["update_to_data"], "grasp_success_rate": rew / rounds,
            "epsilon": out["epsilon"], "loss": out["loss"], "cnn_gflop_per_scene_forward": 42.0}
-    env.sim.close()
+    res["learning_cadence"] = (f"{res['optimiser_steps_per_round']:.0f} optimiser steps per round of {n} transitions (update_to_data {res['update_to_data']:.4f}); the reference takes one step per "
+                               "transition (Grasping_Agent_multidiscrete.py:551-556): max_updates_per_round caps the replicated learner's share of a round")
+    for e in agent.envs:
+        e.sim.close()
     return res
 
 
@@ -437,7 +442,7 @@ def main():
                     help="run ONLY this secondary measurement (N = 1) and print it as {name: result}: what the rocprofv3 passes of tools/gpu_evidence_extras.sh profile")
     ap.add_argument("--sub-scenes", type=int, default=None, help="with --sub: scene count instead of the sub-result's own (same-box A/Bs of engine builds)")
     ap.add_argument("--sub-rounds", type=int, default=None, help="with --sub: timed rounds")
-    ap.add_argument("--sub-groups", type=int, default=2, help="with --sub-scenes / --sub-rounds: scene groups (handles + streams) of the sub-result")
+    ap.add_argument("--sub-groups", type=int, default=2, help="with --sub-scenes / --sub-rounds: scene groups (handles + streams) of the sub-result; with --sub dqn / dqn2048: pipelined scene groups of the agent (1 = the serial loop)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for 2 ranks on one device)")
     ap.add_argument("--collectives", action="store_true", help="N = 1 only: create a one-rank process group on --backend and issue every collective of an N-rank job "
                     "(barriers, the per-round all_gather of outcome records, the final reductions) -- how the RCCL path is executed on a one-GPU box; results are unchanged")
@@ -483,6 +488,10 @@ def main():
             # every scene resident at once: the chip idles through the tail), with 2048 the tail amortises
             "dqn2048": lambda cpu: dqn_sub_result(torch, dev, dev_id, 2048, 1, 1)}
     if args.sub:
+        if args.sub in ("dqn", "dqn2048") and (args.sub_scenes or args.sub_rounds or args.sub_groups != 2):
+            dflt = {"dqn": (512, 2), "dqn2048": (2048, 1)}[args.sub]
+            print(json.dumps({args.sub: dqn_sub_result(torch, dev, dev_id, args.sub_scenes or dflt[0], args.sub_rounds or dflt[1], 1, args.sub_groups)}), flush=True)
+            return
         if args.sub in ("it4", "many", "many4096") and (args.sub_scenes or args.sub_rounds or args.sub_groups != 2):
             wl = "it4" if args.sub == "it4" else "many"
             dflt = {"it4": (4096, 4), "many": (2048, 2), "many4096": (4096, 2)}[args.sub]
@@ -598,7 +607,7 @@ def main():
                 out[key] = {"error": f"{type(exc).__name__}: {exc}"}
         # the secondary results once more as top-level scalars (a driver that keeps only scalar keys of the line keeps these)
         for key in ("it4", "many", "many4096", "dqn", "dqn2048"):
-            for f in ("env_steps_per_s", "grasp_attempts_per_s", "roofline_frac", "grasp_success_rate", "newton_iters_per_step"):
+            for f in ("env_steps_per_s", "grasp_attempts_per_s", "roofline_frac", "grasp_success_rate", "newton_iters_per_step", "update_to_data"):
                 if isinstance(out.get(key), dict) and f in out[key]:
                     out[f"{key}_{f}"] = out[key][f]
         for pt in out.get("strong_scaling_points", []):

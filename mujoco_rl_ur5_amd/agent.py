@@ -136,6 +136,32 @@ class Learner:
         self.updates_done += 1
         return self.last_loss
 
+    def feed_round(self, n, parts, learn=True):
+        """push_and_learn for a round whose N transitions arrive in PARTS (scene order): ``parts`` yields (state, action, reward) of consecutive scene ranges as
+        they become available (a generator that waits for a scene group's physics to finish). The chunking is the round's -- k consecutive scenes per optimiser
+        step, k from the whole round's N --, a chunk that straddles two parts waits for the later one: the pushes, batches and steps are exactly those of
+        push_and_learn on the concatenated round, they only start earlier (while the next group's grasp launch is still running)."""
+        k = max(self.transitions_per_update, -(-n // self.max_updates_per_round))
+        losses, held = [], None
+        for st, ac, rw in parts:
+            if held is not None:
+                st, ac, rw = torch.cat((held[0], st)), torch.cat((held[1], ac)), torch.cat((held[2], rw))
+            m = (st.shape[0] // k) * k
+            for i0 in range(0, m, k):
+                self.memory.push(st[i0:i0 + k], ac[i0:i0 + k], rw[i0:i0 + k])
+                if learn:
+                    loss = self.learn()
+                    if loss is not None:
+                        losses.append(loss)
+            held = (st[m:], ac[m:], rw[m:]) if m < st.shape[0] else None
+        if held is not None:                                                                              # the round's last, shorter chunk
+            self.memory.push(*held)
+            if learn:
+                loss = self.learn()
+                if loss is not None:
+                    losses.append(loss)
+        return losses, (len(losses) / n if n else 0.0)
+
     def push_and_learn(self, state, action, reward, learn=True, outcomes=None, first_scene_id=0, n_actions_1=None):
         """A round's N transitions in the reference's order (:551-556: push, then learn): the transitions go into the ring in chunks of
         ``k`` consecutive scenes, an optimiser step after each chunk (its newest transition is in the batch). k = transitions_per_update,
@@ -167,13 +193,34 @@ class Learner:
 class BatchedGraspAgent:
     def __init__(self, env: GraspEnv = None, n_envs=1, device=None, learning_rate=LEARNING_RATE, mem_size=MEMORY_SIZE, eps_start=EPS_START,
                  eps_end=EPS_END, eps_decay=EPS_DECAY, seed=20, load_path=None, first_scene_id=0, n_total=None, transitions_per_update=1,
-                 max_updates_per_round=64, **env_kwargs):
+                 max_updates_per_round=64, pipeline_groups=1, **env_kwargs):
         torch.manual_seed(seed)                                                        # :76-79
         np.random.seed(seed)
         self.device = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
-        self.env = env if env is not None else GraspEnv(n_envs=n_envs, show_obs=False, observation="render", first_scene_id=first_scene_id,
-                                                        n_total=n_total, **env_kwargs)
-        self.N, self.H, self.W = self.env.n_envs, self.env.IMAGE_HEIGHT, self.env.IMAGE_WIDTH
+        # pipeline_groups = G > 1 (round 5): the rank's scenes are G scene groups -- one GraspEnv (engine handle) + one CUDA stream each, consecutive scene ranges.
+        # A round queues group 0's render -> CNN forward -> action selection -> grasp launch, then does the same for group 1 WHILE group 0's grasp launch occupies
+        # the chip, and so on; the replay pushes and optimiser steps of a group start as soon as its rewards are in, under the next group's launch. Every group's
+        # actions are selected with the weights the round started with, pushes keep scene order and the round's chunking: the transitions, batches and optimiser steps
+        # are those of pipeline_groups = 1 (tests/test_agent.py), only the engine no longer idles through the CNN and the learner.
+        self.G = max(1, int(pipeline_groups))
+        if env is not None:
+            if self.G > 1:
+                raise ValueError("pipeline_groups > 1 builds its own scene groups: pass n_envs / first_scene_id / n_total instead of env")
+            self.envs = [env]
+        else:
+            if n_envs % self.G:
+                raise ValueError("n_envs must be a multiple of pipeline_groups")
+            ng = n_envs // self.G
+            if n_total is None and self.G > 1:                                          # the groups' envs cannot derive the job's scene count from their own ranges
+                import torch.distributed as dist
+                world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+                if first_scene_id != (dist.get_rank() if world > 1 else 0) * n_envs:
+                    raise ValueError("first_scene_id > 0 needs n_total (the global scene count)")
+                n_total = world * n_envs
+            kw = dict(dict(show_obs=False, observation="render"), **env_kwargs)
+            self.envs = [GraspEnv(n_envs=ng, first_scene_id=first_scene_id + g * ng, n_total=n_total, **kw) for g in range(self.G)]
+        self.env = self.envs[0]                                                         # model constants, action space, camera (equal in every group)
+        self.N, self.H, self.W = sum(e.n_envs for e in self.envs), self.env.IMAGE_HEIGHT, self.env.IMAGE_WIDTH
         self.n_actions_1, self.n_actions_2 = int(self.env.action_space.nvec[0]), int(self.env.action_space.nvec[1])   # :97-100
         self.output = self.n_actions_1 * self.n_actions_2
         self.policy_net = MULTIDISCRETE_RESNET(number_actions_dim_2=self.n_actions_2).to(self.device)     # :103
@@ -189,6 +236,11 @@ class BatchedGraspAgent:
         self.steps_done, self.eps_threshold = 0, eps_start
         self.first_scene_id = self.env.first_scene_id                                   # one source of truth: the env's scene range
         self.n_total = self.env.n_total
+        self.streams = None
+        if self.G > 1 and self.device.type == "cuda":
+            self.streams = [torch.cuda.Stream(device=self.device) for _ in self.envs]
+            for e, st in zip(self.envs, self.streams):
+                e.use_stream(st)
         self.last_loss = None
         # every random draw of the loop is keyed by (seed, GLOBAL scene id, round): a scene explores, jitters and is noised the same way however the
         # batch is sharded (sharding.scene_uniform)
@@ -205,33 +257,43 @@ class BatchedGraspAgent:
             sharding.broadcast_many_from_rank0([t.data for t in list(self.policy_net.parameters()) + list(self.policy_net.buffers())])   # one set of initial weights (29 MB, once): rank 0's
 
     # ------------------------------------------------------------------ observation -> network input
-    def transform_observation(self, observation, normalize=True, jitter_and_noise=True):
+    def transform_observation(self, observation, normalize=True, jitter_and_noise=True, gids=None):
         """:301-368 for a batch: depth clipped at the table threshold, (noise,) negated and min-max normalised per image; rgb / 255.
-        observation = {"rgb": uint8 [N,H,W,3], "depth": float32 [N,H,W]} device tensors -> float32 [N,4,H,W]."""
+        observation = {"rgb": uint8 [N,H,W,3], "depth": float32 [N,H,W]} device tensors -> float32 [N,4,H,W]. gids: global ids of the scenes shown (default: all)."""
+        gids = self.gids if gids is None else gids
+        n = int(gids.shape[0])
         depth = observation["depth"].to(self.device).float().clamp(max=self.depth_threshold)            # :311
         if normalize:
-            for i0 in range(0, self.N, 128):                                                             # :317 (whenever normalize=True); chunks bound the int64 temporaries (128 x 80 000 x 8 B = 82 MB each)
-                depth[i0:i0 + 128] += 0.001 * sharding.scene_normal(self.seed, self.gids[i0:i0 + 128], self.rounds_done, 4, self.H * self.W).view(-1, self.H, self.W)
+            for i0 in range(0, n, 128):                                                                  # :317 (whenever normalize=True); chunks bound the int64 temporaries (128 x 80 000 x 8 B = 82 MB each)
+                depth[i0:i0 + 128] += 0.001 * sharding.scene_normal(self.seed, gids[i0:i0 + 128], self.rounds_done, 4, self.H * self.W).view(-1, self.H, self.W)
             depth = -depth
             dmin = depth.amin(dim=(1, 2), keepdim=True)
             dmax = depth.amax(dim=(1, 2), keepdim=True)
             depth = (depth - dmin) / (dmax - dmin).clamp_min(1e-12)                                      # :319-321
         rgb = observation["rgb"].to(self.device).permute(0, 3, 1, 2).float() / 255.0                    # ToTensor (:128)
         if normalize and jitter_and_noise:
-            rgb = color_jitter(rgb, u=sharding.scene_uniform(self.seed, self.gids, self.rounds_done, 5, 8))   # self.normal_rgb (:117-123, :334-335)
+            rgb = color_jitter(rgb, u=sharding.scene_uniform(self.seed, gids, self.rounds_done, 5, 8))   # self.normal_rgb (:117-123, :334-335)
         return torch.cat((rgb, depth.unsqueeze(1)), dim=1)
 
     # ------------------------------------------------------------------ action selection
-    def epsilon_greedy(self, state, observation):
-        """:232-282 per scene: greedy = argmax over the [6, H, W] Q maps; random = uniform over the (pixel, rotation) pairs whose pixel
-        lies on the table (world z >= TABLE_HEIGHT - 0.01, :266-280). Returns (action long [N], greedy bool [N])."""
+    def begin_round_epsilon(self):
+        """:241-243, once per round: every scene of the round -- whichever group selects it -- draws against the same threshold."""
         self.eps_threshold = self.eps_end + (self.eps_start - self.eps_end) * math.exp(-1.0 * self.steps_done / self.eps_decay)   # :241-243
         self.steps_done += self.n_total                                                                  # epsilon decays per transition of the whole job
-        u = sharding.scene_uniform(self.seed, self.gids, self.rounds_done, 1, 3, dtype=torch.float64)    # explore?, which table pixel, which rotation
+
+    def epsilon_greedy(self, state, observation, gids=None, env=None, new_round=True):
+        """:232-282 per scene: greedy = argmax over the [6, H, W] Q maps; random = uniform over the (pixel, rotation) pairs whose pixel
+        lies on the table (world z >= TABLE_HEIGHT - 0.01, :266-280). Returns (action long [N], greedy bool [N]). gids / env: a scene group of the round."""
+        if new_round:
+            self.begin_round_epsilon()
+        gids = self.gids if gids is None else gids
+        env = self.env if env is None else env
+        n = int(gids.shape[0])
+        u = sharding.scene_uniform(self.seed, gids, self.rounds_done, 1, 3, dtype=torch.float64)         # explore?, which table pixel, which rotation
         explore = u[:, 0] <= self.eps_threshold
         greedy_action = self._q_all(state)[1]
-        world = self.env.pixel_world_device(observation["depth"], self.device)                           # [N,H,W,3]
-        on_table = (world[..., 2] >= self.env.TABLE_HEIGHT - 0.01).reshape(self.N, -1)
+        world = env.pixel_world_device(observation["depth"], self.device)                                # [N,H,W,3]
+        on_table = (world[..., 2] >= env.TABLE_HEIGHT - 0.01).reshape(n, -1)
         on_table = torch.where(on_table.any(dim=1, keepdim=True), on_table, torch.ones_like(on_table))
         cdf = on_table.cumsum(dim=1, dtype=torch.int32)                                                  # uniform over the table pixels: inverse CDF of the draw (int32: 40 000 pixels)
         want = torch.floor(u[:, 1] * cdf[:, -1].double()).to(torch.int32) + 1                            # the want-th table pixel, 1-based
@@ -246,9 +308,10 @@ class BatchedGraspAgent:
         uses every image's OWN statistics here (qnet.per_sample_statistics): the reference selects actions with a batch of one in training
         mode (:232-299), and a scene's greedy action must not depend on which scenes share its chunk or its rank."""
         vals, idxs = [], []
+        n = int(state.shape[0])
         with torch.no_grad(), per_sample_statistics():
-            for i0 in range(0, self.N, chunk):
-                q = self.policy_net(state[i0:i0 + chunk]).reshape(min(chunk, self.N - i0), -1)           # [c, 6*H*W]
+            for i0 in range(0, n, chunk):
+                q = self.policy_net(state[i0:i0 + chunk]).reshape(min(chunk, n - i0), -1)                # [c, 6*H*W]
                 v, i = q.max(dim=1)
                 vals.append(v)
                 idxs.append(i)
@@ -268,10 +331,57 @@ class BatchedGraspAgent:
         self.last_loss = self.learner.learn()
         return self.last_loss
 
+    # ------------------------------------------------------------------ the same round with the scene groups pipelined (pipeline_groups > 1)
+    def _round_pipelined(self, learn, return_observation):
+        import contextlib
+        cuda = self.streams is not None
+        main = torch.cuda.current_stream(self.device) if cuda else None
+        self.begin_round_epsilon()
+        parts, o = [], 0
+        for g, env in enumerate(self.envs):                                                              # queue every group's rollout: the host never waits here
+            gids = self.gids[o:o + env.n_envs]
+            o += env.n_envs
+            if cuda:
+                self.streams[g].wait_stream(main)                                                        # this round's weights (the previous round's optimiser steps ran on the main stream)
+            with (torch.cuda.stream(self.streams[g]) if cuda else contextlib.nullcontext()):
+                obs = env.observation_device(self.device, sync=not cuda)
+                raw = {k: v.clone() for k, v in obs.items()} if return_observation else None
+                state = self.transform_observation(obs, gids=gids)
+                action, greedy = self.epsilon_greedy(state, obs, gids=gids, env=env, new_round=False)
+                env_action = self.transform_action(action)
+                reward, skipped = env.step_device(env_action, obs["depth"], self.device, sync=not cuda)   # group g's grasp launch: the next group's CNN runs under it
+                rec = torch.stack([gids.int(), env_action[:, 0].int(), env_action[:, 1].int(), reward.int()], dim=1)   # (reward is read when the launch has run: stream order)
+            parts.append(dict(raw=raw, state=state, action=action, greedy=greedy, reward=reward, skipped=skipped, rec=rec))
+
+        def finished():                                                                                  # a group's transitions once its launch has run, in scene order
+            for g, p in enumerate(parts):
+                if cuda:
+                    main.wait_stream(self.streams[g])                                                    # the learner's stream waits for group g only; later groups keep running
+                yield p["state"], p["action"], p["reward"]
+        if self.shared:                                                                                  # several ranks: the ring is filled from the gathered records of ALL ranks, after the round
+            for _ in finished():
+                pass
+            rec = torch.cat([p["rec"] for p in parts])
+            outcomes = sharding.gather_outcomes(rec)
+            losses, utd = self.learner.push_and_learn(torch.cat([p["state"] for p in parts]), torch.cat([p["action"] for p in parts]), torch.cat([p["reward"] for p in parts]),
+                                                      learn=learn, outcomes=outcomes, first_scene_id=self.first_scene_id, n_actions_1=self.n_actions_1)
+        else:                                                                                            # one rank: group g's pushes and optimiser steps run under group g + 1's launch
+            losses, utd = self.learner.feed_round(self.N, finished(), learn=learn)
+            outcomes = sharding.gather_outcomes(torch.cat([p["rec"] for p in parts]))
+        for env in self.envs:
+            if cuda:
+                env.sim.sync()
+            env.check_status()
+        cat = lambda key: torch.cat([p[key] for p in parts])
+        raw = {k: torch.cat([p["raw"][k] for p in parts]) for k in parts[0]["raw"]} if return_observation else None
+        return self._end_round(learn, losses, utd, raw, cat("action"), cat("reward").clone(), cat("skipped"), cat("greedy"), outcomes)
+
     # ------------------------------------------------------------------ one round of the episode loop (:540-560)
     def round(self, learn=True, return_observation=False):
         """observe -> act -> grasp -> store -> learn, for every scene of this rank; outcomes gathered over ranks (X1).
         return_observation: also hand back copies of the raw observation the actions were chosen in (what generate_data.py stores)."""
+        if self.G > 1:
+            return self._round_pipelined(learn, return_observation)
         obs = self.env.observation_device(self.device)
         raw = {k: v.clone() for k, v in obs.items()} if return_observation else None
         state = self.transform_observation(obs)
@@ -282,6 +392,9 @@ class BatchedGraspAgent:
         outcomes = sharding.gather_outcomes(rec)                                                         # the round's only collective on the rollout side: 16 B per scene
         losses, utd = self.learner.push_and_learn(state, action, reward, learn=learn, outcomes=outcomes if self.shared else None,
                                                   first_scene_id=self.first_scene_id, n_actions_1=self.n_actions_1)   # :551-556
+        return self._end_round(learn, losses, utd, raw, action, reward, skipped, greedy, outcomes)
+
+    def _end_round(self, learn, losses, utd, raw, action, reward, skipped, greedy, outcomes):
         self.last_loss = losses[-1] if losses else None
         if self.shared and learn and losses:
             # The replicas take identical steps on identical batches, but GPU kernels are not bit-reproducible across processes (MIOpen's weight-gradient kernels

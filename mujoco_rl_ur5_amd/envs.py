@@ -235,14 +235,22 @@ class GraspEnv(object):
         self._t_t = torch.from_numpy(Rinv @ self.controller.cam_pos).to(device)
         return torch
 
-    def observation_device(self, device=None):
+    def use_stream(self, stream):
+        """Run this env's engine launches on a torch CUDA stream (ur5_set_stream): kernels are then ordered with the torch work queued on that stream, and the
+        ``sync=False`` forms of observation_device / step_device need no host synchronisation at all -- the caller works under ``torch.cuda.stream(stream)`` and
+        waits for the stream when it wants the results (agent.BatchedGraspAgent with pipeline_groups > 1: one env + stream per scene group)."""
+        self.sim.set_stream(stream.cuda_stream)
+        self._stream = stream
+
+    def observation_device(self, device=None, sync=True):
         """get_observation (:390-406) without leaving the device: {"rgb": uint8 [N,H,W,3], "depth": float32 [N,H,W] metres}."""
         torch = self._torch_setup(device)
         cam = self.model.camera_name2id("top_down")
-        if self._t_rgb.is_cuda:
+        if self._t_rgb.is_cuda and sync:
             torch.cuda.synchronize()
         self.sim.render_dev(self._t_rgb.data_ptr(), self._t_gl.data_ptr(), cam, self.IMAGE_WIDTH, self.IMAGE_HEIGHT, 1)
-        self.sim.sync()
+        if sync:
+            self.sim.sync()
         ext = self.model.opt["extent"]
         near, far = self.model.opt["znear"] * ext, self.model.opt["zfar"] * ext
         return {"rgb": self._t_rgb, "depth": near / (1 - self._t_gl * (1 - near / far))}          # depth_2_meters (:729-740)
@@ -252,9 +260,10 @@ class GraspEnv(object):
         self._torch_setup(device)
         return self._t_t - depth.double().unsqueeze(-1) * self._t_rays
 
-    def step_device(self, action, depth, device=None):
+    def step_device(self, action, depth, device=None, sync=True):
         """GraspEnv.step (:62-156) with ``action`` long [N,2] = [pixel, rotation] and the current metric ``depth`` [N,H,W] on the device.
-        Returns (reward int32 [N], skipped bool [N]) as device tensors; the caller asks for the next observation when it needs one."""
+        Returns (reward int32 [N], skipped bool [N]) as device tensors; the caller asks for the next observation when it needs one.
+        sync=False (after use_stream): the launch is only queued; the returned reward tensor is the env's own buffer, valid once the stream has run."""
         torch = self._torch_setup(device)
         a = action.to(self._t_act.device).long().reshape(self.n_envs, 2)
         x, y = a[:, 0] % self.IMAGE_WIDTH, a[:, 0] // self.IMAGE_WIDTH                           # :95-96
@@ -266,11 +275,13 @@ class GraspEnv(object):
         self._t_act[:, :3] = coords
         self._t_act[:, 3] = a[:, 1].double()
         self._t_act[:, 4] = skip.double()
-        if self._t_act.is_cuda:
+        if self._t_act.is_cuda and sync:
             torch.cuda.synchronize()
         self.sim.grasp_attempt_dev(self._t_act.data_ptr(), self._t_rew.data_ptr(), check_mode=self.check_mode, table_height=self.TABLE_HEIGHT)
-        self.sim.sync()
         self.step_called += 1
+        if not sync:
+            return self._t_rew, skip
+        self.sim.sync()
         self.check_status()                                                                      # flagged scenes: warned about once, words in self.last_status
         return self._t_rew.clone(), skip
 

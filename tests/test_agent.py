@@ -142,3 +142,48 @@ def test_graspenv_step_on_gpu_host_path_equals_device_path_and_the_oracle(model_
         o.reset(20 + e, 1, True)
         r, ps, pr = o.grasp_attempt(coords[e], int(act[e, 1]), 0)
         assert r == reward[e] and ps.tolist() == info["phase_steps"][e].tolist()
+
+
+def _loop(model, lib, groups, rounds=6, n=6, device="cpu", width=24, **kw):
+    """`rounds` rounds of the config-5 loop with `groups` pipelined scene groups: (outcome records, losses, weight digest, ring bookkeeping, optimiser steps)."""
+    import hashlib
+    torch.manual_seed(0)
+    common = dict(file=model, show_obs=False, observation="render", image_width=width, image_height=width, check_mode=1, **({"_lib_path": lib} if lib else {}))
+    if groups == 1:
+        env = GraspEnv(n_envs=n, **common)
+        agent = BatchedGraspAgent(env=env, device=device, mem_size=40, eps_start=0.5, eps_end=0.5, max_updates_per_round=4, **kw)
+    else:
+        agent = BatchedGraspAgent(n_envs=n, device=device, mem_size=40, eps_start=0.5, eps_end=0.5, max_updates_per_round=4, pipeline_groups=groups, **common, **kw)
+    for e in agent.envs:
+        e.reset()
+    recs, losses = [], []
+    for _ in range(rounds):
+        out = agent.round()
+        recs.append(out["outcomes"].cpu().numpy().copy())
+        losses += out["losses"]
+    w = torch.cat([p.detach().reshape(-1).cpu() for p in agent.policy_net.parameters()] + [b.detach().reshape(-1).float().cpu() for b in agent.policy_net.buffers()])
+    states = np.concatenate([e.sim.get_state()["qpos"] for e in agent.envs])
+    return np.stack(recs), losses, hashlib.sha256(w.numpy().tobytes()).hexdigest(), (agent.memory.position, agent.memory.count), agent.learner.updates_done, states
+
+
+def test_pipelined_scene_groups_are_the_same_agent(model_it1, emul_lib):
+    """Round-4 verdict item 2: the config-5 loop with two (three) scene groups per rank -- group g + 1's render, CNN forward and action selection queued under group g's
+    grasp launch, a group's replay pushes and optimiser steps under the next group's launch -- must BE the unpipelined loop: the same outcome records in every round,
+    the same loss sequence (chunks of the round's chunking that straddle two groups included: 6 scenes, 4 updates per round -> chunks of 2; 3 groups of 2, 2 groups
+    of 3), bit-identical weights, the same replay ring, the same final scene states."""
+    one = _loop(model_it1, emul_lib, 1)
+    for g in (2, 3):
+        many = _loop(model_it1, emul_lib, g)
+        assert np.array_equal(one[0], many[0]) and one[0][:, :, 0].tolist() == [list(range(6))] * 6
+        assert one[1] == many[1] and len(one[1]) == one[4] == many[4] >= 6
+        assert one[2] == many[2] and one[3] == many[3] and np.array_equal(one[5], many[5])
+
+
+@pytest.mark.gpu
+def test_pipelined_scene_groups_on_gpu(model_it1):
+    """The same on the MI355X with real streams (one engine handle + CUDA stream per group, 64 x 64 observations): outcome records of the rounds before the first
+    optimiser step equal the unpipelined loop's by construction; afterwards the two runs differ only by MIOpen's run-to-run rounding (first losses to 1e-4 / 5 %)."""
+    one = _loop(model_it1, None, 1, rounds=5, n=8, device="cuda", width=64)
+    two = _loop(model_it1, None, 2, rounds=5, n=8, device="cuda", width=64)
+    assert np.array_equal(one[0][:3], two[0][:3]) and one[4] == two[4] >= 6 and one[3] == two[3]
+    assert abs(one[1][0] - two[1][0]) < 1e-4 * one[1][0] and np.allclose(one[1][:2], two[1][:2], rtol=0.05)
