@@ -206,7 +206,7 @@ class BatchedGraspAgent:
         if env is not None:
             if self.G > 1:
                 raise ValueError("pipeline_groups > 1 builds its own scene groups: pass n_envs / first_scene_id / n_total instead of env")
-            self.envs = [env]
+            self.envs, self.streams = [env], None
         else:
             if n_envs % self.G:
                 raise ValueError("n_envs must be a multiple of pipeline_groups")
@@ -218,7 +218,15 @@ class BatchedGraspAgent:
                     raise ValueError("first_scene_id > 0 needs n_total (the global scene count)")
                 n_total = world * n_envs
             kw = dict(dict(show_obs=False, observation="render"), **env_kwargs)
-            self.envs = [GraspEnv(n_envs=ng, first_scene_id=first_scene_id + g * ng, n_total=n_total, **kw) for g in range(self.G)]
+            self.envs, self.streams = [], None
+            for g in range(self.G):
+                self.envs.append(GraspEnv(n_envs=ng, first_scene_id=first_scene_id + g * ng, n_total=n_total, **kw))
+                if self.G > 1 and self.device.type == "cuda":
+                    # one CUDA stream per group, created right after the group's engine handle (as bench.py's scene groups do): HIP deals its hardware queues to streams
+                    # in creation order, and two group streams created back to back after all handles landed on ONE queue -- the groups' work serialised
+                    # (profiles/r05_f_dqn512_timeline_one_queue.txt: CNN burst, engine, CNN burst, engine on queue 4)
+                    self.streams = (self.streams or []) + [torch.cuda.Stream(device=self.device)]
+                    self.envs[-1].use_stream(self.streams[-1])
         self.env = self.envs[0]                                                         # model constants, action space, camera (equal in every group)
         self.N, self.H, self.W = sum(e.n_envs for e in self.envs), self.env.IMAGE_HEIGHT, self.env.IMAGE_WIDTH
         self.n_actions_1, self.n_actions_2 = int(self.env.action_space.nvec[0]), int(self.env.action_space.nvec[1])   # :97-100
@@ -236,11 +244,7 @@ class BatchedGraspAgent:
         self.steps_done, self.eps_threshold = 0, eps_start
         self.first_scene_id = self.env.first_scene_id                                   # one source of truth: the env's scene range
         self.n_total = self.env.n_total
-        self.streams = None
-        if self.G > 1 and self.device.type == "cuda":
-            self.streams = [torch.cuda.Stream(device=self.device) for _ in self.envs]
-            for e, st in zip(self.envs, self.streams):
-                e.use_stream(st)
+
         self.last_loss = None
         # every random draw of the loop is keyed by (seed, GLOBAL scene id, round): a scene explores, jitters and is noised the same way however the
         # batch is sharded (sharding.scene_uniform)
