@@ -224,7 +224,7 @@ def cpu_baseline(model, budget_s=12.0, kind="it1"):
     if kind == "many":
         sn, an, tn, attn, sucn = O.batch(model, cores, budget_s, 4, 1)              # scenes in flight when the budget ends are cut off; their steps count
         return dict(value=sn / tn, unit="env-steps/s", cores=cores, kind="port",
-                    sample=f"{an} piles (scenes 0..{an - 1}): reset + 1000 ms settle + one rendered grasp attempt at the highest object of the bin each, cut off "
+                    sample=f"{an} piles (scenes 0..{an - 1}): reset + 1000 ms settle + one rendered grasp attempt each, aimed by the timed GPU rounds' box rule (oracle bench_pile_aim == It1Rounds.pile_box_actions), cut off "
                            f"after {budget_s:.0f} s ({sn} physics steps, {attn} attempts completed), oracle/ur5_oracle.cpp, one scene per thread on {cores} threads, {tn:.1f} s wall",
                     grasp_attempts_per_s=attn / tn, grasp_success_rate=sucn / max(1, attn), env_steps_per_attempt=sn / max(1, attn))
     mode = 2 if kind == "it1" else 3

@@ -48,6 +48,8 @@ def lib():
         L.ur5o_set_ctrl.argtypes = [vp, dp]
         L.ur5o_get_ctrl.argtypes = [vp, dp]
         L.ur5o_forward.argtypes = [vp]
+        L.ur5o_bench_pile_aim.argtypes = [vp, C.c_int, C.c_int, dp]
+        L.ur5o_bench_pile_aim.restype = C.c_int
         L.ur5o_newton_trace.argtypes = [vp, C.c_int]
         L.ur5o_get_newton_trace.argtypes = [vp, vp, C.c_int]
         L.ur5o_get_newton_trace.restype = C.c_int
@@ -276,6 +278,12 @@ class Oracle:
     @property
     def solver_iter_last(self):
         return lib().ur5o_solver_iter_last(self._h)
+
+    def bench_pile_aim(self, g, r=0):
+        """bench.py's pile aiming rule on the oracle's current state (ur5_oracle.cpp bench_pile_aim): (xy, rotation index)."""
+        xyz = np.zeros(3)
+        rot = lib().ur5o_bench_pile_aim(self._h, int(g), int(r), _dp(xyz))
+        return xyz[:2].copy(), int(rot)
 
     def newton_trace(self, on=True):
         """Switch the recording of the Newton solve's active sets on / off (test hook of ur5_oracle.cpp newton_direction)."""

@@ -1860,6 +1860,57 @@ static void bench_aim(const Sim& s, int g, int j, double* xyz) {
     if (std::fabs(x) <= 0.27 && std::fabs(y + 0.6) <= 0.19 && z >= 0.905 && z <= 1.0) { xyz[0] = x; xyz[1] = y; return; }
   }
 }
+// bench.py's aiming rule for 40-object piles (It1Rounds.pile_box_actions = tools/pile_aim.py pick_box, evaluated on the GPU by the timed rounds): the box inside
+// the bin with the most level top face whose sides are parallel to the fingers at wrist angle 0 / +30 / -30 deg (rotation index 0 / 1 / 4) and nothing lying on it;
+// without such a box the highest object inside the bin (rotation cycling), an empty bin gets an attempt at its centre. Returns the rotation index.
+static int bench_pile_aim(const Sim& s, int g, int r, double* xyz) {
+  const double PI = 3.14159265358979323846;
+  std::vector<int> objs;
+  for (int b = 1; b < s.M.nbody; b++)
+    if (s.M.body_parentid[b] == 0 && s.M.body_jntnum[b] == 1 && s.M.jnt_type[s.M.body_jntadr[b]] == JNT_FREE) objs.push_back(b);
+  double best = 1e300; int best_rot = 0; bool found = false;
+  for (size_t k = 0; k < objs.size(); k++) {
+    const int b = objs[k];
+    int gbox = -1;
+    for (int gi = 0; gi < s.M.ngeom; gi++) if (s.M.geom_bodyid[gi] == b && s.M.geom_type[gi] == GEOM_BOX) gbox = gi;
+    if (gbox < 0) continue;
+    const double* q = &s.qpos[s.M.jnt_qposadr[s.M.body_jntadr[b]]];
+    if (!(std::fabs(q[0]) < 0.17 && std::fabs(q[1] + 0.6) < 0.10 && q[2] > 0.89)) continue;
+    const double w = q[3], x = q[4], y = q[5], z = q[6];
+    const double R[3][3] = {{1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)}, {2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)},
+                            {2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)}};
+    int a = 0;
+    for (int i = 1; i < 3; i++) if (std::fabs(R[2][i]) > std::fabs(R[2][a])) a = i;
+    const double tilt = std::acos(std::min(1.0, std::fabs(R[2][a]))) * 180.0 / PI;
+    const int bb = (a + 1) % 3;
+    const double want = -std::atan2(R[1][bb], R[0][bb]) * 180.0 / PI;
+    const double ang[3] = {0.0, 30.0, -30.0};
+    const int rots[3] = {0, 1, 4};
+    double mis_min = 1e300; int which = 0;
+    for (int i = 0; i < 3; i++) {
+      double v = std::fmod(want - ang[i] + 45.0, 90.0);
+      if (v < 0) v += 90.0;                                                    // python's / torch.remainder's sign convention
+      const double mis = std::fabs(v - 45.0);
+      if (mis < mis_min) { mis_min = mis; which = i; }
+    }
+    bool on_top = false;
+    for (size_t o = 0; o < objs.size(); o++) {
+      if (o == k) continue;
+      const double* p = &s.qpos[s.M.jnt_qposadr[s.M.body_jntadr[objs[o]]]];
+      if (std::hypot(p[0] - q[0], p[1] - q[1]) < 0.05 && p[2] - q[2] > 0.01) on_top = true;
+    }
+    const double score = tilt + mis_min + (on_top ? 100.0 : 0.0);
+    if (score < best) { best = score; best_rot = rots[which]; xyz[0] = q[0]; xyz[1] = q[1]; found = true; }
+  }
+  if (found) return best_rot;
+  xyz[0] = 0; xyz[1] = -0.6;
+  double top = -1;
+  for (int b : objs) {
+    const double* q = &s.qpos[s.M.jnt_qposadr[s.M.body_jntadr[b]]];
+    if (std::fabs(q[0]) < 0.2 && std::fabs(q[1] + 0.6) < 0.13 && q[2] > 0.85 && q[2] > top) { top = q[2]; xyz[0] = q[0]; xyz[1] = q[1]; }
+  }
+  return (g / 4 + r) % 6;
+}
 // the observation step of bench.py's rendered workloads on the CPU: render the 200x200 RGB-D image of camera `cam` (GraspEnv.get_observation), find the
 // pixel over world (x, y) at table height (the inverse of the renderer's own pixel -> ray map) and return the world height the depth image shows there
 static int g_batch_cam = 1;   // "top_down" of both scene files
@@ -1880,8 +1931,8 @@ static double bench_observed_height(Sim& s, double x, double y, std::vector<unsi
 // mode 0: reset + settle + ONE aimed attempt per scene (round-1 sample, kept for comparison); mode 1: reset + nsteps raw steps (many-object drop);
 // mode 2: bench.py's stationary IT1 workload -- whole episodes of reset + settle + `nsteps` aimed attempts (bench_aim) per scene;
 // mode 3: the same episodes on the rendered workload (bench.py kind "it4"): every attempt renders the observation and takes its height from the depth
-// image, in-tree script (check_mode 0); mode 4: 40-object piles (kind "many"): reset + 1000 ms settle + ONE rendered attempt at the highest object of
-// the bin per scene (a whole episode of a pile is minutes of CPU time: the sample is bounded to one attempt).
+// image, in-tree script (check_mode 0); mode 4: 40-object piles (kind "many"): reset + 1000 ms settle + ONE rendered attempt aimed by the timed GPU
+// rounds' box rule (bench_pile_aim) per scene (a whole episode of a pile is minutes of CPU time: the sample is bounded to one attempt).
 long ur5o_batch(const void* blob, size_t nbytes, int ee_body, int base_body, int nthreads, double budget_s, int mode, int nsteps,
                 long* scenes_out, double* wall_out, long* attempts_out, long* success_out) {
   std::atomic<long> steps{0}, scenes{0}, attempts{0}, success{0};
@@ -1918,15 +1969,11 @@ long ur5o_batch(const void* blob, size_t nbytes, int ee_body, int base_body, int
         }
       } else if (mode == 4) {
         s.reset(20 + (uint64_t)g, 1, 1);
-        double xyz[3] = {0, -0.6, 0.91}, top = -1;
-        for (int b = 1; b < s.M.nbody; b++) {
-          if (s.M.body_parentid[b] != 0 || s.M.body_jntnum[b] != 1 || s.M.jnt_type[s.M.body_jntadr[b]] != JNT_FREE) continue;
-          const double* q = &s.qpos[s.M.jnt_qposadr[s.M.body_jntadr[b]]];
-          if (std::fabs(q[0]) < 0.2 && std::fabs(q[1] + 0.6) < 0.13 && q[2] > 0.85 && q[2] > top) { top = q[2]; xyz[0] = q[0]; xyz[1] = q[1]; }
-        }
+        double xyz[3] = {0, -0.6, 0.91};
+        const int rot = bench_pile_aim(s, g, 0, xyz);               // the timed GPU rounds' rule (bench.py It1Rounds.pile_box_actions)
         xyz[2] = bench_observed_height(s, xyz[0], xyz[1], rgb, depth);
         int ps[12], pr[12];
-        int r = s.grasp_attempt(xyz, g % 6, 0, 0.91, ps, pr);
+        int r = s.grasp_attempt(xyz, rot, 0, 0.91, ps, pr);
         if (!stop.load()) { success += r; attempts++; }
       } else {
         s.reset(20 + (uint64_t)g, 1, 0);
@@ -1948,6 +1995,7 @@ long ur5o_batch(const void* blob, size_t nbytes, int ee_body, int base_body, int
   if (success_out) *success_out = success.load();
   return steps.load();
 }
+int ur5o_bench_pile_aim(void* h, int g, int r, double* xyz) { return bench_pile_aim(*(Sim*)h, g, r, xyz); }
 int ur5o_grasp_attempt(void* h, const double* xyz, int rot, int check_mode, double table_height, int* phase_steps, int* phase_result) {
   return ((Sim*)h)->grasp_attempt(xyz, rot, check_mode, table_height, phase_steps, phase_result);
 }

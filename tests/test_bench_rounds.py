@@ -107,3 +107,39 @@ def test_device_side_pile_rule_equals_tools_pile_aim(model_it1):
         nbox += 1
         assert found[e] and int(rot[e]) == b[2] and np.allclose(xy[e].numpy(), b[1][:2], atol=1e-12), (e, b, xy[e], rot[e])
     assert nbox > 40 and not found[5] and np.allclose(xy[5].numpy(), [0.0, -0.6])
+
+
+def test_cpu_leg_of_the_pile_rounds_aims_with_the_same_box_rule(model_it1):
+    """Round-4 verdict 3d: bench.py's `many` CPU leg used to aim at the highest object of the bin while the timed GPU rounds aim with the box rule, so attempts/s and
+    success rates of the two legs were not like for like. The oracle's batch mode 4 now calls bench_pile_aim: the same choice as tools/pile_aim.py / the torch rule."""
+    from mujoco_rl_ur5_amd.model import load_model
+    from oracle.oracle import Oracle
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from pile_aim import pick_box
+    m = load_model("/UR5+gripper/UR5gripper_2_finger_many_objects.xml")
+    o = Oracle(m)
+    rng = np.random.default_rng(11)
+    found = 0
+    for trial in range(40):
+        q = np.array(m.qpos0, dtype=np.float64)
+        P = q[8:].reshape(-1, 7)
+        P[:, 0], P[:, 1], P[:, 2] = rng.uniform(-0.22, 0.22, 40), rng.uniform(-0.75, -0.45, 40), rng.uniform(0.9, 1.05, 40)
+        quat = rng.normal(size=(40, 4)); quat /= np.linalg.norm(quat, axis=1, keepdims=True)
+        if trial % 2 == 0:                                                       # level boxes with random yaw
+            yaw = rng.uniform(-np.pi, np.pi, 40)
+            quat[10:20] = np.stack([np.cos(yaw[10:20] / 2), 0 * yaw[10:20], 0 * yaw[10:20], np.sin(yaw[10:20] / 2)], axis=1)
+        P[:, 3:7] = quat
+        if trial == 7:
+            P[:, 0] = 0.5                                                        # nothing in the bin
+        o.set_state(qpos=q, qvel=np.zeros(m.nv), warmstart=np.zeros(m.nv))
+        xy, rot = o.bench_pile_aim(trial, 0)
+        b = pick_box(m, q)
+        if b is None:
+            continue
+        found += 1
+        assert rot == b[2] and np.allclose(xy, b[1][:2], atol=1e-12), (trial, b, xy, rot)
+    assert found > 20
+    P[:, 0] = 0.5                                                                # an empty bin: an attempt at its centre, rotation cycling with the scene id
+    o.set_state(qpos=q, qvel=np.zeros(m.nv), warmstart=np.zeros(m.nv))
+    xy, rot = o.bench_pile_aim(9, 0)
+    assert np.allclose(xy, [0.0, -0.6]) and rot == (9 // 4) % 6
