@@ -483,10 +483,12 @@ def main():
     subs = {"it4": lambda cpu: rendered_sub_result(torch, dist, sharding, dev, dev_id, "it4", 4096, 4, 1, cpu),
             "many": lambda cpu: rendered_sub_result(torch, dist, sharding, dev, dev_id, "many", 2048, 2, 1, cpu),   # BASELINE configs[3]: 16384 piles on 8 GPUs = 2048 per GPU
             "many4096": lambda cpu: rendered_sub_result(torch, dist, sharding, dev, dev_id, "many", 4096, 2, 1, False),   # north_star: "a 4096-env synthetic pile" on one GPU
-            "dqn": lambda cpu: dqn_sub_result(torch, dev, dev_id, 512, 2, 1),
+            # pipelined scene groups (agent.BatchedGraspAgent): +3 % at 512 piles (one pile per CU: the other group's CNN finds LDS), -2 % at 2048 (two piles per CU hold
+            # 99.5 % of a CU's LDS: a CNN kernel only gets a CU in the launch's tail, and runs 3.7 x slower there) -- same-box A/B in profiles/r05_g_dqn_ab.log
+            "dqn": lambda cpu: dqn_sub_result(torch, dev, dev_id, 512, 2, 1, 2),
             # the same loop at the per-GPU scene count of configs[3] / [4] (16384 piles on 8 GPUs): with 512 piles a round lasts as long as its longest scene (2 piles per CU,
             # every scene resident at once: the chip idles through the tail), with 2048 the tail amortises
-            "dqn2048": lambda cpu: dqn_sub_result(torch, dev, dev_id, 2048, 1, 1)}
+            "dqn2048": lambda cpu: dqn_sub_result(torch, dev, dev_id, 2048, 1, 1, 1)}
     if args.sub:
         if args.sub in ("dqn", "dqn2048") and (args.sub_scenes or args.sub_rounds or args.sub_groups != 2):
             dflt = {"dqn": (512, 2), "dqn2048": (2048, 1)}[args.sub]
