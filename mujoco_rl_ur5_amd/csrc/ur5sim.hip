@@ -7,31 +7,15 @@
 #include "ur5_engine.h"
 #include "ur5sim_host.h"
 
-// Lanes per scene (GS) and register budget of the small-scene kernels. Measured on one MI355X, bench.py workload (profiles/r02_*):
-//  * GS = 64 (default): one scene per wavefront, two waves per SIMD at 256 registers (8 scenes per CU, the LDS limit). The two resident
-//    waves hide each other's latencies almost perfectly (a wave alone takes 68 us per settled step, 8 per CU 90 us each).
-//  * GS = 32 (-DUR5_SMALL_GS=32, NV = 32 kernel only): TWO scenes per wavefront, one wave per SIMD with the whole 512-entry register file.
-//    One instruction stream serves two scenes (a lone wave: 88 us per step for both), but the LDS footprint still caps a CU at 8 scenes,
-//    i.e. ONE such wave per SIMD with nothing to overlap it: 5.5 M env-steps/s against 7.7 M for GS = 64 on the same box. It would need
-//    <= 10 KB of LDS per scene (two such waves per SIMD) to win. Kept as a build option; tests/ pass in both layouts.
-#ifndef UR5_SMALL_GS
-#define UR5_SMALL_GS 64
-#endif
-#ifndef UR5_WAVES_PER_EU
-#define UR5_WAVES_PER_EU 2
-#endif
-#if defined(UR5_MANY) && defined(UR5_MANY_OCC2)   // experiment: two pile scenes per CU need <= 256 registers per lane (and an LDS image <= 80 KB)
+// Register budget. Small-scene unit: one scene per wavefront, two wavefronts per SIMD at 256 registers (8 scenes per CU, the LDS limit): the two resident waves hide each
+// other's latencies almost perfectly (a wave alone takes 68 us per settled step, 8 per CU 90 us each). A 168-register cap for a third wave costs 26 %.
+// Pile unit: two scenes per CU need <= 256 registers per lane and an LDS image <= 80 KB; the cap alone was +-0 % (profiles/r04_d_ab_many_register_cap.log).
+#ifdef UR5_MANY
 #define UR5_KERNEL_ATTR(GS) __launch_bounds__(UR5_NT) __attribute__((amdgpu_waves_per_eu(2, 2)))
-#elif defined(UR5_MANY)
-#define UR5_KERNEL_ATTR(GS) __launch_bounds__(UR5_NT)
-#else
-#define UR5_KERNEL_ATTR(GS) __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((GS) < 64 ? 1 : UR5_WAVES_PER_EU)))
-#endif
-#if defined(UR5_MANY) && defined(UR5_MANY_OCC2)
 static_assert(2 * sizeof(ur5::Lds<double, UR5_MAXNV>) <= 160 * 1024, "two 40-object scenes per CU: the pile's LDS image must stay below 80 KB");
-#endif
-#if !defined(UR5_MANY) && !defined(UR5_PROFILE)   // (the per-phase cycle accounting build adds its counters to the image)
-#ifndef UR5_LDS_PAD
+#else
+#define UR5_KERNEL_ATTR(GS) __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
+#ifndef UR5_PROFILE   // (the per-phase cycle accounting build adds its counters to the image)
 static_assert(8 * sizeof(ur5::Lds<double, 32>) <= 160 * 1024, "the IT1 scene image must leave room for 8 scenes per CU (2 waves per SIMD): LDS is what caps residency");
 static_assert(7 * sizeof(ur5::Lds<double, 44>) <= 160 * 1024 && sizeof(ur5::Lds<double, 44>) <= 18 * 1280, "the six-object image: 7 scenes per CU = 18 of the 128 LDS granules of 1 280 B (profiles/r04_z_lds_residency.log)");
 #endif
@@ -251,10 +235,8 @@ static int be_launch(ur5_sim* h, const Ur5Launch& P) {
   }
   hipLaunchKernelGGL((ur5_run_kernel<UR5_MAXNV, UR5_NT>), grid, block, sizeof(ur5::Lds<double, UR5_MAXNV>), b->stream, h->d_rec, P);
 #else
-  if (h->nvt == 32) {
-    constexpr int SPW = UR5_NT / UR5_SMALL_GS;   // scenes per workgroup
-    hipLaunchKernelGGL((ur5_run_kernel<32, UR5_SMALL_GS>), dim3((h->n + SPW - 1) / SPW), block, SPW * sizeof(ur5::Lds<double, 32>), b->stream, h->d_rec, P);
-  } else hipLaunchKernelGGL((ur5_run_kernel<UR5_MAXNV, 64>), dim3(h->n), block, sizeof(ur5::Lds<double, UR5_MAXNV>), b->stream, h->d_rec, P);
+  if (h->nvt == 32) hipLaunchKernelGGL((ur5_run_kernel<32, 64>), dim3(h->n), block, sizeof(ur5::Lds<double, 32>), b->stream, h->d_rec, P);
+  else hipLaunchKernelGGL((ur5_run_kernel<UR5_MAXNV, 64>), dim3(h->n), block, sizeof(ur5::Lds<double, UR5_MAXNV>), b->stream, h->d_rec, P);
 #endif
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(ev1, b->stream));

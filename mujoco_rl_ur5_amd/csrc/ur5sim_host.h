@@ -769,7 +769,7 @@ int ur5_grasp_rounds_dev(ur5_sim* h, const ur5_aim_rule* rule, int round0, int r
 #endif
   if (!rule || !reward_dev || rounds < 1 || rule->kind != 1 || rule->episode_rounds < 1 || rule->n_total < 1 || rule->first_scene_id < 0)
     return fail(UR5_ERR_ARG, "ur5_grasp_rounds_dev: rule (kind 1), reward_dev and rounds >= 1 are required");
-#if defined(UR5_MANY) || (defined(UR5_SMALL_GS) && UR5_SMALL_GS != 64)
+#ifdef UR5_MANY
   return fail(UR5_ERR_MODEL, "ur5_grasp_rounds_dev: wavefront-per-scene engine only");
 #else
   Ur5Launch P = base_launch(h, UR5_OP_GRASP);

@@ -32,12 +32,18 @@ def pytest_collection_modifyitems(config, items):
                 it.add_marker(skip)
 
 
+def _engine_sources():
+    """Every file of the engine source the test builds compile: the header, its per-phase parts (ur5_engine_*.inc) and the host side."""
+    import glob
+    d = os.path.join(ROOT, "mujoco_rl_ur5_amd", "csrc")
+    return [os.path.join(d, f) for f in ("ur5_engine.h", "ur5sim_host.h", "ur5_devmodel.h", "ur5_raster.h", "ur5_many_names.h")] + sorted(glob.glob(os.path.join(d, "ur5_engine_*.inc")))
+
+
 def build_emul(flags=(), name="libur5sim_emul.so"):
     """Test-only lane-emulation build of the engine source (see tests/emul/ur5sim_emul.cpp)."""
     lib = os.path.join(os.path.dirname(EMUL_LIB), name)
     srcs = [os.path.join(EMUL_DIR, f) for f in ("ur5sim_emul.cpp", "ur5sim_emul_many.cpp")]
-    deps = srcs + [os.path.join(ROOT, "mujoco_rl_ur5_amd", "csrc", f)
-                   for f in ("ur5_engine.h", "ur5sim_host.h", "ur5_devmodel.h", "ur5_raster.h", "ur5_many_names.h")]
+    deps = srcs + _engine_sources()
     if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(s) for s in deps):
         os.makedirs(os.path.dirname(lib), exist_ok=True)
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", *flags, "-o", lib] + srcs)
@@ -51,8 +57,7 @@ def build_simt():
     tag = "".join(c if c.isalnum() else "_" for c in "".join(extra))
     lib = os.path.join(os.path.dirname(EMUL_LIB), f"libur5sim_simt{('_' + tag) if tag else ''}.so")
     srcs = [os.path.join(EMUL_DIR, f) for f in ("ur5sim_simt.cpp", "ur5sim_simt_many.cpp")]
-    deps = srcs + [os.path.join(EMUL_DIR, "ur5_simt_shim.h")] + [
-        os.path.join(ROOT, "mujoco_rl_ur5_amd", "csrc", f) for f in ("ur5_engine.h", "ur5sim_host.h", "ur5_devmodel.h", "ur5_raster.h", "ur5_many_names.h")]
+    deps = srcs + [os.path.join(EMUL_DIR, "ur5_simt_shim.h")] + _engine_sources()
     if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(s) for s in deps):
         os.makedirs(os.path.dirname(lib), exist_ok=True)
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-I" + EMUL_DIR, *extra, "-o", lib] + srcs)
