@@ -191,6 +191,8 @@ struct Ur5Launch {
   long long rule_gid0, rule_ntotal;   // global id of scene 0 of this handle, scenes of the whole job (episode seeds: base + gid + ntotal * episode)
   uint64_t rule_base_seed;
   double rule_plate[8];         // plate: half width in x, centre y, half width in y, lowest / highest z of an object that counts as "on the plate"; grasp z; fallback x, y
+  const int* step_cap;          // test hook, optional [n]: the scene stops after this many physics steps of the launch (capped replay: the same attempt cut off at
+                                // several step counts shows WHEN two implementations part; include/ur5sim_test.h ur5_set_step_cap_dev)
   double* action_out;           // optional [rounds][n][8]: the action records the rule produced (x y z rot skip box-found - -), for the caller's outcome records
 };
 #ifndef UR5_MANY

@@ -420,7 +420,7 @@ template <class real, int NV_> struct Lds {
 #endif
   int status, solver_iters, ncon_max, badstate;
   real pid_dt;
-  int contacts_enabled, last_steps, total_steps;
+  int contacts_enabled, last_steps, total_steps, step_cap;
   // the arrays that live in the Hessian's tail in the six-object image (TAIL), at their own address otherwise
 #ifndef UR5_MANY
   UR5_FN real (*tw_())[6] { if constexpr (TAIL) return reinterpret_cast<real (*)[6]>(H + TAIL_TW); else return tw; }
@@ -509,9 +509,9 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
   }
 #endif
 
-  UR5_FN void load(const double* rec, real dt, int con) {
+  UR5_FN void load(const double* rec, real dt, int con, int step_cap = 0x7fffffff) {
     PAR(i, UR5_REC_STRIDE) S.rec[i] = (real)rec[i];
-    if (UR5_LANE == 0) { S.pid_dt = dt; S.contacts_enabled = con; S.last_steps = 0; S.total_steps = 0; }
+    if (UR5_LANE == 0) { S.pid_dt = dt; S.contacts_enabled = con; S.last_steps = 0; S.total_steps = 0; S.step_cap = step_cap; }
     if (UR5_LANE == 0) { S.status = 0; S.solver_iters = 0; S.ncon_max = 0; S.ncon = 0; S.nsr = 0; S.badstate = 0; }
 #ifndef UR5_MANY
     if (UR5_LANE == 0) S.nsup = -1;

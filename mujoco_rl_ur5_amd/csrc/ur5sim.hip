@@ -31,7 +31,7 @@ __global__ void UR5_KERNEL_ATTR(GS) ur5_run_kernel(double* __restrict__ rec, Ur5
   const bool live = present && !(P.op == UR5_OP_STAY && P.max_steps[env] <= 0);
   ur5::Engine<double, NV, GS> eng;
   double* r = rec + (size_t)(live ? env : 0) * UR5_REC_STRIDE;
-  if (live) eng.load(r, P.pid_dt, P.contacts_enabled);
+  if (live) eng.load(r, P.pid_dt, P.contacts_enabled, P.step_cap ? P.step_cap[env] : 0x7fffffff);
 #ifdef UR5_MANY
   eng.set_hess(P.hess + (size_t)env * UR5_HESS_STRIDE);
 #endif

@@ -429,6 +429,7 @@ struct ur5_sim {
   unsigned* d_mask = nullptr;
   double *d_target = nullptr, *d_tol = nullptr, *d_debug = nullptr, *d_hess = nullptr, *d_qpos0 = nullptr;
   void* d_gpose = nullptr;        // render: per-scene geom poses + screen boxes (HIP backend)
+  const int* d_step_cap = nullptr;   // test hook (ur5_set_step_cap_dev): caller-owned [n] physics-step caps of the scripted launches, NULL = none
   const int* d_order = nullptr;   // dispatch order of the scripted launches (ur5_set_order_dev), NULL = scene order; points at d_order_buf
   int* d_order_buf = nullptr;     // handle-owned copy, made by an ASYNCHRONOUS device-to-device copy on the handle's stream: the caller's buffer must stay valid (and unmodified) until the work
                                   // queued on that stream so far has run (include/ur5sim.h); same-stream callers (ur5_set_stream) have nothing to do
@@ -463,6 +464,7 @@ static Ur5Launch base_launch(ur5_sim* h, int op) {
   P.op = op; P.n_env = h->n; P.contacts_enabled = h->contacts_enabled; P.pid_dt = h->pid_dt; P.table_height = 0.91;
   P.hess = h->d_hess;
   P.order = (op == UR5_OP_GRASP || op == UR5_OP_STAY) ? h->d_order : nullptr;
+  P.step_cap = op == UR5_OP_GRASP ? h->d_step_cap : nullptr;
 #ifdef UR5_PROFILE
   if (!h->d_debug) h->d_debug = (double*)be_alloc(h, (size_t)h->n * UR5_DEBUG_STRIDE * 8);
   P.debug = h->d_debug;
@@ -507,7 +509,7 @@ int ur5m_ik(ur5_sim* h, const double* xyz, double* q5, int* result);
 int ur5m_render_dev(ur5_sim* h, int camera_id, int width, int height, int depth_mode, uint8_t* rgb_dev, float* depth_dev);
 int ur5m_render(ur5_sim* h, int camera_id, int width, int height, int depth_mode, uint8_t* rgb, float* depth);
 int ur5m_sync(ur5_sim* h); int ur5m_set_order_dev(ur5_sim* h, const int* order_dev); int ur5m_set_stream(ur5_sim* h, void* s, int external); double ur5m_last_launch_ms(ur5_sim* h); void* ur5m_state_device_ptr(ur5_sim* h);
-int ur5m_forward_debug(ur5_sim* h, double* out); int ur5m_body_xpos(ur5_sim* h, double* out); int ur5m_profile_read(ur5_sim* h, double* out);
+int ur5m_forward_debug(ur5_sim* h, double* out); int ur5m_set_step_cap_dev(ur5_sim* h, const int* cap_dev); int ur5m_body_xpos(ur5_sim* h, double* out); int ur5m_profile_read(ur5_sim* h, double* out);
 }
 #endif
 
@@ -868,6 +870,12 @@ double ur5_kernel_ms_total(ur5_sim* h) {
 void* ur5_state_device_ptr(ur5_sim* h) {
   UR5_FWD(state_device_ptr, (h)); return h->d_rec; }
 
+int ur5_set_step_cap_dev(ur5_sim* h, const int* cap_dev) {
+  UR5_FWD(set_step_cap_dev, (h, cap_dev));
+  if (!h) return ur5host::fail(UR5_ERR_ARG, "ur5_set_step_cap_dev: NULL handle");
+  h->d_step_cap = cap_dev;   // the caller keeps the buffer alive (and unchanged) while launches that use it are in flight
+  return 0;
+}
 int ur5_forward_debug(ur5_sim* h, double* out) {
   UR5_FWD(forward_debug, (h, out));
   using namespace ur5host;

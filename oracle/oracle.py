@@ -48,6 +48,9 @@ def lib():
         L.ur5o_set_ctrl.argtypes = [vp, dp]
         L.ur5o_get_ctrl.argtypes = [vp, dp]
         L.ur5o_forward.argtypes = [vp]
+        L.ur5o_set_checkpoints.argtypes = [vp, ip, C.c_int]
+        L.ur5o_get_checkpoints.argtypes = [vp, dp]
+        L.ur5o_get_checkpoints.restype = C.c_int
         L.ur5o_bench_pile_aim.argtypes = [vp, C.c_int, C.c_int, dp]
         L.ur5o_bench_pile_aim.restype = C.c_int
         L.ur5o_newton_trace.argtypes = [vp, C.c_int]
@@ -278,6 +281,18 @@ class Oracle:
     @property
     def solver_iter_last(self):
         return lib().ur5o_solver_iter_last(self._h)
+
+    def set_checkpoints(self, steps):
+        """Record qpos after these numbers of steps (ascending), counted from now (test hook of ur5_oracle.cpp Sim::step)."""
+        a = np.ascontiguousarray(steps, dtype=np.int32)
+        lib().ur5o_set_checkpoints(self._h, a.ctypes.data_as(C.POINTER(C.c_int)), len(a))
+
+    def get_checkpoints(self):
+        """qpos [k, nq] of the checkpoints reached so far."""
+        k = lib().ur5o_get_checkpoints(self._h, None)
+        out = np.zeros((max(k, 1), self.model.nq))
+        lib().ur5o_get_checkpoints(self._h, _dp(out))
+        return out[:k]
 
     def bench_pile_aim(self, g, r=0):
         """bench.py's pile aiming rule on the oracle's current state (ur5_oracle.cpp bench_pile_aim): (xy, rotation index)."""

@@ -1419,6 +1419,10 @@ struct Sim {
   // bench.py's CPU legs bound their sample by wall time: past the deadline a step does nothing, so the scripts of the scenes in flight run out quickly
   // (their loops end on max_steps) and the leg returns; the steps taken before the deadline are counted
   const std::atomic<bool>* stop_flag = nullptr;
+  // test hook (ur5o_set_checkpoints): qpos after the given numbers of steps from the moment the hook was armed -- the trajectory samples of tools/pile_divergence_time.py
+  std::vector<int> ckpt_steps;
+  std::vector<std::vector<double>> ckpt_qpos;
+  long ckpt_base = 0;
   void step() {  // sim.step(), MujocoController.py:379
     if (stop_flag && stop_flag->load(std::memory_order_relaxed)) return;
     forward();
@@ -1426,6 +1430,7 @@ struct Sim {
     integrate();
     total_steps++;
     if (state_is_bad()) { reset_data(); bad_state_resets++; }
+    if (ckpt_qpos.size() < ckpt_steps.size() && total_steps - ckpt_base == ckpt_steps[ckpt_qpos.size()]) ckpt_qpos.push_back(qpos);
   }
 
   // ------------------------------------------------------------------ controller layer
@@ -1994,6 +1999,13 @@ long ur5o_batch(const void* blob, size_t nbytes, int ee_body, int base_body, int
   if (attempts_out) *attempts_out = attempts.load();
   if (success_out) *success_out = success.load();
   return steps.load();
+}
+// checkpoints (ascending step counts, counted from now): ur5o_get_checkpoints copies the qpos rows recorded so far, returns their number
+void ur5o_set_checkpoints(void* h, const int* steps, int n) { Sim* s = (Sim*)h; s->ckpt_steps.assign(steps, steps + n); s->ckpt_qpos.clear(); s->ckpt_base = s->total_steps; }
+int ur5o_get_checkpoints(void* h, double* out) {
+  Sim* s = (Sim*)h;
+  for (size_t k = 0; k < s->ckpt_qpos.size(); k++) if (out) memcpy(out + k * s->nq, s->ckpt_qpos[k].data(), 8ull * s->nq);
+  return (int)s->ckpt_qpos.size();
 }
 int ur5o_bench_pile_aim(void* h, int g, int r, double* xyz) { return bench_pile_aim(*(Sim*)h, g, r, xyz); }
 int ur5o_grasp_attempt(void* h, const double* xyz, int rot, int check_mode, double table_height, int* phase_steps, int* phase_result) {

@@ -38,7 +38,7 @@ template <int NV> static void run_all(ur5_sim* h, const Ur5Launch& P) {
     ur5_emul_lds = lds;
     ur5_emul_model = h->dm;
     ur5::Engine<double, NV> eng;
-    eng.load(h->d_rec + (size_t)e * UR5_REC_STRIDE, P.pid_dt, P.contacts_enabled);
+    eng.load(h->d_rec + (size_t)e * UR5_REC_STRIDE, P.pid_dt, P.contacts_enabled, P.step_cap ? P.step_cap[e] : 0x7fffffff);
 #ifdef UR5_MANY
     eng.set_hess(P.hess + (size_t)e * UR5_HESS_STRIDE);
 #endif

@@ -146,7 +146,7 @@ template <int NV> static void kernel_body(void* a) {
   const bool live = present && !(P.op == UR5_OP_STAY && P.max_steps[env] <= 0);
   ur5::Engine<double, NV, UR5_NT> eng;
   double* r = K.rec + (size_t)(live ? env : 0) * UR5_REC_STRIDE;
-  if (live) eng.load(r, P.pid_dt, P.contacts_enabled);
+  if (live) eng.load(r, P.pid_dt, P.contacts_enabled, P.step_cap ? P.step_cap[env] : 0x7fffffff);
 #ifdef UR5_MANY
   eng.set_hess(P.hess + (size_t)env * UR5_HESS_STRIDE);
 #endif

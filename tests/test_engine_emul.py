@@ -218,3 +218,34 @@ def test_random_agent_attempts_take_the_same_exits_as_the_oracle(model_it1, emul
     assert any(c[3] == 2 for c in codes) and any(c[3] == 0 for c in codes)
     codes = check_random_agent_parity(BatchSim, load_model("/UR5+gripper/UR5gripper_2_finger.xml"), 10, lib_path=emul_lib)   # 3 boxes + 3 spheres
     assert any(c[3] == 2 for c in codes)
+
+
+def test_capped_replay_samples_the_attempt_s_trajectory(model_it1, emul_lib):
+    """Test hook ur5_set_step_cap_dev (include/ur5sim_test.h), the instrument of the pile divergence-time statistic (tools/gpu_many_divergence.py): copies of one scene
+    frozen after 150 / 600 / 1500 physics steps of the same grasp attempt hold the oracle's qpos after exactly that many steps of its attempt (Oracle.set_checkpoints),
+    a copy whose cap lies beyond the attempt's end is the uncapped result, and the hook switched off changes nothing."""
+    from oracle.oracle import Oracle
+    caps = np.array([150, 600, 1500, 10 ** 6], dtype=np.int32)
+    n = len(caps)
+    sim = BatchSim(model_it1, n, lib_path=emul_lib)
+    sim.reset(np.full(n, 23, dtype=np.uint64), 1, 1000.0)
+    st = sim.get_state()
+    before = sim.counters()["total_steps"].copy()                            # the settle steps of the reset
+    objs = st["qpos"][0][8:].reshape(-1, 7)
+    act = np.array([objs[1, 0], -0.6 + objs[1, 1], 0.91])
+    sim.set_step_cap_dev(caps.ctypes.data)
+    rew, ps, pr = sim.grasp_attempt(np.tile(act, (n, 1)), rot=2, check_mode=1)
+    q = sim.get_state()["qpos"]
+    taken = sim.counters()["total_steps"] - before
+    o = Oracle(model_it1)
+    o.reset(23, 1, True)
+    o.set_checkpoints(caps[:3])
+    r, pso, pro = o.grasp_attempt(act, 2, 1)
+    ck = o.get_checkpoints()
+    assert taken[:3].tolist() == caps[:3].tolist() and taken[3] > 1500
+    assert len(ck) == 3 and np.abs(q[:3] - ck).max() < 1e-9, np.abs(q[:3] - ck).max(axis=1)
+    assert rew[3] == r and ps[3].tolist() == pso.tolist() and np.abs(q[3] - o.get_state()["qpos"]).max() < 1e-9
+    sim.set_step_cap_dev(None)
+    sim.reset(np.full(n, 23, dtype=np.uint64), 1, 1000.0)
+    rew2, ps2, _ = sim.grasp_attempt(np.tile(act, (n, 1)), rot=2, check_mode=1)
+    assert rew2.tolist() == [int(r)] * n and all(ps2[k].tolist() == pso.tolist() for k in range(n))

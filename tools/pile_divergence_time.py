@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""WHEN do two correct implementations of a pile's grasp attempt part?  (round-4 verdict 3c; CPU side, reads tools/gpu_many_dump.py's states and
+tools/gpu_many_divergence.py's capped replays of the HIP kernel.)
+
+An END-bit statistic (profiles/r04_q_pile_chaos_floor_*.json) cannot see a kernel bug that costs 1 % agreement. This one measures the trajectory: per scene the first
+checkpoint (physics steps into the attempt) at which max |qpos_a - qpos_b| exceeds 1e-6, for the HIP kernel against the oracle and for the oracle against its own
+rounding-level twins (contact list reversed; one coordinate moved by 1 ulp) -- the same perturbation class as two texts of one algorithm. A kernel that is one more
+member of the oracle's rounding family parts from it no EARLIER than the twins part from each other.
+    python tools/pile_divergence_time.py <states.npz> <divergence_gpu.npz> [threads=8] [limit] > profiles/r05_pile_divergence_time.json"""
+import json, os, sys, time
+from concurrent.futures import ThreadPoolExecutor
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from mujoco_rl_ur5_amd.model import load_model
+from oracle.oracle import Oracle
+
+D = {k: v for k, v in np.load(sys.argv[1]).items()}
+threads = int(sys.argv[3]) if len(sys.argv) > 3 else (os.cpu_count() or 8)
+CACHE = sys.argv[1].replace(".npz", "_oracle_trajectories.npz")       # the oracle side is 45 min of CPU and does not depend on the kernel: kept next to the states
+if sys.argv[2] == "oracle-only":                                      # python tools/pile_divergence_time.py <states.npz> oracle-only [threads] [limit]: fill the cache, no GPU file needed
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    G = None
+    CK = [5, 10, 20, 40, 80, 120, 160, 240, 320, 400, 480, 560, 640, 800, 1000, 1200, 1500, 1800]     # = tools/gpu_many_divergence.py CHECKPOINTS
+    n = min(int(sys.argv[4]), len(D["sel"])) if len(sys.argv) > 4 else len(D["sel"])
+else:
+    G = {k: v for k, v in np.load(sys.argv[2]).items()}
+    n = min(int(sys.argv[4]), len(G["qpos"])) if len(sys.argv) > 4 else len(G["qpos"])
+    CK = G["checkpoints"].tolist()
+m = load_model("/UR5+gripper/UR5gripper_2_finger_many_objects.xml")
+VARIANTS = ("base", "reversed_contacts", "one_ulp")
+THRESH = 1e-6
+
+
+def one(job):
+    e, variant = job
+    o = Oracle(m)
+    q = D["qpos"][e].copy()
+    if variant == "one_ulp":
+        q[8] = np.nextafter(q[8], np.inf)
+    o.set_state(qpos=q, qvel=D["qvel"][e], warmstart=D["warmstart"][e], pid=D["pid"][e])
+    o.set_ctrl(D["ctrl"][e])
+    if variant == "reversed_contacts":
+        o.set_contact_order(1)
+    o.set_checkpoints(CK)
+    r, ps, pr = o.grasp_attempt(D["acts"][e], int(D["rots"][e]), 0)
+    c = o.get_checkpoints()
+    full = np.full((len(CK), m.nq), np.nan)
+    full[:len(c)] = c
+    return full, int(r), int(ps.sum())
+
+
+t0 = time.time()
+cached = np.load(CACHE) if os.path.exists(CACHE) else None
+if cached is not None and cached["checkpoints"].tolist() == CK and len(cached["base"]) >= n and np.array_equal(cached["qpos0"][:n], D["qpos"][:n]):
+    T = {v: cached[v][:n] for v in VARIANTS}
+else:
+    jobs = [(e, v) for e in range(n) for v in VARIANTS]
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        res = list(ex.map(one, jobs))
+    T = {v: np.stack([res[e * 3 + k][0] for e in range(n)]) for k, v in enumerate(VARIANTS)}     # [n, K, nq]
+    np.savez_compressed(CACHE, checkpoints=np.array(CK), qpos0=D["qpos"][:n], **T)
+if G is None:
+    print(json.dumps(dict(scenes=n, oracle_seconds=round(time.time() - t0, 1), cache=CACHE)))
+    sys.exit(0)
+gpu = G["qpos"][:n].astype(np.float64).copy()
+gpu[G["steps_taken"][:n] != np.array(CK)[None, :]] = np.nan                                   # the attempt ended before that cap: no sample (as on the oracle)
+
+
+def first_divergence(A, B):
+    """per scene: index of the first checkpoint with max|dq| > THRESH (len(CK) = never within the samples both have), and the largest difference at the first checkpoint"""
+    d = np.nanmax(np.abs(A - B), axis=2)                                                      # [n, K]; NaN where either trajectory has no sample
+    both = ~np.isnan(A[:, :, 0]) & ~np.isnan(B[:, :, 0])
+    idx = np.full(len(d), len(CK))
+    for e in range(len(d)):
+        bad = np.flatnonzero(both[e] & (d[e] > THRESH))
+        if len(bad): idx[e] = bad[0]
+    return idx, d
+
+
+def summary(idx):
+    steps = np.array(CK + [CK[-1] * 2])[idx]                                                  # "never" is booked as beyond the last checkpoint
+    return dict(median_steps=float(np.median(steps)), quartiles=[float(np.percentile(steps, 25)), float(np.percentile(steps, 75))], mean_checkpoint_index=float(idx.mean()),
+                never_within_the_samples=int((idx == len(CK)).sum()), histogram_by_checkpoint={str(CK[k]) if k < len(CK) else "never": int((idx == k).sum()) for k in range(len(CK) + 1)})
+
+
+pairs = {"kernel_vs_oracle": (gpu, T["base"]), "kernel_vs_oracle_reversed_contacts": (gpu, T["reversed_contacts"]), "kernel_vs_oracle_one_ulp": (gpu, T["one_ulp"]),
+         "oracle_vs_oracle_reversed_contacts": (T["base"], T["reversed_contacts"]), "oracle_vs_oracle_one_ulp": (T["base"], T["one_ulp"]),
+         "oracle_reversed_vs_oracle_one_ulp": (T["reversed_contacts"], T["one_ulp"])}
+out = dict(scenes=n, checkpoints=CK, threshold=THRESH, oracle_seconds=round(time.time() - t0, 1), threads=threads)
+idxs = {}
+for name, (A, B) in pairs.items():
+    idxs[name], d = first_divergence(A, B)
+    out[name] = summary(idxs[name])
+    out[name]["max_abs_difference_at_the_first_checkpoint_median"] = float(np.nanmedian(d[:, 0]))
+k_med = np.median([out[k]["median_steps"] for k in pairs if k.startswith("kernel")])
+o_med = np.median([out[k]["median_steps"] for k in pairs if k.startswith("oracle")])
+out["summary"] = dict(kernel_median_steps_to_divergence=float(k_med), twins_median_steps_to_divergence=float(o_med), kernel_over_twins=float(k_med / o_med),
+                      kernel_parts_no_earlier_than_0_9_x_the_twins=bool(k_med >= 0.9 * o_med),
+                      note="first checkpoint with max|dqpos| > 1e-6; every run starts from the HIP kernel's settled state of the same scenes; the kernel's own run-to-run result is bit-identical")
+print(json.dumps(out))
