@@ -412,7 +412,7 @@ def strong_scaling_points(torch, dist, sharding, model, dev, dev_id, args):
     pts = []
     for n in (2048, 1024, 512):
         try:
-            k = 0 if args.fused_rounds == 0 else (4 if n >= 2048 else 8)            # the default of a shard of that size
+            k = 0 if args.fused_rounds == 0 else 8                                  # the default of a shard below 4096 scenes
             job = Job(torch, dist, sharding, model, "it1", "aimed", n, n, 0, 1, dev, dev_id, args.groups, 20)
             job.run_rounds(0, 2, None, k)
             dt, c0, c1, _, _ = job.timed(2, 18, None, k)
@@ -437,7 +437,7 @@ def main():
     ap.add_argument("--groups", type=int, default=2, help="scene groups per GPU, one engine handle + HIP stream each, rounds pipelined (1 = one handle)")
     ap.add_argument("--fused-rounds", type=int, default=-1, help="headline workload: K consecutive rounds of a scene per launch, the aiming rule evaluated in the kernel, no lock "
                     "step between scenes (ur5_grasp_rounds_dev; per-scene results bit-identical to K lock-step rounds). 0 = one launch per round, re-aimed on the device by torch; "
-                    "default: one episode (4 rounds) per launch when the chip is full (>= 2048 scenes per GPU), two episodes (8) for smaller shards, where a launch's tail is what idles the chip")
+                    "default: one episode (4 rounds) per launch at 4096 scenes per GPU and more (the chip is full), two episodes (8) for smaller shards, where a launch's tail is what idles the chip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the uniform-rule figure and the it4 / many sub-results (N = 1 only)")
     ap.add_argument("--sub", choices=("it4", "many", "many4096", "dqn", "dqn2048"), default=None,
@@ -513,7 +513,7 @@ def main():
     groups, G, n_g, run_rounds, timed = job.groups, job.G, job.n_g, job.run_rounds, job.timed
 
     if args.fused_rounds < 0:
-        args.fused_rounds = 4 if n_local >= 2048 else 8
+        args.fused_rounds = 4 if n_local >= 4096 else 8                         # same-box sweep: profiles/r05_j_headline_groups_and_rounds_per_launch.log
     fused = args.fused_rounds if args.rule == "aimed" else 0
     run_rounds(0, args.warmup, None, fused)
     elapsed, c0, c1, kernel_ms, gathered = timed(args.warmup, rounds, None, fused)
