@@ -375,17 +375,50 @@ def test_pile_grasp_bits_against_the_oracle_on_gpu(model_many):
     rew, ps, pr = sim.grasp_attempt(acts, rot=rots, check_mode=0)
     assert sim.counters()["status"].max() == 0
 
-    def one(e):
+    CK = [10, 40, 120, 240, 400, 640, 1000]                                   # physics steps into the attempt at which trajectories are compared (below)
+    NT = 8                                                                    # scenes that also get a rounding-level twin of the oracle
+
+    def one(job):
+        e, twin = job
         o = Oracle(model_many)
         o.set_state(qpos=st["qpos"][e], qvel=st["qvel"][e], warmstart=st["warmstart"][e], pid=st["pid"][e])
         o.set_ctrl(ctrl[e])
+        if twin:
+            o.set_contact_order(1)                                            # the same contacts in reversed order: only the association order of the sums changes
+        o.set_checkpoints(CK)
         r, pso, pro = o.grasp_attempt(acts[e], int(rots[e]), 0)
-        return r, pro
-    with ThreadPoolExecutor(max_workers=min(n, os.cpu_count() or 8)) as ex:
-        res = list(ex.map(one, sel))
+        ck = np.full((len(CK), model_many.nq), np.nan)
+        got = o.get_checkpoints()
+        ck[:len(got)] = got
+        return r, pro, ck
+    with ThreadPoolExecutor(max_workers=min(n + NT, os.cpu_count() or 8)) as ex:
+        allres = list(ex.map(one, [(e, False) for e in sel] + [(e, True) for e in sel[:NT]]))
+    res = [(r, pro) for r, pro, _ in allres[:n]]
     orew = [r for r, _ in res]
     bits = sum(int(r == rew[e]) for e, (r, _) in zip(sel, res))
     codes = sum(int(pro.tolist() == pr[e].tolist()) for e, (_, pro) in zip(sel, res))
+    # WHEN do they part (round-4 verdict 3c)? The end bit cannot see a kernel bug that costs 1 % agreement; the trajectory can. The first NT scenes replayed on the kernel
+    # with step caps (ur5_set_step_cap_dev: one frozen copy per checkpoint) against the oracle's samples at the same steps, next to the oracle against its own twin:
+    # index of the first checkpoint with max |dqpos| > 1e-6. A kernel of the oracle's rounding family parts from it about when the twin does -- not checkpoints earlier.
+    import torch
+    K = len(CK)
+    cap_sim = BatchSim(model_many, NT * K)
+    rep = lambda a: np.repeat(a[sel[:NT]], K, axis=0)
+    cap_sim.set_state(qpos=rep(st["qpos"]), qvel=rep(st["qvel"]), warmstart=rep(st["warmstart"]), pid=rep(st["pid"]))
+    cap_sim.set_ctrl(rep(ctrl))
+    caps = torch.tensor(np.tile(CK, NT), dtype=torch.int32, device="cuda")
+    cap_sim.set_step_cap_dev(caps.data_ptr())
+    cap_sim.grasp_attempt(rep(acts), rot=rep(rots), check_mode=0)
+    gq = cap_sim.get_state()["qpos"].reshape(NT, K, -1)
+
+    def first(a, b):
+        d = np.abs(a - b).max(axis=1)                                         # NaN where the oracle's attempt ended before that checkpoint
+        bad = np.flatnonzero(d > 1e-6)
+        return int(bad[0]) if len(bad) else K
+    kernel_idx = [first(gq[i], allres[i][2]) for i in range(NT)]
+    twin_idx = [first(allres[n + i][2], allres[i][2]) for i in range(NT)]
+    assert np.abs(gq[:, 0] - np.stack([allres[i][2][0] for i in range(NT)])).max() < 1e-7, "ten steps in, kernel and oracle still agree to rounding"
+    assert np.median(kernel_idx) >= np.median(twin_idx) - 1 and min(kernel_idx) >= 1, (kernel_idx, twin_idx)
     assert sum(orew) >= 2, orew                                               # a statistic with positives (28 % in the 256-scene run)
     # Piles are chaotic, and round 4 measured how chaotic (tools/pile_chaos_floor.py, profiles/r04_pile_chaos_floor_256of3072.json): the ORACLE agrees with its own
     # rounding-level twins -- the same contacts in reversed order, one coordinate moved by 1 ulp -- on 94.5-96.1 % of the grasp bits and 89-91 % of the result codes of

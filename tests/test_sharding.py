@@ -224,7 +224,7 @@ def test_two_ranks_are_one_agent_on_gpu(tmp_path):
     assert b0["ring"] == b1["ring"] == a["ring"] and b0["owned"] + b1["owned"] == 40
 
 
-def _gpu_worker(rank, world, port, n_total, out):
+def _gpu_worker(rank, world, port, n_total, out, fused=0):
     """One rank of the real multi-GPU path, except that every rank sits on device 0 (the test box has one GPU) and the collective runs over
     gloo: bench.py's round driver on the rank's shard with the real libur5sim.so."""
     import torch
@@ -247,7 +247,14 @@ def _gpu_worker(rank, world, port, n_total, out):
     wl = bench.It1Rounds(torch, m, sim, dev, lo, hi - lo, n_total, "aimed")
     ids = torch.arange(lo, hi, dtype=torch.int32, device=dev)
     recs = []
-    for r in range(5):                                                   # crosses an episode boundary for every scene
+    if fused:                                                            # the five rounds in ONE launch per rank, the rule evaluated in the kernel (ur5_grasp_rounds_dev)
+        rew = torch.zeros((5, hi - lo), dtype=torch.int32, device=dev)
+        act, pixel = wl.launch_rounds(0, 5, rew)
+        sim.sync()
+        for r in range(5):
+            rec = torch.stack([ids, pixel[r], act[r, :, 3].to(torch.int32), rew[r]], dim=1)
+            recs.append(sharding.gather_outcomes(rec).cpu().numpy())
+    for r in range(0 if fused else 5):                                   # crosses an episode boundary for every scene
         rew = torch.zeros(hi - lo, dtype=torch.int32, device=dev)
         act, pixel = wl.launch(r, rew)
         rec = torch.stack([ids, pixel, act[:, 3].to(torch.int32), rew], dim=1)
@@ -279,6 +286,12 @@ def test_two_ranks_on_one_gpu_equal_one_rank_bit_for_bit(tmp_path):
     a, b = np.load(one), np.load(two)
     assert a["recs"].shape == (5, n_total, 4) and np.array_equal(a["recs"], b["recs"])
     assert np.array_equal(a["state"], b["state"])
+    # ... and the same five rounds fused into one launch per rank (no lock step between scenes): two ranks == one rank == the lock-step rounds, records and states
+    f1, f2 = str(tmp_path / "f1.npz"), str(tmp_path / "f2.npz")
+    mp.spawn(_gpu_worker, args=(1, port + 2, n_total, f1, 1), nprocs=1, join=True)
+    mp.spawn(_gpu_worker, args=(2, port + 3, n_total, f2, 1), nprocs=2, join=True)
+    c, d = np.load(f1), np.load(f2)
+    assert np.array_equal(c["recs"], a["recs"]) and np.array_equal(d["recs"], a["recs"]) and np.array_equal(c["state"], a["state"]) and np.array_equal(d["state"], a["state"])
     assert a["recs"][:, :, 1].max() > 0 and set(np.unique(a["recs"][:, :, 3])) == {0, 1}      # pixel field filled, both outcomes occur
 
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # final evidence of a round (one gpurun call): GPU tests, smoke, the driver's bench command, rocprofv3 stats + PMC passes of headline / many / it4 / dqn, pile states for the CPU-side agreement run
 set -u
-TAG=${1:-final_r04}; PFX=${2:-r04_k}
+TAG=${1:-final}; PFX=${2:-r05_z}
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
@@ -12,3 +12,9 @@ python -c "import __graft_entry__ as g; g.smoke()" > $OUT/${PFX}_smoke.log 2>&1;
 bash tools/gpu_evidence.sh $TAG/ev $PFX > $OUT/evidence.log 2>&1; tail -3 $OUT/evidence.log
 bash tools/gpu_evidence_extras.sh $TAG/evx $PFX > $OUT/evidence_extras.log 2>&1; tail -3 $OUT/evidence_extras.log
 timeout 600 python tools/gpu_many_dump.py 3072 256 $OUT/${PFX}_many_states.npz > $OUT/${PFX}_many_determinism_3072piles.json 2> $OUT/many_dump.err; cat $OUT/${PFX}_many_determinism_3072piles.json
+# round 5: the RCCL path on this one GPU (one-rank nccl process group, every collective issued), grasp agreement of the FINAL small-scene kernels against the oracle on the
+# box's host cores, and the capped replays of the dumped piles for the CPU-side divergence-time statistic (tools/pile_divergence_time.py)
+timeout 300 python bench.py --steps 8 --warmup 4 --no-extras --no-cpu-baseline --collectives --backend nccl > $OUT/${PFX}_bench_collectives_nccl.json 2> $OUT/bench_collectives.err; cut -c1-300 $OUT/${PFX}_bench_collectives_nccl.json
+timeout 600 python tools/gpu_agreement.py 1024 it1_4box 2>/dev/null | tail -1 > $OUT/${PFX}_grasp_agreement_1024_it1.json; cut -c1-400 $OUT/${PFX}_grasp_agreement_1024_it1.json
+timeout 600 python tools/gpu_agreement.py 768 /UR5+gripper/UR5gripper_2_finger.xml 2>/dev/null | tail -1 > $OUT/${PFX}_grasp_agreement_768_2f.json; cut -c1-400 $OUT/${PFX}_grasp_agreement_768_2f.json
+timeout 300 python tools/gpu_many_divergence.py $OUT/${PFX}_many_states.npz $OUT/${PFX}_many_states_divergence_gpu.npz 2>&1 | grep -v amdgpu.ids | tail -1 > $OUT/${PFX}_many_divergence_gpu.json; cat $OUT/${PFX}_many_divergence_gpu.json

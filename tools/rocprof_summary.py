@@ -23,9 +23,9 @@ def main():
     d, bench_json, prefix = sys.argv[1], sys.argv[2], sys.argv[3]
     bench = json.loads([l for l in open(bench_json) if l.startswith("{")][-1])
     steps = bench["steps"]
-    lpr = int(bench["roofline"].get("launches_per_round", 1))            # one engine launch per scene group and round
+    lpr = float(bench["roofline"].get("launches_per_round", 1))          # engine launches per round: scene groups / rounds per launch (0.5 = two groups, four rounds per launch)
     env_steps = bench["roofline"].get("env_steps_per_launch", bench["roofline"].get("env_steps_per_round"))
-    launches = steps * lpr
+    launches = max(1, int(round(steps * lpr)))
     # kernel stats
     for p in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
         rs = rows(p)
