@@ -365,6 +365,14 @@ def rendered_sub_result(torch, dist, sharding, dev, dev_id, workload, n, rounds,
            "roofline_frac": steps * 2 * words * 8 / dt / 8e12, "bytes_per_env_step": 2 * words * 8,
            "kernel": "ur5m_run_kernel<248>" if many else "ur5_run_kernel<44>"}
     job.close()
+    # counter traffic of this kernel, from the round's rocprofv3 PMC passes of `bench.py --sub many` (tools/gpu_evidence_extras.sh): not measured in this run
+    tp = os.path.join(ROOT, "profiles", "many_hbm_traffic_latest.json")
+    if many and os.path.exists(tp):
+        with open(tp) as f:
+            tj = json.load(f)
+        out["hbm_bytes_per_env_step_from_profiles"] = tj["hbm_bytes_per_env_step"]
+        out["traffic_over_algorithmic"] = tj["hbm_bytes_per_env_step"] / (2 * words * 8)
+        out["traffic_source"] = f"profiles/many_hbm_traffic_latest.json ({tj.get('source', '')}): 2 x FETCH_SIZE + WRITE_SIZE per env-step, separate PMC passes; NOT measured in this run"
     if with_cpu:
         out["cpu_baseline"] = cpu_baseline(model, 20.0 if many else 8.0, workload)
     return out

@@ -48,6 +48,7 @@ static const Ur5DevModel* ur5_emul_model = nullptr;
 #define UR5_MODEL (*ur5_emul_model)
 #define PAR(i, n) for (int i = 0; i < (n); ++i)
 #define SYNC() ((void)0)
+#define SYNC1() ((void)0)
 #define WAVE_SUM(v) (v)
 #define WAVE_MAX(v) (v)
 #define UR5_LANE 0
@@ -105,10 +106,14 @@ __constant__ Ur5DevModel ur5_cmodel;
 // executes a wave's LDS instructions in issue order, so all that is needed is that the COMPILER keeps the accesses on their side of
 // the line: wavefront-scope fences and a scheduling barrier, no instruction. __syncthreads() in a 64-thread workgroup costs an
 // `s_waitcnt lgkmcnt(0)` -- a full drain of the LDS queue and of every scalar load in flight -- at each of the several hundred SYNCs of a step.
+// SYNC1: a phase boundary that only the one-wavefront unit keeps (there it is a compiler fence and costs nothing; its kernel stays as measured). In the pile unit a
+// nearby workgroup barrier already orders the accesses in question -- each site says which -- and a further s_barrier would only add a rendezvous of four wavefronts.
 #if UR5_NT == 64
 #define SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#define SYNC1() SYNC()
 #else
 #define SYNC() __syncthreads()
+#define SYNC1() ((void)0)
 #endif
 #define UR5_LANE ((int)threadIdx.x & (GS - 1))
 #define UR5_GBASE 0
