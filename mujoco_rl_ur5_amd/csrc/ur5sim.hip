@@ -43,6 +43,7 @@ __global__ void UR5_KERNEL_ATTR(GS) ur5_run_kernel(double* __restrict__ rec, Ur5
 // (several handles with the SAME model -- scene groups on separate streams -- share the copy: the upload is keyed by a hash of the struct)
 static ur5_sim* g_model_owner[64] = {nullptr};
 static uint64_t g_model_hash[64] = {0};
+static long g_model_uploads = 0;   // test hook (ur5_model_uploads): how often this unit's constant-memory model was (re-)written
 static uint64_t model_hash(const Ur5DevModel& m) {
   const unsigned char* p = reinterpret_cast<const unsigned char*>(&m);
   uint64_t h = 1469598103934665603ull;
@@ -259,11 +260,13 @@ static int be_upload_model(ur5_sim* h) {
       HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(ur5_cmodel), &h->hm, sizeof(Ur5DevModel), 0, hipMemcpyHostToDevice));
       HIPCHK(hipDeviceSynchronize());   // the copy runs on the null stream; the launches that read the model go to a non-blocking stream
       g_model_hash[h->device & 63] = h->model_hash;
+      g_model_uploads++;
     }
     g_model_owner[h->device & 63] = h;
   }
   return 0;
 }
+static long be_model_uploads() { return g_model_uploads; }
 static int be_render(ur5_sim* h, int cam, int W, int Hh, int mode, uint8_t* rgb_dev, float* depth_dev) {
   HipBackend* b = (HipBackend*)h->be;
   HIPCHK(hipSetDevice(h->device));

@@ -454,6 +454,7 @@ static int be_sync(ur5_sim* h);
 static int be_set_stream(ur5_sim* h, void* stream, int external);
 static int be_render(ur5_sim* h, int cam, int W, int Hh, int mode, uint8_t* rgb_dev, float* depth_dev);
 static int be_reset_dev(ur5_sim* h, const uint64_t* seeds_dev, const uint8_t* mask_dev, int chunks, int* max_steps_dev);
+static long be_model_uploads();
 
 namespace ur5host {
 static int pull(ur5_sim* h) { h->h_rec.resize((size_t)h->n * UR5_REC_STRIDE); return be_d2h(h, h->h_rec.data(), h->d_rec, h->h_rec.size() * 8); }
@@ -509,7 +510,7 @@ int ur5m_ik(ur5_sim* h, const double* xyz, double* q5, int* result);
 int ur5m_render_dev(ur5_sim* h, int camera_id, int width, int height, int depth_mode, uint8_t* rgb_dev, float* depth_dev);
 int ur5m_render(ur5_sim* h, int camera_id, int width, int height, int depth_mode, uint8_t* rgb, float* depth);
 int ur5m_sync(ur5_sim* h); int ur5m_set_order_dev(ur5_sim* h, const int* order_dev); int ur5m_set_stream(ur5_sim* h, void* s, int external); double ur5m_last_launch_ms(ur5_sim* h); void* ur5m_state_device_ptr(ur5_sim* h);
-int ur5m_forward_debug(ur5_sim* h, double* out); int ur5m_set_step_cap_dev(ur5_sim* h, const int* cap_dev); int ur5m_body_xpos(ur5_sim* h, double* out); int ur5m_profile_read(ur5_sim* h, double* out);
+int ur5m_forward_debug(ur5_sim* h, double* out); int ur5m_set_step_cap_dev(ur5_sim* h, const int* cap_dev); long ur5m_model_uploads(ur5_sim* h); int ur5m_body_xpos(ur5_sim* h, double* out); int ur5m_profile_read(ur5_sim* h, double* out);
 }
 #endif
 
@@ -870,6 +871,10 @@ double ur5_kernel_ms_total(ur5_sim* h) {
 void* ur5_state_device_ptr(ur5_sim* h) {
   UR5_FWD(state_device_ptr, (h)); return h->d_rec; }
 
+long ur5_model_uploads(ur5_sim* h) {
+  UR5_FWD(model_uploads, (h));
+  return be_model_uploads();
+}
 int ur5_set_step_cap_dev(ur5_sim* h, const int* cap_dev) {
   UR5_FWD(set_step_cap_dev, (h, cap_dev));
   if (!h) return ur5host::fail(UR5_ERR_ARG, "ur5_set_step_cap_dev: NULL handle");

@@ -21,7 +21,7 @@ EXPORTS = ["ur5_last_error", "ur5_create", "ur5_destroy", "ur5_num_envs", "ur5_n
            "ur5_set_state", "ur5_get_state", "ur5_set_ctrl", "ur5_get_ctrl", "ur5_step", "ur5_move_group", "ur5_stay",
            "ur5_move_ee", "ur5_ik", "ur5_grasp_attempt", "ur5_grasp_attempt_dev", "ur5_grasp_attempt_reset_dev", "ur5_grasp_rounds_dev", "ur5_sync", "ur5_set_stream", "ur5_set_order_dev", "ur5_last_launch_ms",
            "ur5_get_counters", "ur5_body_xpos", "ur5_render", "ur5_render_dev", "ur5_state_device_ptr"]
-TEST_EXPORTS = ["ur5_forward_debug", "ur5_set_step_cap_dev"]   # include/ur5sim_test.h: introspection for tests/ and tools/, not part of the boundary
+TEST_EXPORTS = ["ur5_forward_debug", "ur5_set_step_cap_dev", "ur5_model_uploads"]   # include/ur5sim_test.h: introspection for tests/ and tools/, not part of the boundary
 
 
 class Config(C.Structure):
@@ -83,6 +83,9 @@ def load(path=None):
     L.ur5_forward_debug.argtypes = [vp, dp]
     if hasattr(L, "ur5_set_step_cap_dev"):
         L.ur5_set_step_cap_dev.argtypes = [vp, vp]
+    if hasattr(L, "ur5_model_uploads"):
+        L.ur5_model_uploads.argtypes = [vp]
+        L.ur5_model_uploads.restype = C.c_long
     L.ur5_render.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint8), C.POINTER(C.c_float)]
     L.ur5_render_dev.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
     _libs[path] = L
@@ -241,6 +244,10 @@ class BatchSim:
         waits for another one's round. reward_ptr -> int32 [rounds][n], action_out_ptr -> float64 [rounds][n][8] or None (device pointers). Asynchronous."""
         self._check(self.lib.ur5_grasp_rounds_dev(self._h, C.byref(rule), int(round0), int(rounds), int(check_mode), float(table_height), C.c_void_p(reward_ptr),
                                                   C.c_void_p(action_out_ptr) if action_out_ptr else None, float(settle_ms)), "ur5_grasp_rounds_dev")
+
+    def model_uploads(self):
+        """Test hook: (re-)writes of the constant-memory model of this handle's engine unit so far (include/ur5sim_test.h)."""
+        return int(self.lib.ur5_model_uploads(self._h))
 
     def set_step_cap_dev(self, cap_ptr):
         """Test hook (include/ur5sim_test.h): int32 [n] device pointer of physics-step caps for the following grasp launches, or None."""

@@ -52,7 +52,7 @@ def build_emul(flags=(), name="libur5sim_emul.so"):
 
 def build_simt():
     """Test-only host build of the engine's DEVICE code path, one fibre per lane of a wavefront (tests/emul/ur5sim_simt.cpp)."""
-    # UR5_SIMT_FLAGS="-DUR5_MPR_W=16" pytest tests/test_engine_simt.py ... checks a build option of the engine on the wavefront emulation before it costs GPU time
+    # UR5_SIMT_FLAGS="-DUR5_PANEL_SLOT=16" pytest tests/test_engine_simt.py ... checks a build option of the engine on the wavefront emulation before it costs GPU time
     extra = os.environ.get("UR5_SIMT_FLAGS", "").split()
     tag = "".join(c if c.isalnum() else "_" for c in "".join(extra))
     lib = os.path.join(os.path.dirname(EMUL_LIB), f"libur5sim_simt{('_' + tag) if tag else ''}.so")

@@ -126,6 +126,7 @@ static int be_d2h(ur5_sim*, void* dst, const void* src, size_t bytes) { memcpy(d
 static int be_d2d_async(ur5_sim*, void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); return 0; }
 static int be_sync(ur5_sim*) { return 0; }
 static int be_set_stream(ur5_sim*, void*, int) { return 0; }
+static long be_model_uploads() { return 0; }   // (the test builds read the model through a pointer: nothing is uploaded)
 static int be_reset_dev(ur5_sim* h, const uint64_t* seeds, const uint8_t* mask, int chunks, int* max_steps) {
   for (int e = 0; e < h->n; e++) {
     const bool on = !mask || mask[e];
