@@ -36,7 +36,7 @@ typedef int ur5_pair_t;
 #define UR5_MAXG 80
 #define UR5_MAXDG 56
 #define UR5_MAXPAIR 2560
-#define UR5_MAXCON 96                              // 3072 settled + grasped piles of the reference's scene peak at 80 contacts (profiles/r04_b_many_determinism_3072piles.json);
+#define UR5_MAXCON 96                              // 3072 settled + grasped piles of the reference's scene peak at 84 contacts (profiles/r05_z_many_determinism_3072piles.json: 4 scenes above 80);
                                                    // more than 96 raises UR5_ST_CONTACT_OVERFLOW. 160 slots cost 19 KB of LDS that two scenes per CU cannot spare
 #define UR5_MAXCAND 512
 #define UR5_MAXHV 1024                             // 590 for the gripper's full hulls + 7 x 32 for the optional arm-link hulls
