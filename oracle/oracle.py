@@ -48,6 +48,7 @@ def lib():
         L.ur5o_set_ctrl.argtypes = [vp, dp]
         L.ur5o_get_ctrl.argtypes = [vp, dp]
         L.ur5o_forward.argtypes = [vp]
+        L.ur5o_set_cholesky_order.argtypes = [vp, C.c_int]
         L.ur5o_set_checkpoints.argtypes = [vp, ip, C.c_int]
         L.ur5o_get_checkpoints.argtypes = [vp, dp]
         L.ur5o_get_checkpoints.restype = C.c_int
@@ -281,6 +282,10 @@ class Oracle:
     @property
     def solver_iter_last(self):
         return lib().ur5o_solver_iter_last(self._h)
+
+    def set_cholesky_order(self, mode):
+        """Test hook: 1 = the Newton solve eliminates the dofs in reversed order (same mathematics, another rounding: a 'different text' twin)."""
+        lib().ur5o_set_cholesky_order(self._h, int(mode))
 
     def set_checkpoints(self, steps):
         """Record qpos after these numbers of steps (ascending), counted from now (test hook of ur5_oracle.cpp Sim::step)."""

@@ -1167,7 +1167,19 @@ struct Sim {
       out[i] = s2;
     }
   }
-  bool dense_cholesky_solve(std::vector<double>& A, std::vector<double>& b) const {  // A = L L^T in place (lower), b <- A^-1 b
+  // test hook (ur5o_set_cholesky_order): 1 = eliminate the dofs in REVERSED order. Mathematically the same solve; the rounding differs the way it differs between two
+  // implementations that factor in different orders (the HIP pile kernel eliminates by island and x position, this oracle by dof number) -- the "different text" twin of
+  // tools/pile_divergence_time.py, next to the summation-order and 1-ulp twins.
+  int cholesky_order = 0;
+  bool dense_cholesky_solve(std::vector<double>& A, std::vector<double>& b) const {
+    if (cholesky_order == 0) return dense_cholesky_solve_natural(A, b);
+    std::vector<double> Ap((size_t)nv * nv), bp(nv);
+    for (int i = 0; i < nv; i++) { bp[i] = b[nv - 1 - i]; for (int j = 0; j < nv; j++) Ap[(size_t)i * nv + j] = A[(size_t)(nv - 1 - i) * nv + (nv - 1 - j)]; }
+    const bool ok = dense_cholesky_solve_natural(Ap, bp);
+    for (int i = 0; i < nv; i++) b[nv - 1 - i] = bp[i];
+    return ok;
+  }
+  bool dense_cholesky_solve_natural(std::vector<double>& A, std::vector<double>& b) const {  // A = L L^T in place (lower), b <- A^-1 b
     for (int j = 0; j < nv; j++) {
       double d = A[(size_t)j * nv + j];
       for (int k = 0; k < j; k++) d -= A[(size_t)j * nv + k] * A[(size_t)j * nv + k];
@@ -2001,6 +2013,7 @@ long ur5o_batch(const void* blob, size_t nbytes, int ee_body, int base_body, int
   return steps.load();
 }
 // checkpoints (ascending step counts, counted from now): ur5o_get_checkpoints copies the qpos rows recorded so far, returns their number
+void ur5o_set_cholesky_order(void* h, int mode) { ((Sim*)h)->cholesky_order = mode; }
 void ur5o_set_checkpoints(void* h, const int* steps, int n) { Sim* s = (Sim*)h; s->ckpt_steps.assign(steps, steps + n); s->ckpt_qpos.clear(); s->ckpt_base = s->total_steps; }
 int ur5o_get_checkpoints(void* h, double* out) {
   Sim* s = (Sim*)h;

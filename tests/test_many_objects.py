@@ -561,6 +561,7 @@ def test_a_small_scene_handle_and_a_pile_handle_do_not_evict_each_others_model(m
     pile = BatchSim(model_many, 2)
     six.reset(20 + np.arange(4, dtype=np.uint64), 1, 0.0)
     pile.reset(20 + np.arange(2, dtype=np.uint64), 1, 0.0)
+    six.step(1); pile.step(1)                                                 # the first launch of a handle writes its unit's model (a reset without settling launches nothing)
     u6, up = six.model_uploads(), pile.model_uploads()
     for _ in range(5):                                                        # alternating launches of the two handles
         six.step(3)
