@@ -40,7 +40,8 @@ for k in range(steps):                                                         #
     dq, dv = np.abs(g["qpos"] - oq).max(axis=1), np.abs(g["qvel"] - ov).max(axis=1)
     da = np.abs(g["warmstart"] - ow).max(axis=1) / np.maximum(1.0, np.abs(ow).max(axis=1))
     same = git == oit
-    rows.append(dict(step=k, qpos_diff_median=float(np.median(dq)), qpos_diff_max=float(dq.max()), qvel_diff_median=float(np.median(dv)), qacc_rel_diff_median=float(np.median(da)),
+    jumps = {"above_1e-14": int((dq > 1e-14).sum()), "above_1e-12": int((dq > 1e-12).sum()), "above_1e-10": int((dq > 1e-10).sum()), "above_1e-8": int((dq > 1e-8).sum())}
+    rows.append(dict(step=k, scenes_by_qpos_diff=jumps, qpos_diff_median=float(np.median(dq)), qpos_diff_max=float(dq.max()), qvel_diff_median=float(np.median(dv)), qacc_rel_diff_median=float(np.median(da)),
                      qacc_rel_diff_max=float(da.max()), scenes_with_equal_newton_iterations=int(same.sum()), qpos_diff_median_equal_iterations=float(np.median(dq[same])) if same.any() else None,
                      qpos_diff_median_other_iterations=float(np.median(dq[~same])) if (~same).any() else None, kernel_iterations_mean=float(git.mean()), oracle_iterations_mean=float(oit.mean())))
     st = dict(qpos=oq, qvel=ov, warmstart=ow, pid=st["pid"])
