@@ -68,10 +68,11 @@ def test_fused_rounds_equal_lock_step_rounds_on_the_emulation_build(model_it1, e
 
 
 def test_fused_rounds_on_the_device_code_path(model_it1, simt_lib):
-    """The interpreter as the GPU runs it (wavefront intrinsics, one fibre per lane) on the SIMT host build: scene 3 of 4, two rounds, its episode ends with the first."""
-    a, b = _both_ways(model_it1, 1, 2, 2, torch.device("cpu"), lo=3, n_total=4, lib_path=simt_lib)
+    """The interpreter as the GPU runs it (wavefront intrinsics, one fibre per lane) on the SIMT host build: two rounds of one scene in one launch against two launches
+    (the episode boundary inside a launch is the emulation build's and the GPU test's case: both run this same interpreter)."""
+    a, b = _both_ways(model_it1, 1, 2, 2, torch.device("cpu"), lo=0, n_total=4, lib_path=simt_lib)
     _assert_identical(a, b, 2, 1)
-    assert a[4]["total_steps"].min() > 2 * 1200 + 400                              # two attempts and the 500 settle steps of the reset between them
+    assert a[4]["total_steps"].min() > 2 * 1200
 
 
 def test_the_pile_engine_refuses_the_scripted_rule(emul_lib):
