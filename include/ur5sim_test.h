@@ -13,9 +13,9 @@ int ur5_forward_debug(ur5_sim* h, double* out);
    steps and saves its record as it stands. Copies of one scene with caps 10, 20, 40 ... show WHEN the engine and the oracle (or the oracle and its rounding-level
    twins) part on a chaotic pile -- tools/gpu_many_divergence.py, tools/pile_divergence_time.py. Results of scenes whose script ends before the cap are unchanged. */
 int ur5_set_step_cap_dev(ur5_sim* h, const int* cap_dev);
-/* how often the constant-memory model of the handle's engine unit has been (re-)written in this process. The model of a unit is ONE __constant__ copy per device:
-   handles with equal models share it, the small-scene unit and the pile unit have one each (an IT4 handle and a pile handle never evict each other), two handles of the
-   SAME unit with DIFFERENT models (IT1 and the six-object scene) re-write 43 KB behind a device synchronisation on every alternating launch. */
+/* how many model copies the handle's engine unit has sent to a device in this process: one per handle, by ur5_create. The kernels read the model through the handle's
+   own device copy (csrc/ur5_engine.h: ur5_model_ptr()), so no launch uploads anything and handles with different models never evict each other (rounds 1-4: one
+   __constant__ copy per unit and device, re-written whenever handles with different models took turns). */
 long ur5_model_uploads(ur5_sim* h);
 #ifdef __cplusplus
 }

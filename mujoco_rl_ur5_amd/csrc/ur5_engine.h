@@ -43,9 +43,8 @@
 #define UR5_PHASE_G inline
 #define UR5_PHASE_H inline
 static void* ur5_emul_lds = nullptr;
-static const Ur5DevModel* ur5_emul_model = nullptr;
+inline const Ur5DevModel* ur5_uniform_model(const Ur5DevModel* p) { return p; }
 #define UR5_LDS_PTR(T) (static_cast<T*>(ur5_emul_lds))
-#define UR5_MODEL (*ur5_emul_model)
 #define PAR(i, n) for (int i = 0; i < (n); ++i)
 #define SYNC() ((void)0)
 #define SYNC1() ((void)0)
@@ -93,14 +92,26 @@ static const Ur5DevModel* ur5_emul_model = nullptr;
 #ifndef UR5_BOXBOX_ATTR
 #define UR5_BOXBOX_ATTR UR5_BIG
 #endif
-// The scene lives in dynamic LDS and the model in constant memory, both reached through these file-scope symbols so that
-// every (non-inlined) phase routine addresses them with ds_* / s_load instead of flat instructions.
+// The scene lives in dynamic LDS, reached through this file-scope symbol so that every (non-inlined) phase routine addresses it with ds_* instructions.
 extern __shared__ __attribute__((aligned(16))) double ur5_smem[];
-__constant__ Ur5DevModel ur5_cmodel;
+// The model is the HANDLE's (ur5_sim::dm, uploaded once by ur5_create), a kernel argument. struct Engine's only data member is its address: the kernel holds it in a
+// scalar register pair, every phase routine that is a real function gets it BY VALUE (two VGPRs at the call, v_readfirstlane in the callee -- no memory access, where
+// re-reading it from the kernel arguments costs every called function a dependent scalar load: -1.5 % on the headline kernel, profiles/r05_n_*) and builds its own
+// Engine around it. Constant address space + a uniform address: every uniform model read is an s_load through the scalar cache, as it was from the one
+// __constant__ symbol per unit and device of rounds 1-4 (which handles with different models re-uploaded whenever they took turns).
+#if defined(UR5_SIMT)
+inline const Ur5DevModel* ur5_uniform_model(const Ur5DevModel* p) { return p; }
+#else
+__device__ __forceinline__ const Ur5DevModel* ur5_uniform_model(const Ur5DevModel* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+  typedef const Ur5DevModel __attribute__((address_space(4)))* cptr;
+  return (const Ur5DevModel*)(cptr)(((unsigned long long)hi << 32) | lo);
+}
+#endif
 // A scene is owned by the GS = UR5_NT lanes of ONE workgroup (Engine<real, NV, GS>): a wavefront (64) in the small-scene unit, four wavefronts (256) in the pile unit.
 // UR5_LANE is the lane's index inside it. (Rounds 1-4 also carried GS = 32, two scenes per wavefront: -30 % on the bench, profiles/r02_*, removed in round 5.)
 #define UR5_LDS_PTR(T) (reinterpret_cast<T*>(ur5_smem))
-#define UR5_MODEL ur5_cmodel
 #define PAR(i, n) for (int i = UR5_LANE; i < (n); i += GS)
 // SYNC orders the LDS traffic of the lanes that share a scene. With one wavefront per workgroup (UR5_NT == 64) the hardware already
 // executes a wave's LDS instructions in issue order, so all that is needed is that the COMPILER keeps the accesses on their side of
@@ -459,7 +470,9 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
   typedef M3<real> m3;
   typedef Q4<real> q4;
 #define S (*UR5_LDS_PTR(L))
-#define M UR5_MODEL
+#define M (*mp_)
+  const Ur5DevModel* mp_;   // the handle's model: the ONLY data member (the scene lives in LDS), so that an Engine is rebuilt for free inside every phase routine that is a real function
+  UR5_FN explicit Engine(const Ur5DevModel* mp) : mp_(ur5_uniform_model(mp)) {}
 
   // views into the persistent record
   UR5_FN real* qpos() { return S.rec + UR5_REC_QPOS; }

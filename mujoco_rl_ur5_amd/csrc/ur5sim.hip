@@ -21,7 +21,7 @@ static_assert(7 * sizeof(ur5::Lds<double, 44>) <= 160 * 1024 && sizeof(ur5::Lds<
 #endif
 #endif
 template <int NV, int GS>
-__global__ void UR5_KERNEL_ATTR(GS) ur5_run_kernel(double* __restrict__ rec, Ur5Launch P) {
+__global__ void UR5_KERNEL_ATTR(GS) ur5_run_kernel(double* __restrict__ rec, Ur5Launch P, const Ur5DevModel* __restrict__ model) {
   const int slot = blockIdx.x * (UR5_NT / GS) + (int)threadIdx.x / GS;
   const bool present = slot < P.n_env;             // a half-filled last workgroup: the lanes of the missing scene idle
   // workgroups are dispatched in blockIdx order: a caller that knows which scenes have the most work ahead of them (an episode reset to
@@ -29,7 +29,7 @@ __global__ void UR5_KERNEL_ATTR(GS) ur5_run_kernel(double* __restrict__ rec, Ur5
   const int env = (present && P.order) ? P.order[slot] : slot;
   // a stay of zero chunks (the unflagged scenes of ur5_reset_dev) touches nothing: the record, last_movement_steps included, stays as it is
   const bool live = present && !(P.op == UR5_OP_STAY && P.max_steps[env] <= 0);
-  ur5::Engine<double, NV, GS> eng;
+  ur5::Engine<double, NV, GS> eng(model);
   double* r = rec + (size_t)(live ? env : 0) * UR5_REC_STRIDE;
   if (live) eng.load(r, P.pid_dt, P.contacts_enabled, P.step_cap ? P.step_cap[env] : 0x7fffffff);
 #ifdef UR5_MANY
@@ -39,36 +39,24 @@ __global__ void UR5_KERNEL_ATTR(GS) ur5_run_kernel(double* __restrict__ rec, Ur5
   if (live) eng.save(r);
 }
 
-// the model sits in __constant__ memory (one copy per device); a handle re-uploads it only when another handle used the device last
-// (several handles with the SAME model -- scene groups on separate streams -- share the copy: the upload is keyed by a hash of the struct)
-static ur5_sim* g_model_owner[64] = {nullptr};
-static uint64_t g_model_hash[64] = {0};
-static long g_model_uploads = 0;   // test hook (ur5_model_uploads): how often this unit's constant-memory model was (re-)written
-static uint64_t model_hash(const Ur5DevModel& m) {
-  const unsigned char* p = reinterpret_cast<const unsigned char*>(&m);
-  uint64_t h = 1469598103934665603ull;
-  for (size_t i = 0; i < sizeof(Ur5DevModel); i++) { h ^= p[i]; h *= 1099511628211ull; }
-  return h ? h : 1;
-}
-
 // RGB-D observation in two launches. (1) ur5_render_pose_kernel, one 64-thread block per scene: the (serial, fp64) forward kinematics of
 // the scene ONCE, then every render geom's world pose and its conservative screen box. (2) ur5_render_kernel, one block per 16x16 pixel tile
 // of one scene: the tile stages the scene's geom poses in LDS, keeps (in geom order) only the geoms whose box meets the tile, and every
 // thread casts the ray of its pixel against that short list.
 struct Ur5GeomPose { float p[12]; short box[4]; };
-__global__ void __launch_bounds__(64) ur5_render_pose_kernel(const Ur5RenderModel* __restrict__ R, const double* __restrict__ rec, int n, int cam, int W, int H,
+__global__ void __launch_bounds__(64) ur5_render_pose_kernel(const Ur5DevModel* __restrict__ Mp, const Ur5RenderModel* __restrict__ R, const double* __restrict__ rec, int n, int cam, int W, int H,
                                                              Ur5GeomPose* __restrict__ gpose) {
   __shared__ float bp[UR5_MAXB][12];
   const int scene = blockIdx.x;
   if (scene >= n) return;
   const double* r = rec + (size_t)scene * UR5_REC_STRIDE;
-  if (threadIdx.x == 0) ur5r::robot_poses(ur5_cmodel, r, bp);                                            // a serial chain: one lane
-  else for (int k = (int)threadIdx.x - 1; k < ur5_cmodel.nobj; k += (int)blockDim.x - 1) ur5r::object_pose(ur5_cmodel, r, k, bp);   // the objects: the other lanes
+  if (threadIdx.x == 0) ur5r::robot_poses(*Mp, r, bp);                                            // a serial chain: one lane
+  else for (int k = (int)threadIdx.x - 1; k < Mp->nobj; k += (int)blockDim.x - 1) ur5r::object_pose(*Mp, r, k, bp);   // the objects: the other lanes
   __syncthreads();
   for (int g = threadIdx.x; g < R->ngeom; g += blockDim.x) {
     Ur5GeomPose* o = gpose + (size_t)scene * UR5_R_MAXG + g;
     float gp[12];
-    ur5r::geom_pose(*R, ur5_cmodel, bp, g, gp);
+    ur5r::geom_pose(*R, *Mp, bp, g, gp);
     ur5r::geom_screen_box(*R, gp, g, cam, W, H, o->box);
 #pragma unroll
     for (int k = 0; k < 12; k++) o->p[k] = gp[k];
@@ -111,12 +99,12 @@ __global__ void __launch_bounds__(256) ur5_render_kernel(const Ur5RenderModel* _
 
 // GraspEnv.reset_model for the flagged scenes, one thread per scene (ur5host::reset_record: the same code the host path runs);
 // max_steps[e] = number of 10-step settle chunks the following stay launch gives scene e (0: the scene sits it out).
-__global__ void __launch_bounds__(64) ur5_reset_kernel(double* __restrict__ rec, const double* __restrict__ qpos0, const uint64_t* __restrict__ seeds,
+__global__ void __launch_bounds__(64) ur5_reset_kernel(const Ur5DevModel* __restrict__ Mp, double* __restrict__ rec, const double* __restrict__ qpos0, const uint64_t* __restrict__ seeds,
                                                        const uint8_t* __restrict__ mask, int n, int chunks, int* __restrict__ max_steps) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
   const bool on = !mask || mask[e];
-  if (on) ur5host::reset_record(ur5_cmodel, qpos0, rec + (size_t)e * UR5_REC_STRIDE, seeds[e]);
+  if (on) ur5host::reset_record(*Mp, qpos0, rec + (size_t)e * UR5_REC_STRIDE, seeds[e]);
   max_steps[e] = on ? chunks : 0;
 }
 
@@ -167,7 +155,6 @@ static int be_open(ur5_sim* h, int device_id) {
 }
 static void be_close(ur5_sim* h) {
   HipBackend* b = (HipBackend*)h->be;
-  if (g_model_owner[h->device & 63] == h) g_model_owner[h->device & 63] = nullptr;   // the constant-memory copy stays valid for handles with the same hash
   if (!b) return;
   (void)hipSetDevice(h->device);
   if (b->stream) (void)hipStreamSynchronize(b->stream);
@@ -216,11 +203,9 @@ static int be_d2d_async(ur5_sim* h, void* dst, const void* src, size_t bytes) {
   HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, b->stream));
   return 0;
 }
-static int be_upload_model(ur5_sim* h);
 static int be_launch(ur5_sim* h, const Ur5Launch& P) {
   HipBackend* b = (HipBackend*)h->be;
   HIPCHK(hipSetDevice(h->device));
-  { int rcm = be_upload_model(h); if (rcm) return rcm; }
   hipEvent_t ev0, ev1;
   if (be_event_pair(h, b, &ev0, &ev1)) return ur5host::fail(UR5_ERR_DEVICE, "hipEventCreate failed");
   HIPCHK(hipEventRecord(ev0, b->stream));
@@ -234,10 +219,10 @@ static int be_launch(ur5_sim* h, const Ur5Launch& P) {
       attr_set[h->device & 63] = true;
     }
   }
-  hipLaunchKernelGGL((ur5_run_kernel<UR5_MAXNV, UR5_NT>), grid, block, sizeof(ur5::Lds<double, UR5_MAXNV>), b->stream, h->d_rec, P);
+  hipLaunchKernelGGL((ur5_run_kernel<UR5_MAXNV, UR5_NT>), grid, block, sizeof(ur5::Lds<double, UR5_MAXNV>), b->stream, h->d_rec, P, (const Ur5DevModel*)h->dm);
 #else
-  if (h->nvt == 32) hipLaunchKernelGGL((ur5_run_kernel<32, 64>), dim3(h->n), block, sizeof(ur5::Lds<double, 32>), b->stream, h->d_rec, P);
-  else hipLaunchKernelGGL((ur5_run_kernel<UR5_MAXNV, 64>), dim3(h->n), block, sizeof(ur5::Lds<double, UR5_MAXNV>), b->stream, h->d_rec, P);
+  if (h->nvt == 32) hipLaunchKernelGGL((ur5_run_kernel<32, 64>), dim3(h->n), block, sizeof(ur5::Lds<double, 32>), b->stream, h->d_rec, P, (const Ur5DevModel*)h->dm);
+  else hipLaunchKernelGGL((ur5_run_kernel<UR5_MAXNV, 64>), dim3(h->n), block, sizeof(ur5::Lds<double, UR5_MAXNV>), b->stream, h->d_rec, P, (const Ur5DevModel*)h->dm);
 #endif
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(ev1, b->stream));
@@ -247,31 +232,13 @@ static int be_launch(ur5_sim* h, const Ur5Launch& P) {
 static int be_reset_dev(ur5_sim* h, const uint64_t* seeds_dev, const uint8_t* mask_dev, int chunks, int* max_steps_dev) {
   HipBackend* b = (HipBackend*)h->be;
   HIPCHK(hipSetDevice(h->device));
-  { int rcm = be_upload_model(h); if (rcm) return rcm; }
-  hipLaunchKernelGGL(ur5_reset_kernel, dim3((h->n + 63) / 64), dim3(64), 0, b->stream, h->d_rec, h->d_qpos0, seeds_dev, mask_dev, h->n, chunks, max_steps_dev);
+  hipLaunchKernelGGL(ur5_reset_kernel, dim3((h->n + 63) / 64), dim3(64), 0, b->stream, (const Ur5DevModel*)h->dm, h->d_rec, h->d_qpos0, seeds_dev, mask_dev, h->n, chunks, max_steps_dev);
   HIPCHK(hipGetLastError());
   return 0;
 }
-static int be_upload_model(ur5_sim* h) {
-  if (g_model_owner[h->device & 63] != h) {
-    if (!h->model_hash) h->model_hash = model_hash(h->hm);
-    if (g_model_hash[h->device & 63] != h->model_hash) {
-      HIPCHK(hipDeviceSynchronize());
-      HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(ur5_cmodel), &h->hm, sizeof(Ur5DevModel), 0, hipMemcpyHostToDevice));
-      HIPCHK(hipDeviceSynchronize());   // the copy runs on the null stream; the launches that read the model go to a non-blocking stream
-      g_model_hash[h->device & 63] = h->model_hash;
-      g_model_uploads++;
-    }
-    g_model_owner[h->device & 63] = h;
-  }
-  return 0;
-}
-static long be_model_uploads() { return g_model_uploads; }
 static int be_render(ur5_sim* h, int cam, int W, int Hh, int mode, uint8_t* rgb_dev, float* depth_dev) {
   HipBackend* b = (HipBackend*)h->be;
   HIPCHK(hipSetDevice(h->device));
-  int rc = be_upload_model(h);
-  if (rc) return rc;
   if (!h->d_gpose) {
     h->d_gpose = be_alloc(h, (size_t)h->n * UR5_R_MAXG * sizeof(Ur5GeomPose));
     if (!h->d_gpose) return ur5host::fail(UR5_ERR_DEVICE, "device allocation failed (render geom poses)");
@@ -279,7 +246,7 @@ static int be_render(ur5_sim* h, int cam, int W, int Hh, int mode, uint8_t* rgb_
   hipEvent_t ev0, ev1;
   if (be_event_pair(h, b, &ev0, &ev1)) return ur5host::fail(UR5_ERR_DEVICE, "hipEventCreate failed");
   HIPCHK(hipEventRecord(ev0, b->stream));
-  hipLaunchKernelGGL(ur5_render_pose_kernel, dim3(h->n), dim3(64), 0, b->stream, h->d_rm, h->d_rec, h->n, cam, W, Hh, (Ur5GeomPose*)h->d_gpose);
+  hipLaunchKernelGGL(ur5_render_pose_kernel, dim3(h->n), dim3(64), 0, b->stream, (const Ur5DevModel*)h->dm, h->d_rm, h->d_rec, h->n, cam, W, Hh, (Ur5GeomPose*)h->d_gpose);
   dim3 grid(((W + 15) / 16) * ((Hh + 15) / 16), h->n), block(256);
   hipLaunchKernelGGL(ur5_render_kernel, grid, block, 0, b->stream, h->d_rm, (const Ur5GeomPose*)h->d_gpose, cam, W, Hh, mode, rgb_dev, depth_dev);
   HIPCHK(hipGetLastError());

@@ -433,7 +433,6 @@ struct ur5_sim {
   const int* d_order = nullptr;   // dispatch order of the scripted launches (ur5_set_order_dev), NULL = scene order; points at d_order_buf
   int* d_order_buf = nullptr;     // handle-owned copy, made by an ASYNCHRONOUS device-to-device copy on the handle's stream: the caller's buffer must stay valid (and unmodified) until the work
                                   // queued on that stream so far has run (include/ur5sim.h); same-stream callers (ur5_set_stream) have nothing to do
-  uint64_t model_hash = 0;        // of hm: handles with equal models share the device's constant-memory copy
   double kernel_ms_total = 0;   // engine-kernel time of every launch since ur5_create (HIP events on the handle's stream)
   int *d_max = nullptr, *d_result = nullptr, *d_steps = nullptr, *d_ps = nullptr, *d_pr = nullptr;
   std::vector<double> h_rec;
@@ -454,7 +453,7 @@ static int be_sync(ur5_sim* h);
 static int be_set_stream(ur5_sim* h, void* stream, int external);
 static int be_render(ur5_sim* h, int cam, int W, int Hh, int mode, uint8_t* rgb_dev, float* depth_dev);
 static int be_reset_dev(ur5_sim* h, const uint64_t* seeds_dev, const uint8_t* mask_dev, int chunks, int* max_steps_dev);
-static long be_model_uploads();
+static long g_model_uploads = 0;   // test hook (ur5_model_uploads): model copies this unit has sent to a device -- one per handle, by ur5_create, never at a launch
 
 namespace ur5host {
 static int pull(ur5_sim* h) { h->h_rec.resize((size_t)h->n * UR5_REC_STRIDE); return be_d2h(h, h->h_rec.data(), h->d_rec, h->h_rec.size() * 8); }
@@ -558,7 +557,8 @@ int ur5_create(const void* blob, size_t nbytes, int n_env, int device_id, const 
     ur5_destroy(h);
     return fail(UR5_ERR_DEVICE, "device allocation failed");
   }
-  be_h2d(h, h->dm, &h->hm, sizeof(Ur5DevModel));
+  be_h2d(h, h->dm, &h->hm, sizeof(Ur5DevModel));   // the kernels read the model THROUGH this pointer (a kernel argument, struct Engine's only member): handles never share or evict a model
+  g_model_uploads++;
   if (h->d_rm) be_h2d(h, h->d_rm, &h->hrm, sizeof(Ur5RenderModel));
   // initial records: qpos0, controller construction state
   h->h_rec.assign(n * UR5_REC_STRIDE, 0.0);
@@ -873,7 +873,7 @@ void* ur5_state_device_ptr(ur5_sim* h) {
 
 long ur5_model_uploads(ur5_sim* h) {
   UR5_FWD(model_uploads, (h));
-  return be_model_uploads();
+  return g_model_uploads;
 }
 int ur5_set_step_cap_dev(ur5_sim* h, const int* cap_dev) {
   UR5_FWD(set_step_cap_dev, (h, cap_dev));

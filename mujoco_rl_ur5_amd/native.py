@@ -246,7 +246,7 @@ class BatchSim:
                                                   C.c_void_p(action_out_ptr) if action_out_ptr else None, float(settle_ms)), "ur5_grasp_rounds_dev")
 
     def model_uploads(self):
-        """Test hook: (re-)writes of the constant-memory model of this handle's engine unit so far (include/ur5sim_test.h)."""
+        """Test hook: model copies this handle's engine unit has sent to a device so far -- one per handle, at creation (include/ur5sim_test.h)."""
         return int(self.lib.ur5_model_uploads(self._h))
 
     def set_step_cap_dev(self, cap_ptr):

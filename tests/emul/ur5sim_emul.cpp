@@ -19,7 +19,6 @@ static int be_d2h(ur5_sim*, void* dst, const void* src, size_t bytes) { memcpy(d
 static int be_d2d_async(ur5_sim*, void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); return 0; }
 static int be_sync(ur5_sim*) { return 0; }
 static int be_set_stream(ur5_sim*, void*, int) { return 0; }
-static long be_model_uploads() { return 0; }   // (the test builds read the model through a pointer: nothing is uploaded)
 static int be_reset_dev(ur5_sim* h, const uint64_t* seeds, const uint8_t* mask, int chunks, int* max_steps) {
   for (int e = 0; e < h->n; e++) {
     const bool on = !mask || mask[e];
@@ -37,8 +36,7 @@ template <int NV> static void run_all(ur5_sim* h, const Ur5Launch& P) {
     if (P.op == UR5_OP_STAY && P.max_steps[e] <= 0) continue;   // as in ur5_run_kernel: a stay of zero chunks touches nothing
     memset((void*)lds, 0xFF, sizeof(L));
     ur5_emul_lds = lds;
-    ur5_emul_model = h->dm;
-    ur5::Engine<double, NV> eng;
+    ur5::Engine<double, NV> eng(h->dm);
     eng.load(h->d_rec + (size_t)e * UR5_REC_STRIDE, P.pid_dt, P.contacts_enabled, P.step_cap ? P.step_cap[e] : 0x7fffffff);
 #ifdef UR5_MANY
     eng.set_hess(P.hess + (size_t)e * UR5_HESS_STRIDE);

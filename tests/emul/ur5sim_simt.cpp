@@ -126,7 +126,6 @@ static int be_d2h(ur5_sim*, void* dst, const void* src, size_t bytes) { memcpy(d
 static int be_d2d_async(ur5_sim*, void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); return 0; }
 static int be_sync(ur5_sim*) { return 0; }
 static int be_set_stream(ur5_sim*, void*, int) { return 0; }
-static long be_model_uploads() { return 0; }   // (the test builds read the model through a pointer: nothing is uploaded)
 static int be_reset_dev(ur5_sim* h, const uint64_t* seeds, const uint8_t* mask, int chunks, int* max_steps) {
   for (int e = 0; e < h->n; e++) {
     const bool on = !mask || mask[e];
@@ -137,7 +136,7 @@ static int be_reset_dev(ur5_sim* h, const uint64_t* seeds, const uint8_t* mask, 
 }
 
 // the body of ur5_run_kernel<NV, 64> (csrc/ur5sim.hip), executed by each of the 64 fibres of a wave
-template <int NV> struct KernelArgs { double* rec; const Ur5Launch* P; };
+template <int NV> struct KernelArgs { double* rec; const Ur5Launch* P; const Ur5DevModel* model; };
 template <int NV> static void kernel_body(void* a) {
   const KernelArgs<NV>& K = *(const KernelArgs<NV>*)a;
   const Ur5Launch& P = *K.P;
@@ -145,7 +144,7 @@ template <int NV> static void kernel_body(void* a) {
   const bool present = slot < P.n_env;
   const int env = (present && P.order) ? P.order[slot] : slot;
   const bool live = present && !(P.op == UR5_OP_STAY && P.max_steps[env] <= 0);
-  ur5::Engine<double, NV, UR5_NT> eng;
+  ur5::Engine<double, NV, UR5_NT> eng(K.model);
   double* r = K.rec + (size_t)(live ? env : 0) * UR5_REC_STRIDE;
   if (live) eng.load(r, P.pid_dt, P.contacts_enabled, P.step_cap ? P.step_cap[env] : 0x7fffffff);
 #ifdef UR5_MANY
@@ -156,8 +155,7 @@ template <int NV> static void kernel_body(void* a) {
 }
 template <int NV> static void run_all(ur5_sim* h, const Ur5Launch& P) {
   static_assert(sizeof(ur5::Lds<double, NV>) <= sizeof(ur5_smem), "LDS image fits");
-  ur5_cmodel = *h->dm;
-  KernelArgs<NV> K{h->d_rec, &P};
+  KernelArgs<NV> K{h->d_rec, &P, h->dm};
   for (int b = 0; b < h->n; b++) {
     memset(ur5_smem, 0xFF, sizeof(ur5::Lds<double, NV>));       // a workgroup starts with whatever the previous one left in the CU's LDS
     simt::bid.x = (unsigned)b;

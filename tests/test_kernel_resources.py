@@ -40,10 +40,12 @@ def test_kernel_registers_and_scratch(tmp_path):
     small, six, many = find("ur5_run_kernelILi32ELi64E"), find("ur5_run_kernelILi44ELi64E"), find("ur5m_run_kernelILi248ELi256E")
     assert small["vgpr_count"] <= 256 and six["vgpr_count"] <= 256              # two waves per SIMD
     assert small["max_flat_workgroup_size"] == 64 and many["max_flat_workgroup_size"] == 256
-    assert small["private_segment_fixed_size"] <= 512, small                    # B per lane, the whole call tree (was 1 216)
-    assert six["private_segment_fixed_size"] <= 800, six                        # 824 until the integration became a real function in this instantiation
+    # B per lane, the whole call tree (round 1: 1 216; rounds 2-4: 488 / 792; round 5: the model behind the handle's pointer instead of a __constant__ symbol --
+    # one SGPR pair + immediate offsets instead of a pc-relative address per use -- 408 / 728, and 864 instead of 1 040 in the pile unit)
+    assert small["private_segment_fixed_size"] <= 416, small
+    assert six["private_segment_fixed_size"] <= 736, six
     # round 4: TWO pile scenes per CU -- the kernel is capped at 256 registers (same-box A/B of the cap alone: +-0 %, the step is latency-bound), spills 1 KB per lane, and
     # its LDS image must leave room for a second scene (checked where the image is defined: static_assert in csrc/ur5sim.hip; the launch passes sizeof(Lds) as dynamic LDS)
-    assert many["private_segment_fixed_size"] <= 1280 and many["vgpr_count"] <= 256, many
+    assert many["private_segment_fixed_size"] <= 896 and many["vgpr_count"] <= 256, many
     assert find("ur5_render_kernel")["private_segment_fixed_size"] == 0
     assert small["group_segment_fixed_size"] == 0                               # the scene is dynamic LDS, sized at launch

@@ -551,27 +551,30 @@ def test_arm_link_hulls_on_gpu(model_many_armcol):
 
 
 @pytest.mark.gpu
-def test_a_small_scene_handle_and_a_pile_handle_do_not_evict_each_others_model(model_many):
-    """Round-4 verdict item 7 ("an IT4 env + a pile env in one process hit the __constant__ ping-pong"): the two engine units are two translation units with ONE
-    constant-memory model each (ur5_cmodel / ur5m_cmodel), so a six-object handle and a pile handle alternating on one GPU never re-upload -- counted by the test hook
-    ur5_model_uploads. What does re-upload (43 KB behind a device synchronisation, results unaffected) is two DIFFERENT models of the SAME unit taking turns: stated in
-    include/ur5sim_test.h and DESIGN.md section 5; equal models (scene groups of one workload) share the copy."""
+def test_every_handle_reads_its_own_model(model_many):
+    """Round-4 verdict item 7 ("per-handle model behind a pointer"): rounds 1-4 kept ONE __constant__ model per engine unit and device, re-uploaded (43 KB behind a
+    device synchronisation) whenever handles with different models took turns. Since round 5 the kernels read the model through the handle's own device copy
+    (ur5_model_ptr(), csrc/ur5_engine.h): ur5_create uploads it once -- counted by the test hook ur5_model_uploads -- and no launch ever uploads again, however
+    the handles of a process alternate; and each handle's results are those it produces alone."""
     from mujoco_rl_ur5_amd.model import load_model
-    six = BatchSim(load_model("/UR5+gripper/UR5gripper_2_finger.xml"), 4)
+    m6, m1 = load_model("/UR5+gripper/UR5gripper_2_finger.xml"), load_model("it1_4box")
+    alone = BatchSim(m6, 4)
+    alone.reset(20 + np.arange(4, dtype=np.uint64), 1, 0.0)
+    alone.step(40)
+    q_alone = alone.get_state()["qpos"].copy()
+    alone.close()
+    six, it1 = BatchSim(m6, 4), BatchSim(m1, 2)                               # two DIFFERENT models of the small-scene unit
+    u_small = six.model_uploads()
     pile = BatchSim(model_many, 2)
+    u_pile = pile.model_uploads()
     six.reset(20 + np.arange(4, dtype=np.uint64), 1, 0.0)
-    pile.reset(20 + np.arange(2, dtype=np.uint64), 1, 0.0)
-    six.step(1); pile.step(1)                                                 # the first launch of a handle writes its unit's model (a reset without settling launches nothing)
-    u6, up = six.model_uploads(), pile.model_uploads()
-    for _ in range(5):                                                        # alternating launches of the two handles
-        six.step(3)
-        pile.step(3)
-    assert six.model_uploads() == u6 and pile.model_uploads() == up          # zero re-uploads
-    twin = BatchSim(load_model("/UR5+gripper/UR5gripper_2_finger.xml"), 2)   # a second handle with the SAME model shares the copy
-    twin.reset(30 + np.arange(2, dtype=np.uint64), 1, 0.0)
-    six.step(1); twin.step(1); six.step(1)
-    assert six.model_uploads() == u6
-    it1 = BatchSim(load_model("it1_4box"), 2)                                # another model of the small-scene unit: this one does take turns
     it1.reset(40 + np.arange(2, dtype=np.uint64), 1, 0.0)
-    six.step(1); it1.step(1); six.step(1)
-    assert six.model_uploads() >= u6 + 2 and pile.model_uploads() == up and six.counters()["status"].max() == 0
+    pile.reset(20 + np.arange(2, dtype=np.uint64), 1, 0.0)
+    for _ in range(10):                                                       # alternating launches of the three handles
+        six.step(4); it1.step(4); pile.step(2)
+    assert six.model_uploads() == u_small and it1.model_uploads() == u_small and pile.model_uploads() == u_pile      # nothing re-uploaded
+    assert np.array_equal(six.get_state()["qpos"], q_alone)                        # every bit of qpos as if the handle had the GPU to itself
+    for s in (six, it1, pile):
+        assert s.counters()["status"].max() == 0
+    twin = BatchSim(m6, 2)                                                    # one upload per handle, at creation
+    assert twin.model_uploads() == u_small + 1 and pile.model_uploads() == u_pile
