@@ -498,7 +498,7 @@ def main():
             "dqn": lambda cpu: dqn_sub_result(torch, dev, dev_id, 512, 2, 1, 2),
             # the same loop at the per-GPU scene count of configs[3] / [4] (16384 piles on 8 GPUs): with 512 piles a round lasts as long as its longest scene (2 piles per CU,
             # every scene resident at once: the chip idles through the tail), with 2048 the tail amortises
-            "dqn2048": lambda cpu: dqn_sub_result(torch, dev, dev_id, 2048, 1, 1, 1)}
+            "dqn2048": lambda cpu: dqn_sub_result(torch, dev, dev_id, 2048, 2, 1, 1)}
     if args.sub:
         if args.sub in ("dqn", "dqn2048") and (args.sub_scenes or args.sub_rounds or args.sub_groups != 2):
             dflt = {"dqn": (512, 2), "dqn2048": (2048, 1)}[args.sub]
