@@ -263,6 +263,7 @@ class Job:
 
     def __init__(self, torch, dist, sharding, model, kind, rule, n_local, n_total, lo, world, dev, dev_id, G, rows):
         from mujoco_rl_ur5_amd.native import BatchSim
+        from mujoco_rl_ur5_amd.streams import group_streams
         self.torch, self.dist, self.sharding, self.world, self.model, self.kind = torch, dist, sharding, world, model, kind
         self.G = G if n_local % max(1, G) == 0 else 1
         self.n_g, self.n_local, self.n_total = n_local // self.G, n_local, n_total
@@ -274,12 +275,14 @@ class Job:
                 self.lo = lo + g * job.n_g
                 self.sim = BatchSim(model, job.n_g, device_id=dev_id)
                 self.sim.reset(BASE_SEED + np.arange(self.lo, self.lo + job.n_g, dtype=np.uint64), 1, 1000.0)   # episode 0 (GraspingEnv.py:409-477), untimed
-                self.stream = torch.cuda.Stream(device=dev) if job.G > 1 else torch.cuda.current_stream()
+                self.stream = job.streams[g]
                 self.sim.set_stream(self.stream.cuda_stream)
                 with torch.cuda.stream(self.stream):
                     self.wl = It1Rounds(torch, model, self.sim, dev, self.lo, job.n_g, n_total, rule, kind)
                     self.reward = torch.zeros((rows, job.n_g), dtype=torch.int32, device=dev)
                     self.ids = torch.arange(self.lo, self.lo + job.n_g, dtype=torch.int32, device=dev)
+        # streams that the runtime has put on different hardware queues -- measured, not assumed (mujoco_rl_ur5_amd/streams.py)
+        self.streams, self.streams_overlap_verified = group_streams(torch, dev, self.G)
         self.groups = [Group(g) for g in range(self.G)]
         torch.cuda.synchronize()
 
@@ -358,7 +361,7 @@ def rendered_sub_result(torch, dist, sharding, dev, dev_id, workload, n, rounds,
                         "box rule of tools/pile_aim.py on the device, depth-derived grasp height, one grasp script; episodes of 4 rounds with reset_model + 1000 ms settle" if many
                         else "BASELINE.json configs[2] shape: IT4 (in-tree UR5gripper_2_finger.xml, 3 boxes + 3 spheres), per round a 200x200 RGB-D render, device-side "
                         "re-aim at an object still on the plate, depth-derived grasp height, one grasp script; episodes of 4 rounds with reset_model + 1000 ms settle"),
-           "scenes": n, "rounds": rounds, "warmup": warmup, "scene_groups": job.G, "env_steps_per_s": steps / dt, "grasp_attempts_per_s": rounds * n / dt,
+           "scenes": n, "rounds": rounds, "warmup": warmup, "scene_groups": job.G, "scene_group_streams_overlap_verified": job.streams_overlap_verified, "env_steps_per_s": steps / dt, "grasp_attempts_per_s": rounds * n / dt,
            "grasp_success_rate": succ / (rounds * n), "env_steps_per_attempt": steps / (rounds * n),
            "newton_iters_per_step": float((c1["solver_iters"] - c0["solver_iters"]).sum()) / max(1, steps),
            "status_bits": int(np.bitwise_or.reduce(c1["status"] | c1["status_ended"])), "ms_per_round": 1e3 * dt / rounds, "kernel_ms_per_round_and_group": kms / (rounds * job.G),
@@ -566,6 +569,7 @@ def main():
             "env_steps_per_attempt": steps_all / attempts,
             "newton_iters_per_step": float((c1["solver_iters"] - c0["solver_iters"]).sum()) / max(1, steps_local),
             "status_bits": int(np.bitwise_or.reduce(c1["status"] | c1["status_ended"])),   # incl. the episodes that ended inside the timed launches
+            "scene_group_streams_overlap_verified": job.streams_overlap_verified,        # the groups' HIP streams sit on different hardware queues: measured (streams.py)
             "config": {"workload": "BASELINE.json configs[1]: IT1 (UR5gripper_2_finger.xml robot + bins, 4 equal 4 cm boxes), physics only, fixed "
                                    "z = 0.91, lift + 500-step closing check; one grasp-attempt round per step, episodes of 4 rounds with reset_model "
                                    "(+ 1000 ms settle) for the quarter of the batch that starts an episode in the round",

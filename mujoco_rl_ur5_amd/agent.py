@@ -221,12 +221,13 @@ class BatchedGraspAgent:
             self.envs, self.streams = [], None
             for g in range(self.G):
                 self.envs.append(GraspEnv(n_envs=ng, first_scene_id=first_scene_id + g * ng, n_total=n_total, **kw))
-                if self.G > 1 and self.device.type == "cuda":
-                    # one CUDA stream per group, created right after the group's engine handle (as bench.py's scene groups do): HIP deals its hardware queues to streams
-                    # in creation order, and two group streams created back to back after all handles landed on ONE queue -- the groups' work serialised
-                    # (profiles/r05_f_dqn512_timeline_one_queue.txt: CNN burst, engine, CNN burst, engine on queue 4)
-                    self.streams = (self.streams or []) + [torch.cuda.Stream(device=self.device)]
-                    self.envs[-1].use_stream(self.streams[-1])
+            if self.G > 1 and self.device.type == "cuda":
+                # one CUDA stream per group, on DIFFERENT hardware queues -- chosen by measurement (streams.py): which queue the HIP runtime gives a stream depends on the
+                # process's whole stream history, and two group streams on one queue serialise the groups (profiles/r05_f_dqn512_timeline_one_queue.txt)
+                from .streams import group_streams
+                self.streams, self.streams_overlap_verified = group_streams(torch, self.device, self.G)
+                for e, st in zip(self.envs, self.streams):
+                    e.use_stream(st)
         self.env = self.envs[0]                                                         # model constants, action space, camera (equal in every group)
         self.N, self.H, self.W = sum(e.n_envs for e in self.envs), self.env.IMAGE_HEIGHT, self.env.IMAGE_WIDTH
         self.n_actions_1, self.n_actions_2 = int(self.env.action_space.nvec[0]), int(self.env.action_space.nvec[1])   # :97-100
