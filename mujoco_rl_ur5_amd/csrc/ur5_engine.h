@@ -92,8 +92,15 @@ inline const Ur5DevModel* ur5_uniform_model(const Ur5DevModel* p) { return p; }
 #ifndef UR5_BOXBOX_ATTR
 #define UR5_BOXBOX_ATTR UR5_BIG
 #endif
-// The scene lives in dynamic LDS, reached through this file-scope symbol so that every (non-inlined) phase routine addresses it with ds_* instructions.
-extern __shared__ __attribute__((aligned(16))) double ur5_smem[];
+// The scene image is STATIC LDS, one variable per Engine instantiation (round 5; rounds 1-4: dynamic LDS behind one `extern __shared__` symbol). A phase routine that is a
+// real function does not know where dynamic LDS starts: the compiler hands every function the launching kernel's id and has it read the base from a table in constant
+// memory (llvm.amdgcn.dynlds.offset.table) -- s_getpc / s_add / s_addc / s_lshl / s_load_dword / s_waitcnt in front of the function's LDS accesses and, with the machine
+// LICM off, again inside loops (552 of the small-scene unit's 1 246 scalar loads). A static variable that only ONE kernel reaches gets an absolute address: no table, no load,
+// immediate ds_* offsets. Same-box A/B: headline +2 %, six-object scenes +3 %, piles +1.3 %, bit-identical (profiles/r05_s_*; the detour over a literal address:
+// profiles/r05_v_lds_base_lookup_finding.txt).
+#ifdef UR5_SIMT
+extern __shared__ __attribute__((aligned(16))) double ur5_smem[];   // the host fibres' "LDS" (tests/emul/ur5sim_simt.cpp)
+#endif
 // The model is the HANDLE's (ur5_sim::dm, uploaded once by ur5_create), a kernel argument. struct Engine's only data member is its address: the kernel holds it in a
 // scalar register pair, every phase routine that is a real function gets it BY VALUE (two VGPRs at the call, v_readfirstlane in the callee -- no memory access, where
 // re-reading it from the kernel arguments costs every called function a dependent scalar load: -1.5 % on the headline kernel, profiles/r05_n_*) and builds its own
@@ -111,7 +118,12 @@ __device__ __forceinline__ const Ur5DevModel* ur5_uniform_model(const Ur5DevMode
 #endif
 // A scene is owned by the GS = UR5_NT lanes of ONE workgroup (Engine<real, NV, GS>): a wavefront (64) in the small-scene unit, four wavefronts (256) in the pile unit.
 // UR5_LANE is the lane's index inside it. (Rounds 1-4 also carried GS = 32, two scenes per wavefront: -30 % on the bench, profiles/r02_*, removed in round 5.)
+#ifdef UR5_SIMT
 #define UR5_LDS_PTR(T) (reinterpret_cast<T*>(ur5_smem))
+#else
+template <class T> __device__ __forceinline__ T* ur5_lds_image() { __shared__ __attribute__((aligned(16))) T image; return &image; }
+#define UR5_LDS_PTR(T) (ur5_lds_image<T>())
+#endif
 #define PAR(i, n) for (int i = UR5_LANE; i < (n); i += GS)
 // SYNC orders the LDS traffic of the lanes that share a scene. With one wavefront per workgroup (UR5_NT == 64) the hardware already
 // executes a wave's LDS instructions in issue order, so all that is needed is that the COMPILER keeps the accesses on their side of

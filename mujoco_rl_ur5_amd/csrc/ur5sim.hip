@@ -212,17 +212,10 @@ static int be_launch(ur5_sim* h, const Ur5Launch& P) {
   dim3 block(UR5_NT);
 #ifdef UR5_MANY
   dim3 grid(h->n);
-  {   // the scene needs more than the default 64 KB of dynamic LDS (one scene per CU)
-    static bool attr_set[64] = {false};
-    if (!attr_set[h->device & 63]) {
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ur5_run_kernel<UR5_MAXNV, UR5_NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ur5::Lds<double, UR5_MAXNV>)));
-      attr_set[h->device & 63] = true;
-    }
-  }
-  hipLaunchKernelGGL((ur5_run_kernel<UR5_MAXNV, UR5_NT>), grid, block, sizeof(ur5::Lds<double, UR5_MAXNV>), b->stream, h->d_rec, P, (const Ur5DevModel*)h->dm);
+  hipLaunchKernelGGL((ur5_run_kernel<UR5_MAXNV, UR5_NT>), grid, block, 0, b->stream, h->d_rec, P, (const Ur5DevModel*)h->dm);
 #else
-  if (h->nvt == 32) hipLaunchKernelGGL((ur5_run_kernel<32, 64>), dim3(h->n), block, sizeof(ur5::Lds<double, 32>), b->stream, h->d_rec, P, (const Ur5DevModel*)h->dm);
-  else hipLaunchKernelGGL((ur5_run_kernel<UR5_MAXNV, 64>), dim3(h->n), block, sizeof(ur5::Lds<double, UR5_MAXNV>), b->stream, h->d_rec, P, (const Ur5DevModel*)h->dm);
+  if (h->nvt == 32) hipLaunchKernelGGL((ur5_run_kernel<32, 64>), dim3(h->n), block, 0, b->stream, h->d_rec, P, (const Ur5DevModel*)h->dm);
+  else hipLaunchKernelGGL((ur5_run_kernel<UR5_MAXNV, 64>), dim3(h->n), block, 0, b->stream, h->d_rec, P, (const Ur5DevModel*)h->dm);
 #endif
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(ev1, b->stream));
