@@ -14,7 +14,7 @@ int ur5_forward_debug(ur5_sim* h, double* out);
    twins) part on a chaotic pile -- tools/gpu_many_divergence.py, tools/pile_divergence_time.py. Results of scenes whose script ends before the cap are unchanged. */
 int ur5_set_step_cap_dev(ur5_sim* h, const int* cap_dev);
 /* how many model copies the handle's engine unit has sent to a device in this process: one per handle, by ur5_create. The kernels read the model through the handle's
-   own device copy (csrc/ur5_engine.h: ur5_model_ptr()), so no launch uploads anything and handles with different models never evict each other (rounds 1-4: one
+   own device copy (a kernel argument, struct Engine's only member: csrc/ur5_engine.h), so no launch uploads anything and handles with different models never evict each other (rounds 1-4: one
    __constant__ copy per unit and device, re-written whenever handles with different models took turns). */
 long ur5_model_uploads(ur5_sim* h);
 #ifdef __cplusplus

@@ -554,7 +554,7 @@ def test_arm_link_hulls_on_gpu(model_many_armcol):
 def test_every_handle_reads_its_own_model(model_many):
     """Round-4 verdict item 7 ("per-handle model behind a pointer"): rounds 1-4 kept ONE __constant__ model per engine unit and device, re-uploaded (43 KB behind a
     device synchronisation) whenever handles with different models took turns. Since round 5 the kernels read the model through the handle's own device copy
-    (ur5_model_ptr(), csrc/ur5_engine.h): ur5_create uploads it once -- counted by the test hook ur5_model_uploads -- and no launch ever uploads again, however
+    (a kernel argument, struct Engine's only member: csrc/ur5_engine.h): ur5_create uploads it once -- counted by the test hook ur5_model_uploads -- and no launch ever uploads again, however
     the handles of a process alternate; and each handle's results are those it produces alone."""
     from mujoco_rl_ur5_amd.model import load_model
     m6, m1 = load_model("/UR5+gripper/UR5gripper_2_finger.xml"), load_model("it1_4box")
