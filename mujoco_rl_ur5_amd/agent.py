@@ -342,23 +342,37 @@ class BatchedGraspAgent:
         cuda = self.streams is not None
         main = torch.cuda.current_stream(self.device) if cuda else None
         self.begin_round_epsilon()
-        parts, o = [], 0
+        parts, o, selected = [], 0, []
+        probe = getattr(self, "_order_probe", None)                                                      # tests/test_agent.py: dict(flag=int tensor, delay_cycles=int, seen=[])
+        if cuda and probe is not None:
+            probe["flag"].zero_()
         for g, env in enumerate(self.envs):                                                              # queue every group's rollout: the host never waits here
             gids = self.gids[o:o + env.n_envs]
             o += env.n_envs
             if cuda:
                 self.streams[g].wait_stream(main)                                                        # this round's weights (the previous round's optimiser steps ran on the main stream)
             with (torch.cuda.stream(self.streams[g]) if cuda else contextlib.nullcontext()):
+                if cuda and probe is not None and g > 0:
+                    torch.cuda._sleep(int(probe["delay_cycles"]))                                        # test hook: a late group (its CNN would still be running when group 0's launch ends)
                 obs = env.observation_device(self.device, sync=not cuda)
                 raw = {k: v.clone() for k, v in obs.items()} if return_observation else None
                 state = self.transform_observation(obs, gids=gids)
                 action, greedy = self.epsilon_greedy(state, obs, gids=gids, env=env, new_round=False)
                 env_action = self.transform_action(action)
+                if cuda:                                                                                 # group g has READ the round-start weights from here on: the learner's first optimiser
+                    selected.append(torch.cuda.Event())                                                  # step (main stream) waits for every group's event, or it would overwrite policy_net
+                    selected[-1].record(self.streams[g])                                                 # under a later group's CNN forward (advisor, round 5)
+                    if probe is not None:
+                        probe["seen"].append(probe["flag"].clone())                                      # 0 = chosen before the learner's first step of this round was queued to run
                 reward, skipped = env.step_device(env_action, obs["depth"], self.device, sync=not cuda)   # group g's grasp launch: the next group's CNN runs under it
                 rec = torch.stack([gids.int(), env_action[:, 0].int(), env_action[:, 1].int(), reward.int()], dim=1)   # (reward is read when the launch has run: stream order)
             parts.append(dict(raw=raw, state=state, action=action, greedy=greedy, reward=reward, skipped=skipped, rec=rec))
 
         def finished():                                                                                  # a group's transitions once its launch has run, in scene order
+            for ev in selected:
+                main.wait_event(ev)                                                                      # every group has chosen its actions with the round-start weights
+            if cuda and probe is not None:
+                probe["flag"].fill_(1)                                                                   # (main stream, in front of the first optimiser step)
             for g, p in enumerate(parts):
                 if cuda:
                     main.wait_stream(self.streams[g])                                                    # the learner's stream waits for group g only; later groups keep running

@@ -219,7 +219,9 @@ constexpr int NB = UR5_NB;  // base directions per contact: normal, 2 tangents, 
 // another portal face now and then (a 5e-3 jump of a contact normal), and piles of cylinders are full of the degenerate configurations where that happens.
 // With identical arithmetic the kernel reproduces the oracle's contacts from the same state instead of its own variant of them. The wavefront-per-scene
 // kernel keeps contraction: its scenes have few such pairs, and kinematics + collision are a third of its step.
-#if defined(UR5_MANY) && !defined(UR5_EMUL) && !defined(UR5_SIMT)
+// (A lane-emulation build made with clang and -mfma -ffp-contract=fast -- tools/qacc_error_budget.py -- gets the same split: the HIP pile unit's arithmetic on the host.)
+#if defined(UR5_MANY) && !defined(UR5_SIMT) && (!defined(UR5_EMUL) || defined(__clang__))
+#define UR5_STRICT_GEOMETRY 1
 #pragma clang fp contract(off)
 #define UR5_STRICT _Pragma("clang fp contract(off)")
 #else
@@ -258,6 +260,13 @@ template <class T> UR5_FN Q4<T> qnormalize(Q4<T> q) {
   if (n < (T)1e-300) return Q4<T>{1, 0, 0, 0};
   T s = (T)1 / n;
   return Q4<T>{q.w * s, q.x * s, q.y * s, q.z * s};
+}
+// The oracle's text of the same normalisation (oracle/ur5_oracle.cpp qnormalize: four divisions). The pile unit uses it for the objects' orientations: q / n and
+// q * (1 / n) differ in the last bit of some components, and its contacts are to be bit-equal to the oracle's from the same state (tools/contact_bits.py).
+template <class T> UR5_FN Q4<T> qnormalize_div(Q4<T> q) {
+  T n = sqrt(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+  if (n < (T)1e-300) return Q4<T>{1, 0, 0, 0};
+  return Q4<T>{q.w / n, q.x / n, q.y / n, q.z / n};
 }
 template <class T> struct M3 {  // row-major
   T m[9];
@@ -303,7 +312,7 @@ template <class T> UR5_FN T minv(T a, T b) { return a < b ? a : b; }
 // index of (i, j), i >= j, in a packed symmetric 6x6 (21 entries, row-major lower)
 UR5_FN int sym6(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
 
-#if defined(UR5_MANY) && !defined(UR5_EMUL) && !defined(UR5_SIMT)
+#ifdef UR5_STRICT_GEOMETRY
 #pragma clang fp contract(fast)
 #endif
 // ---------------------------------------------------------------------------------------------- LDS image of one scene

@@ -37,6 +37,16 @@
 
 namespace {
 
+// The control twin "fmadyn" of tools/pile_divergence_time.py (oracle/Makefile libur5_oracle_fmadyn.so: clang, -mfma -ffp-contract=fast-honor-pragmas) compiles the
+// GEOMETRY of this text -- the helpers below, kinematics, every collide_* routine -- without fused multiply-adds and everything else with them: the split of the HIP
+// pile unit (csrc/ur5_engine.h UR5_STRICT). In the oracle proper (g++ -ffp-contract=off) nothing is fused anywhere and the two macros are empty.
+#if defined(__clang__) && defined(UR5O_FMA_DYNAMICS)
+#pragma clang fp contract(off)
+#define UR5O_STRICT _Pragma("clang fp contract(off)")
+#else
+#define UR5O_STRICT
+#endif
+
 // ------------------------------------------------------------------------------------------ small maths
 struct V3 {
   double x, y, z;
@@ -420,6 +430,9 @@ bool mpr_penetration(const Shape& A, const Shape& B, double* depth, V3* dir_out,
   }
 }
 
+#if defined(__clang__) && defined(UR5O_FMA_DYNAMICS)
+#pragma clang fp contract(fast)
+#endif
 // ------------------------------------------------------------------------------------------ the simulator
 struct Sim {
   Model M;
@@ -486,7 +499,7 @@ struct Sim {
   }
 
   // ------------------------------------------------------------------ mj_kinematics + mj_comPos  [3P, SURVEY C.1/C.2]
-  void kinematics() {
+  void kinematics() { UR5O_STRICT;
     xpos[0] = V3(); xquat[0] = Q4{1, 0, 0, 0}; xmat[0] = qmat(xquat[0]); xipos[0] = V3();
     for (int b = 1; b < M.nbody; b++) {
       int p = M.body_parentid[b];
@@ -658,7 +671,7 @@ struct Sim {
   }
 
   // ------------------------------------------------------------------ collision  [3P, SURVEY C.3]
-  static void make_frame(V3 n, V3* fr) {
+  static void make_frame(V3 n, V3* fr) { UR5O_STRICT;
     fr[0] = n;
     V3 y = std::fabs(n.y) < 0.5 ? V3(0, 1, 0) : V3(0, 0, 1);
     y = y - n * dot(n, y);
@@ -666,7 +679,7 @@ struct Sim {
     fr[1] = y;
     fr[2] = cross(n, y);
   }
-  Shape make_shape(int g, double margin) const {
+  Shape make_shape(int g, double margin) const { UR5O_STRICT;
     Shape s;
     s.type = M.geom_type[g];
     s.pos = gxpos[g];
@@ -683,7 +696,7 @@ struct Sim {
     s.margin = margin;
     return s;
   }
-  void add_contact(int g1, int g2, double dist, V3 pos, V3 n, double margin) {
+  void add_contact(int g1, int g2, double dist, V3 pos, V3 n, double margin) { UR5O_STRICT;
     Contact c;
     c.dist = dist; c.pos = pos;
     make_frame(n, c.frame);
@@ -700,13 +713,13 @@ struct Sim {
     contacts.push_back(c);
   }
 
-  void collide_plane_sphere(int g1, int g2, double margin) {
+  void collide_plane_sphere(int g1, int g2, double margin) { UR5O_STRICT;
     V3 n = gxmat[g1].col(2);
     double r = M.geom_size[3 * g2];
     double d = dot(gxpos[g2] - gxpos[g1], n) - r;
     if (d < margin) add_contact(g1, g2, d, gxpos[g2] - n * (r + 0.5 * d), n, margin);
   }
-  void collide_plane_box(int g1, int g2, double margin) {
+  void collide_plane_box(int g1, int g2, double margin) { UR5O_STRICT;
     V3 n = gxmat[g1].col(2);
     V3 s = v3(M.geom_size + 3 * g2);
     int cnt = 0;
@@ -717,14 +730,14 @@ struct Sim {
       if (d < margin) { add_contact(g1, g2, d, v - n * (0.5 * d), n, margin); cnt++; }
     }
   }
-  void collide_plane_convex(int g1, int g2, double margin) {
+  void collide_plane_convex(int g1, int g2, double margin) { UR5O_STRICT;
     V3 n = gxmat[g1].col(2);
     Shape s = make_shape(g2, 0.0);
     V3 v = support(s, -n);
     double d = dot(v - gxpos[g1], n);
     if (d < margin) add_contact(g1, g2, d, v - n * (0.5 * d), n, margin);
   }
-  void collide_sphere_sphere(int g1, int g2, double margin) {
+  void collide_sphere_sphere(int g1, int g2, double margin) { UR5O_STRICT;
     V3 d = gxpos[g2] - gxpos[g1];
     double len = norm(d), r1 = M.geom_size[3 * g1], r2 = M.geom_size[3 * g2];
     double dist = len - r1 - r2;
@@ -732,7 +745,7 @@ struct Sim {
     V3 n = len > 1e-12 ? d * (1.0 / len) : V3(1, 0, 0);
     add_contact(g1, g2, dist, gxpos[g1] + n * (r1 + 0.5 * dist), n, margin);
   }
-  void collide_sphere_box(int g1, int g2, double margin) {
+  void collide_sphere_box(int g1, int g2, double margin) { UR5O_STRICT;
     double r = M.geom_size[3 * g1];
     V3 s = v3(M.geom_size + 3 * g2);
     V3 cl = mulT(gxmat[g2], gxpos[g1] - gxpos[g2]);
@@ -759,7 +772,7 @@ struct Sim {
   // box partners analytically [3P: mjc_PlaneCapsule, mjc_SphereCapsule, mjc_CapsuleCapsule, mjc_CapsuleBox]; only their results'
   // shape is documented (two contacts for a capsule lying on a plane or a box face, one otherwise), so the routines below are own
   // restatements built from sphere tests at points of the segment. Other partners (cylinder, mesh) go through MPR as in MuJoCo.
-  void sphere_at_vs_sphere_at(int g1, int g2, V3 p1, double r1, V3 p2, double r2, double margin) {
+  void sphere_at_vs_sphere_at(int g1, int g2, V3 p1, double r1, V3 p2, double r2, double margin) { UR5O_STRICT;
     V3 d = p2 - p1;
     double len = norm(d), dist = len - r1 - r2;
     if (dist >= margin) return;
@@ -767,7 +780,7 @@ struct Sim {
     add_contact(g1, g2, dist, p1 + n * (r1 + 0.5 * dist), n, margin);
   }
   // sphere (centre c, radius r, geom g1) against box g2; returns the signed distance (1e300 when the pair was not evaluated)
-  double sphere_at_vs_box(int g1, int g2, V3 c, double r, double margin, bool emit) {
+  double sphere_at_vs_box(int g1, int g2, V3 c, double r, double margin, bool emit) { UR5O_STRICT;
     V3 s = v3(M.geom_size + 3 * g2);
     V3 cl = mulT(gxmat[g2], c - gxpos[g2]);
     V3 p(std::min(std::max(cl.x, -s.x), s.x), std::min(std::max(cl.y, -s.y), s.y), std::min(std::max(cl.z, -s.z), s.z));
@@ -786,7 +799,7 @@ struct Sim {
     if (emit) add_contact(g1, g2, -best - r, c + e * (0.5 * (best - r)), -e, margin);
     return -best - r;
   }
-  void collide_plane_capsule(int g1, int g2, double margin) {   // both end spheres
+  void collide_plane_capsule(int g1, int g2, double margin) { UR5O_STRICT;   // both end spheres
     V3 n = gxmat[g1].col(2), ax = gxmat[g2].col(2);
     double r = M.geom_size[3 * g2], h = M.geom_size[3 * g2 + 1];
     for (int e = 0; e < 2; e++) {
@@ -795,13 +808,13 @@ struct Sim {
       if (d < margin) add_contact(g1, g2, d, c - n * (r + 0.5 * d), n, margin);
     }
   }
-  void collide_sphere_capsule(int g1, int g2, double margin) {  // sphere against the nearest point of the segment
+  void collide_sphere_capsule(int g1, int g2, double margin) { UR5O_STRICT;  // sphere against the nearest point of the segment
     V3 ax = gxmat[g2].col(2);
     double h = M.geom_size[3 * g2 + 1];
     double t = std::min(std::max(dot(gxpos[g1] - gxpos[g2], ax), -h), h);
     sphere_at_vs_sphere_at(g1, g2, gxpos[g1], M.geom_size[3 * g1], gxpos[g2] + ax * t, M.geom_size[3 * g2], margin);
   }
-  void collide_capsule_capsule(int g1, int g2, double margin) {
+  void collide_capsule_capsule(int g1, int g2, double margin) { UR5O_STRICT;
     V3 a1 = gxmat[g1].col(2), a2 = gxmat[g2].col(2), w = gxpos[g1] - gxpos[g2];
     double h1 = M.geom_size[3 * g1 + 1], h2 = M.geom_size[3 * g2 + 1], r1 = M.geom_size[3 * g1], r2 = M.geom_size[3 * g2];
     double b = dot(a1, a2), d = dot(a1, w), e = dot(a2, w), den = 1.0 - b * b;
@@ -823,7 +836,7 @@ struct Sim {
     t1 = std::min(std::max(b * t2 - d, -h1), h1);           // re-project after clamping
     sphere_at_vs_sphere_at(g1, g2, gxpos[g1] + a1 * t1, r1, gxpos[g2] + a2 * t2, r2, margin);
   }
-  void collide_capsule_box(int g1, int g2, double margin) {
+  void collide_capsule_box(int g1, int g2, double margin) { UR5O_STRICT;
     V3 ax = gxmat[g1].col(2);
     double r = M.geom_size[3 * g1], h = M.geom_size[3 * g1 + 1];
     double d_hi = sphere_at_vs_box(g1, g2, gxpos[g1] + ax * h, r, margin, false), d_lo = sphere_at_vs_box(g1, g2, gxpos[g1] - ax * h, r, margin, false);
@@ -847,7 +860,7 @@ struct Sim {
 
   // box-box: separating-axis test + reference-face clipping (own algorithm; MuJoCo's mjc_BoxBox [3P] likewise
   // returns up to 8 points for face contacts and 1 for edge-edge)
-  void collide_box_box(int g1, int g2, double margin) {
+  void collide_box_box(int g1, int g2, double margin) { UR5O_STRICT;
     V3 pa = gxpos[g1], pb = gxpos[g2], a = v3(M.geom_size + 3 * g1), b = v3(M.geom_size + 3 * g2);
     const M3 &Ra = gxmat[g1], &Rb = gxmat[g2];
     V3 t = pb - pa;
@@ -939,7 +952,7 @@ struct Sim {
       if (d < margin) add_contact(g1, g2, d, poly[k] - nref * (0.5 * d), n, margin);
     }
   }
-  void collide_convex(int g1, int g2, double margin) {
+  void collide_convex(int g1, int g2, double margin) { UR5O_STRICT;
     Shape A = make_shape(g1, margin), B = make_shape(g2, margin);
     double depth; V3 dir, pos;
     if (!mpr_penetration(A, B, &depth, &dir, &pos)) return;
@@ -947,7 +960,7 @@ struct Sim {
     if (dist < margin) add_contact(g1, g2, dist, pos, dir, margin);
   }
 
-  void collision() {
+  void collision() { UR5O_STRICT;
     contacts.clear();
     if (!contacts_enabled) return;
     for (int p = 0; p < M.npair; p++) {
@@ -1167,12 +1180,12 @@ struct Sim {
       out[i] = s2;
     }
   }
-  // test hook (ur5o_set_cholesky_order): 1 = eliminate the dofs in REVERSED order. Mathematically the same solve; the rounding differs the way it differs between two
+  // test hook (ur5o_set_cholesky_order): 2 = pivots by reciprocal square root (below); 1 = eliminate the dofs in REVERSED order. Mathematically the same solve; the rounding differs the way it differs between two
   // implementations that factor in different orders (the HIP pile kernel eliminates by island and x position, this oracle by dof number) -- the "different text" twin of
   // tools/pile_divergence_time.py, next to the summation-order and 1-ulp twins.
   int cholesky_order = 0;
   bool dense_cholesky_solve(std::vector<double>& A, std::vector<double>& b) const {
-    if (cholesky_order == 0) return dense_cholesky_solve_natural(A, b);
+    if (cholesky_order == 0 || cholesky_order == 2) return dense_cholesky_solve_natural(A, b);
     std::vector<double> Ap((size_t)nv * nv), bp(nv);
     for (int i = 0; i < nv; i++) { bp[i] = b[nv - 1 - i]; for (int j = 0; j < nv; j++) Ap[(size_t)i * nv + j] = A[(size_t)(nv - 1 - i) * nv + (nv - 1 - j)]; }
     const bool ok = dense_cholesky_solve_natural(Ap, bp);
@@ -1184,6 +1197,16 @@ struct Sim {
       double d = A[(size_t)j * nv + j];
       for (int k = 0; k < j; k++) d -= A[(size_t)j * nv + k] * A[(size_t)j * nv + k];
       if (d < MINVAL) d = MINVAL;
+      if (cholesky_order == 2) {   // test hook: pivots through 1 / sqrt and multiplications, the way the HIP kernels factor (rsqrt + one Newton step): a "second text" twin
+        const double inv = 1.0 / std::sqrt(d);
+        A[(size_t)j * nv + j] = d * inv;
+        for (int i = j + 1; i < nv; i++) {
+          double v = A[(size_t)i * nv + j];
+          for (int k = 0; k < j; k++) v -= A[(size_t)i * nv + k] * A[(size_t)j * nv + k];
+          A[(size_t)i * nv + j] = v * inv;
+        }
+        continue;
+      }
       d = std::sqrt(d);
       A[(size_t)j * nv + j] = d;
       for (int i = j + 1; i < nv; i++) {
@@ -2031,6 +2054,7 @@ int ur5o_last_steps(void* h) { return ((Sim*)h)->last_steps; }
 // introspection
 void ur5o_body_xpos(void* h, double* out) { Sim* s = (Sim*)h; for (int b = 0; b < s->M.nbody; b++) for (int k = 0; k < 3; k++) out[3 * b + k] = s->xpos[b][k]; }
 void ur5o_body_xmat(void* h, double* out) { Sim* s = (Sim*)h; for (int b = 0; b < s->M.nbody; b++) memcpy(out + 9 * b, s->xmat[b].m, 72); }
+void ur5o_geom_pose(void* h, double* out) { Sim* s = (Sim*)h; for (int g = 0; g < s->M.ngeom; g++) { for (int k = 0; k < 3; k++) out[12 * g + k] = s->gxpos[g][k]; memcpy(out + 12 * g + 3, s->gxmat[g].m, 72); } }
 void ur5o_mass_matrix(void* h, double* out) { Sim* s = (Sim*)h; memcpy(out, s->Mm.data(), 8ull * s->nv * s->nv); }
 void ur5o_get_vec(void* h, int which, double* out) {
   Sim* s = (Sim*)h;

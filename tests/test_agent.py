@@ -187,3 +187,22 @@ def test_pipelined_scene_groups_on_gpu(model_it1):
     two = _loop(model_it1, None, 2, rounds=5, n=8, device="cuda", width=64)
     assert np.array_equal(one[0][:3], two[0][:3]) and one[4] == two[4] >= 6 and one[3] == two[3]
     assert abs(one[1][0] - two[1][0]) < 1e-4 * one[1][0] and np.allclose(one[1][:2], two[1][:2], rtol=0.05)
+
+
+@pytest.mark.gpu
+def test_late_group_selects_with_the_round_start_weights(model_it1):
+    """Round-5 advisor finding: group g's CNN forward runs on its own stream; nothing but an explicit event keeps the learner's optimiser steps (main stream, started as soon as
+    group 0's launch has run) from overwriting policy_net under a LATE group's forward. The hook delays groups 1.. by ~50 ms of GPU time and reads a flag that the main stream
+    sets right in front of its first optimiser step: every group must have chosen its actions before that flag is set (stream order, not numerics)."""
+    torch.manual_seed(0)
+    common = dict(file=model_it1, show_obs=False, observation="render", image_width=64, image_height=64, check_mode=1)
+    agent = BatchedGraspAgent(n_envs=8, device="cuda", mem_size=40, eps_start=0.5, eps_end=0.5, max_updates_per_round=4, pipeline_groups=2, **common)
+    for e in agent.envs:
+        e.reset()
+    agent._order_probe = dict(flag=torch.zeros(1, dtype=torch.int32, device="cuda"), delay_cycles=100_000_000, seen=[])
+    for _ in range(3):
+        out = agent.round()
+    torch.cuda.synchronize()
+    seen = torch.cat(agent._order_probe["seen"]).cpu().tolist()
+    assert len(seen) == 6 and seen == [0] * 6, seen
+    assert agent.learner.updates_done >= 4 and int(agent._order_probe["flag"].item()) == 1        # the learner did run, behind the flag

@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from mujoco_rl_ur5_amd.model import load_model
 from mujoco_rl_ur5_amd.native import BatchSim
 
-CHECKPOINTS = [5, 10, 20, 40, 80, 120, 160, 240, 320, 400, 480, 560, 640, 800, 1000, 1200, 1500, 1800]
+CHECKPOINTS = [5, 10, 20, 30, 40, 60, 80, 100, 120, 160, 240, 320, 400, 480, 560, 640, 800, 1000, 1200, 1500, 1800]
 src = sys.argv[1]
 out = sys.argv[2] if len(sys.argv) > 2 else src.replace(".npz", "_divergence_gpu.npz")
 D = np.load(src)

@@ -53,7 +53,7 @@ if g("SQ_ACTIVE_INST_VALU") and g("SQ_WAVE_CYCLES"): print("VALU busy share of r
 if g("SQ_WAIT_ANY") and g("SQ_WAVE_CYCLES"): print("waiting share (s_waitcnt / barriers) = SQ_WAIT_ANY / SQ_WAVE_CYCLES = %.3f; waiting to issue = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES = %.3f; issuing = SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES = %.3f" % (g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES"), g("SQ_WAIT_INST_ANY", 0) / g("SQ_WAVE_CYCLES"), g("SQ_ACTIVE_INST_ANY", 0) / g("SQ_WAVE_CYCLES")))
 PY
          ;;
-    py) args="${b:-} ${c:-}"; timeout 900 python $a ${args//:/ } > $OUT/$(basename $a .py).log 2>&1; tail -5 $OUT/$(basename $a .py).log ;;
+    py) args="${b:-} ${c:-} ${d:-}"; timeout 900 python $a ${args//:/ } > $OUT/$(basename $a .py).log 2>&1; tail -5 $OUT/$(basename $a .py).log ;;
     *) echo "unknown step $step" ;;
   esac
 done

@@ -20,20 +20,22 @@ CACHE = sys.argv[1].replace(".npz", "_oracle_trajectories.npz")       # the orac
 if sys.argv[2] == "oracle-only":                                      # python tools/pile_divergence_time.py <states.npz> oracle-only [threads] [limit]: fill the cache, no GPU file needed
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     G = None
-    CK = [5, 10, 20, 40, 80, 120, 160, 240, 320, 400, 480, 560, 640, 800, 1000, 1200, 1500, 1800]     # = tools/gpu_many_divergence.py CHECKPOINTS
+    CK = [5, 10, 20, 30, 40, 60, 80, 100, 120, 160, 240, 320, 400, 480, 560, 640, 800, 1000, 1200, 1500, 1800]     # = tools/gpu_many_divergence.py CHECKPOINTS
     n = min(int(sys.argv[4]), len(D["sel"])) if len(sys.argv) > 4 else len(D["sel"])
 else:
     G = {k: v for k, v in np.load(sys.argv[2]).items()}
     n = min(int(sys.argv[4]), len(G["qpos"])) if len(sys.argv) > 4 else len(G["qpos"])
     CK = G["checkpoints"].tolist()
 m = load_model("/UR5+gripper/UR5gripper_2_finger_many_objects.xml")
-VARIANTS = ("base", "reversed_contacts", "one_ulp", "reversed_elimination")
+VARIANTS = ("base", "reversed_contacts", "one_ulp", "reversed_elimination", "rsqrt_cholesky", "fma", "fma_rsqrt_cholesky", "fmadyn")
+# the last three (round 6): the SAME text on an independent arithmetic -- pivots by reciprocal square root (the HIP kernels' Cholesky), every a * b + c fused
+# (oracle/libur5_oracle_fma.so: -ffp-contract=fast -mfma), both; "fmadyn": fused dynamics, strict geometry -- the HIP pile unit's own split (libur5_oracle_fmadyn.so). The summation-order / 1-ulp / elimination-order twins share every other instruction with the oracle.
 THRESH = 1e-6
 
 
 def one(job):
     e, variant = job
-    o = Oracle(m)
+    o = Oracle(m, variant="fmadyn" if variant == "fmadyn" else ("fma" if variant.startswith("fma") else ""))
     q = D["qpos"][e].copy()
     if variant == "one_ulp":
         q[8] = np.nextafter(q[8], np.inf)
@@ -43,6 +45,8 @@ def one(job):
         o.set_contact_order(1)
     if variant == "reversed_elimination":
         o.set_cholesky_order(1)                              # the Newton solve factors the dofs in reversed order: what a second implementation does differently
+    if variant.endswith("rsqrt_cholesky"):
+        o.set_cholesky_order(2)
     o.set_checkpoints(CK)
     r, ps, pr = o.grasp_attempt(D["acts"][e], int(D["rots"][e]), 0)
     c = o.get_checkpoints()
