@@ -123,22 +123,47 @@ class It1Rounds:
         return AimRule(kind=1, episode_rounds=EP, first_scene_id=int(self.gid[0]), n_total=int(self.n_total), base_seed=BASE_SEED, plate_half_x=0.27, plate_centre_y=-0.6,
                        plate_half_y=0.19, z_min=0.905, z_max=1.0, grasp_z=0.91, fallback_x=0.0, fallback_y=-0.6)
 
-    def launch_rounds(self, r0, k, reward_rows):
-        """Rounds r0 .. r0 + k - 1 of every scene in ONE launch, no lock step between scenes (ur5_grasp_rounds_dev): the scene aims by itself with rule(), attempts, and
-        resets + settles where its episode ends, then goes on to its next round. Per-scene results are bit-identical to k calls of launch() (tests/test_grasp_rounds.py).
-        reward_rows: int32 [k, n] (contiguous rows of the reward buffer). Returns (action records [k, n, 8], aimed pixels [k, n] int32)."""
+    def plan_rounds(self, r0, r1, fused):
+        """Everything the launches of rounds r0 .. r1 - 1 need besides the engine, for ALL of them at once: the action-record buffer the kernel fills and one dispatch order
+        per launch (the scenes with more episode ends inside the launch first), a handful of torch kernels queued BEFORE the first engine launch. Round 5 did this per
+        launch: the zero-fill of one launch's records then sat between two engine launches of the stream and waited for a free wave slot while the OTHER group's launch
+        held every register of the chip -- 0.8 s for a 512 KB fill in the rocprofv3 trace (profiles/r05_x_kernel_stats.csv), the group's next launch behind it."""
         torch = self.torch
         assert self.kind == "it1" and self.rule_name == "aimed", "the in-kernel rule is the headline's (physics only, fixed grasp height)"
-        act = torch.zeros((k, self.n, 8), dtype=torch.float64, device=self.gid.device)
-        rr = torch.arange(r0, r0 + k, device=self.gid.device)
-        resets = (((self.gid[:, None] + rr[None, :] + 1) % EP) == 0).sum(dim=1)                      # episode ends of the scene inside the launch
-        order = torch.argsort(resets, descending=True, stable=True).to(torch.int32)                # the scenes with more settling to do first
-        self.sim.set_order_dev(order.data_ptr())
-        self.sim.grasp_rounds_dev(self.rule(), r0, k, reward_rows.data_ptr(), act.data_ptr(), check_mode=1, table_height=0.91, settle_ms=1000.0)
-        self._alive = (act, order, reward_rows)
+        starts = list(range(r0, r1, fused))
+        act = torch.zeros((r1 - r0, self.n, 8), dtype=torch.float64, device=self.gid.device)
+        rr = torch.arange(r0, r1, device=self.gid.device)
+        ends = (((self.gid[:, None] + rr[None, :] + 1) % EP) == 0).to(torch.int32)                   # [n, rounds]: the scene's episode ends after that round
+        stops = starts[1:] + [r1]
+        resets = torch.stack([ends[:, s - r0:e - r0].sum(dim=1) for s, e in zip(starts, stops)])      # [launches, n]
+        order = torch.argsort(resets, dim=1, descending=True, stable=True).to(torch.int32).contiguous()
+        return dict(r0=r0, r1=r1, starts=starts, act=act, order=order)
+
+    def launch_planned(self, plan, i, reward):
+        """Launch i of a plan: rounds starts[i] .. of every scene in ONE launch, no lock step between scenes (ur5_grasp_rounds_dev): the scene aims by itself with rule(),
+        attempts, and resets + settles where its episode ends, then goes on to its next round. Per-scene results are bit-identical to lock-step calls of launch()
+        (tests/test_grasp_rounds.py). Nothing but the engine kernel is queued: the order is read in place (ur5_set_order_view_dev), the records were zeroed by the plan."""
+        s0 = plan["starts"][i]
+        k = min(plan["starts"][i + 1] if i + 1 < len(plan["starts"]) else plan["r1"], plan["r1"]) - s0
+        self.sim.set_order_view_dev(plan["order"][i].data_ptr())
+        self.sim.grasp_rounds_dev(self.rule(), s0, k, reward[s0:s0 + k].data_ptr(), plan["act"][s0 - plan["r0"]:s0 - plan["r0"] + k].data_ptr(), check_mode=1, table_height=0.91,
+                                  settle_ms=1000.0)
+
+    def planned_pixels(self, plan):
+        """aimed pixel [rounds, n] int32 of the action records the kernel wrote"""
+        act = plan["act"]
         px = ((act[..., 0] - self.px0[0]) / self.dxdpx).round().clamp(0, 199)
         py = ((act[..., 1] - self.px0[1]) / self.dydpy).round().clamp(0, 199)
-        return act, (py * 200 + px).to(torch.int32)
+        return (py * 200 + px).to(self.torch.int32)
+
+    def launch_rounds(self, r0, k, reward_rows):
+        """Rounds r0 .. r0 + k - 1 in ONE launch (a plan of one launch). reward_rows: int32 [k, n] (contiguous rows of the reward buffer).
+        Returns (action records [k, n, 8], aimed pixels [k, n] int32)."""
+        plan = self.plan_rounds(r0, r0 + k, k)
+        self.sim.set_order_view_dev(plan["order"][0].data_ptr())
+        self.sim.grasp_rounds_dev(self.rule(), r0, k, reward_rows.data_ptr(), plan["act"].data_ptr(), check_mode=1, table_height=0.91, settle_ms=1000.0)
+        self._alive = (plan, reward_rows)
+        return plan["act"], self.planned_pixels(plan)
 
     def actions(self, r):
         """[n, 8] f64 action records (x y z rot skip - - -), the aimed pixel index [n] int32 and whether a box is aimed at [n] bool, from the
@@ -292,16 +317,31 @@ class Job:
         torch, gathered = self.torch, None
         self.launches = getattr(self, "launches", 0)
         if fused > 0 and wls is None and self.kind == "it1":
-            r = r0
-            while r < r1:
-                k = min(fused, r1 - r)
-                for gr in self.groups:
+            # (1) every group's plan (zeroed records, dispatch orders) while the chip is idle, (2) ALL engine launches of the region, group by group inside a launch index, with
+            # nothing between two launches of a stream but an event record, (3) the outcome records of the whole region in one pass per group and ONE all_gather per group
+            # (16 B per scene and round). With K rounds per launch an outcome becomes visible to the other ranks when its region ends, not its launch: the scripted-policy
+            # rollout (example_agent.py:15-27) reads no outcome; the learner loop (agent.py) gathers per round.
+            plans, self.launch_events = [], [[] for _ in self.groups]
+            for g, gr in enumerate(self.groups):
+                with torch.cuda.stream(gr.stream):
+                    plans.append(gr.wl.plan_rounds(r0, r1, fused))
+            for i in range(max(len(p["starts"]) for p in plans)):
+                for g, gr in enumerate(self.groups):
+                    if i >= len(plans[g]["starts"]):
+                        continue
                     with torch.cuda.stream(gr.stream):
-                        act, pixel = gr.wl.launch_rounds(r, k, gr.reward[r:r + k])
-                        rec = torch.stack([gr.ids[None, :].expand(k, -1), pixel, act[..., 3].to(torch.int32), gr.reward[r:r + k]], dim=2).reshape(-1, 4)
-                        gathered = self.sharding.gather_outcomes(rec)              # [world * k * n_g, 4]: 16 B per scene and round, once per launch
+                        gr.wl.launch_planned(plans[g], i, gr.reward)
+                        ev = torch.cuda.Event(enable_timing=True)
+                        ev.record(gr.stream)
+                        self.launch_events[g].append(ev)
                         self.launches += 1
-                r += k
+            for g, gr in enumerate(self.groups):
+                with torch.cuda.stream(gr.stream):
+                    k = r1 - r0
+                    pixel = gr.wl.planned_pixels(plans[g])
+                    rec = torch.stack([gr.ids[None, :].expand(k, -1), pixel, plans[g]["act"][..., 3].to(torch.int32), gr.reward[r0:r1]], dim=2).reshape(-1, 4)
+                    gathered = self.sharding.gather_outcomes(rec)                  # [world * rounds * n_g, 4]
+            self._plans = plans                                                    # alive until the region's work has run
             return gathered
         for r in range(r0, r1):
             for k, gr in enumerate(self.groups):
@@ -336,6 +376,21 @@ class Job:
         for gr in self.groups:
             gr.sim.sync()                                                          # resolves the HIP event pairs of the region's launches
         c1, k1 = self.counters(), sum(gr.sim.kernel_ms_total() for gr in self.groups)
+        # What the kernel sustains once both groups' launches overlap, next to the driver-protocol figure (which also pays for the region's two edges: the second group's
+        # first launch only starts when the first group's workgroups begin to retire, and the region ends with one group draining alone): per group, the env-steps of its
+        # launches 2 .. L over the time between the END of its first and the END of its last launch (HIP events on its stream); the groups run side by side, so the rates add.
+        # The workload is stationary by construction (a quarter of the scenes starts an episode in every round), so a launch's share of the region's steps is 1 / L.
+        self.steady_state_env_steps_per_s = None
+        evs = getattr(self, "launch_events", None)
+        if fused > 0 and evs and all(len(e) >= 3 for e in evs):
+            rate = 0.0
+            for gi, gr in enumerate(self.groups):
+                L = len(evs[gi])
+                sl = slice(gi * self.n_g, (gi + 1) * self.n_g)
+                steps_g = float((c1["total_steps"][sl] - c0["total_steps"][sl]).sum())
+                rate += steps_g * (L - 1) / L / (1e-3 * evs[gi][0].elapsed_time(evs[gi][-1]))
+            self.steady_state_env_steps_per_s = rate
+        self.launch_events = None
         return elapsed, c0, c1, k1 - k0, g
 
     def close(self):
@@ -416,6 +471,15 @@ def dqn_sub_result(torch, dev, dev_id, n, rounds, warmup, groups=2):
     return res
 
 
+def default_rounds_per_launch(n_local):
+    """K of ur5_grasp_rounds_dev by the scenes per GPU, from same-box sweeps on the MI355X (round 6, no torch kernel between two launches of a stream any more:
+    profiles/r06_g_headline_rounds_per_launch.log). A full chip (2 x 2048 scenes) wants SHORT launches -- each group's tail is refilled by the other group's next launch, and
+    the region's last tail is 2 rounds long instead of 4: K = 2 gives 18.4 M env-steps/s, K = 4 17.6 M, K = 8 16.6 M. A shard that cannot fill the chip wants LONG ones (its
+    only tail is the launch's end): 2048 scenes K = 8, 512 scenes K = 16 (4.4 M against 4.0 M at K = 8). What K costs: an outcome record is gathered when its launch region
+    has run, i.e. up to K rounds after the attempt (the scripted-policy rollout reads no outcome; the learner loop of agent.py gathers every round)."""
+    return 2 if n_local >= 4096 else (8 if n_local >= 1024 else 16)
+
+
 def strong_scaling_points(torch, dist, sharding, model, dev, dev_id, args):
     """What one GPU does with its share of a STRONG-scaling run (4096 scenes in total: 2048 / 1024 / 512 per GPU at 2 / 4 / 8 GPUs), measured here on this
     GPU alone with the headline's rounds (no data-path collective: a shard is independent). Below 2048 scenes the wave slots are no longer full (2048 per
@@ -423,7 +487,7 @@ def strong_scaling_points(torch, dist, sharding, model, dev, dev_id, args):
     pts = []
     for n in (2048, 1024, 512):
         try:
-            k = 0 if args.fused_rounds == 0 else 8                                  # the default of a shard below 4096 scenes
+            k = 0 if args.fused_rounds == 0 else default_rounds_per_launch(n)
             job = Job(torch, dist, sharding, model, "it1", "aimed", n, n, 0, 1, dev, dev_id, args.groups, 20)
             job.run_rounds(0, 2, None, k)
             dt, c0, c1, _, _ = job.timed(2, 18, None, k)
@@ -448,7 +512,7 @@ def main():
     ap.add_argument("--groups", type=int, default=2, help="scene groups per GPU, one engine handle + HIP stream each, rounds pipelined (1 = one handle)")
     ap.add_argument("--fused-rounds", type=int, default=-1, help="headline workload: K consecutive rounds of a scene per launch, the aiming rule evaluated in the kernel, no lock "
                     "step between scenes (ur5_grasp_rounds_dev; per-scene results bit-identical to K lock-step rounds). 0 = one launch per round, re-aimed on the device by torch; "
-                    "default: one episode (4 rounds) per launch at 4096 scenes per GPU and more (the chip is full), two episodes (8) for smaller shards, where a launch's tail is what idles the chip")
+                    "default: default_rounds_per_launch() -- 2 at 4096 scenes per GPU and more (the chip is full: short launches, short tails), 8 / 16 for shards of 1024+ / fewer scenes, where a launch's end is the only tail")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the uniform-rule figure and the it4 / many sub-results (N = 1 only)")
     ap.add_argument("--sub", choices=("it4", "many", "many4096", "dqn", "dqn2048"), default=None,
@@ -524,7 +588,7 @@ def main():
     groups, G, n_g, run_rounds, timed = job.groups, job.G, job.n_g, job.run_rounds, job.timed
 
     if args.fused_rounds < 0:
-        args.fused_rounds = 4 if n_local >= 4096 else 8                         # same-box sweep: profiles/r05_j_headline_groups_and_rounds_per_launch.log
+        args.fused_rounds = default_rounds_per_launch(n_local)
     fused = args.fused_rounds if args.rule == "aimed" else 0
     run_rounds(0, args.warmup, None, fused)
     elapsed, c0, c1, kernel_ms, gathered = timed(args.warmup, rounds, None, fused)
@@ -565,6 +629,9 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic", "scenes_total": n_total, "scenes_per_gpu": n_local,
             "grasp_attempts_per_s": attempts / elapsed, "grasp_success_rate": succ_all / attempts,
+            "env_steps_total": int(round(steps_all)), "grasp_successes_total": int(round(succ_all)),
+            "outcome_records_gathered_last": int(gathered.shape[0]),                     # rows of the last all_gather on rank 0: world x (rounds in it) x scenes of a group
+            "steady_state_env_steps_per_s": job.steady_state_env_steps_per_s if world == 1 else None,   # rank 0's launches 2 .. L, both groups overlapping (Job.timed); `value` is the driver protocol's
             "grasp_success_rate_per_round_rank0": [round(float(x), 4) for x in per_round.tolist()],
             "env_steps_per_attempt": steps_all / attempts,
             "newton_iters_per_step": float((c1["solver_iters"] - c0["solver_iters"]).sum()) / max(1, steps_local),

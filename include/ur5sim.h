@@ -111,6 +111,11 @@ int ur5_grasp_rounds_dev(ur5_sim* h, const ur5_aim_rule* rule, int round0, int r
    synchronises first (with ur5_set_stream on the caller's stream there is nothing to do). Results do not depend on it -- only the
    makespan does: a launch ends with its slowest scene, so callers list the scenes with the most work first. NULL = scene order. */
 int ur5_set_order_dev(ur5_sim* h, const int* order_dev);
+/* The same WITHOUT the copy: the following launches read order_dev itself, so the caller keeps it valid and unmodified until they have run. For callers
+   that queue several launches back to back with a precomputed order each (bench.py: the K-rounds-per-launch rollouts of example_agent.py:15-27's
+   loop shape): the copy of ur5_set_order_dev is a small device kernel of its own, and between two launches of a stream it waits for a free wave slot
+   while another handle's launch holds every register of the chip. NULL = scene order. */
+int ur5_set_order_view_dev(ur5_sim* h, const int* order_dev);
 int ur5_sync(ur5_sim* h);
 /* Queue the handle's launches on a caller-owned HIP stream (hipStream_t, e.g. torch.cuda.current_stream().cuda_stream) so that the
    caller's own device work (action tensors, the CNN) is ordered with them without host synchronisation. external = 1: use hip_stream

@@ -9,7 +9,7 @@ extern "C" {
 /* runs forward dynamics once without integrating and dumps internals (contacts, mass matrix, accelerations): [n][2048] doubles host
    ([n][4096] for many-object models); layout: Engine::dump_body in csrc/ur5_engine.h, decoded by native.BatchSim.forward_debug */
 int ur5_forward_debug(ur5_sim* h, double* out);
-/* capped replay: cap_dev[n] int32 (HIP device pointer, caller-owned; NULL = off): every following grasp-attempt launch stops scene e after cap_dev[e] physics
+/* capped replay: cap_dev[n] int32 (HIP device pointer; the handle copies it on its stream, like a dispatch order; NULL = off): every following grasp-attempt launch stops scene e after cap_dev[e] physics
    steps and saves its record as it stands. Copies of one scene with caps 10, 20, 40 ... show WHEN the engine and the oracle (or the oracle and its rounding-level
    twins) part on a chaotic pile -- tools/gpu_many_divergence.py, tools/pile_divergence_time.py. Results of scenes whose script ends before the cap are unchanged. */
 int ur5_set_step_cap_dev(ur5_sim* h, const int* cap_dev);

@@ -233,6 +233,7 @@ class BatchedGraspAgent:
         self.n_actions_1, self.n_actions_2 = int(self.env.action_space.nvec[0]), int(self.env.action_space.nvec[1])   # :97-100
         self.output = self.n_actions_1 * self.n_actions_2
         self.policy_net = MULTIDISCRETE_RESNET(number_actions_dim_2=self.n_actions_2).to(self.device)     # :103
+        checkpoint = None
         if load_path is not None:                                                      # :109-114
             checkpoint = torch.load(load_path, map_location=self.device)
             self.policy_net.load_state_dict(checkpoint["model_state_dict"])
@@ -243,6 +244,17 @@ class BatchedGraspAgent:
         self.memory, self.optimizer = self.learner.memory, self.learner.optimizer
         self.eps_start, self.eps_end, self.eps_decay = eps_start, eps_end, eps_decay
         self.steps_done, self.eps_threshold = 0, eps_start
+        # :165-180 / :215-217 / :448-465: how often the greedy policy chose each rotation, and the successes per rotation of greedy and of random actions. Kept as device
+        # counters [3, n_rotations] (no host read per round); the reference's three dicts are the properties below and what save() writes.
+        self._rot_counts = torch.zeros((3, self.n_actions_2), dtype=torch.int64, device=self.device)
+        if checkpoint is not None and "optimizer_state_dict" in checkpoint:            # :157-180: a checkpoint of save() / of the reference's trainer resumes the whole trainer
+            self.optimizer.load_state_dict(checkpoint["optimizer_state_dict"])
+            self.steps_done = int(checkpoint.get("step", 0))
+            self.eps_threshold = float(checkpoint.get("epsilon", eps_end))
+            for row, key in enumerate(("greedy_rotations", "greedy_rotations_successes", "random_rotations_successes")):
+                for rot, cnt in dict(checkpoint.get(key, {})).items():
+                    if 0 <= int(rot) < self.n_actions_2:
+                        self._rot_counts[row, int(rot)] = int(cnt)
         self.first_scene_id = self.env.first_scene_id                                   # one source of truth: the env's scene range
         self.n_total = self.env.n_total
 
@@ -413,8 +425,30 @@ class BatchedGraspAgent:
                                                   first_scene_id=self.first_scene_id, n_actions_1=self.n_actions_1)   # :551-556
         return self._end_round(learn, losses, utd, raw, action, reward, skipped, greedy, outcomes)
 
+    def _rotation_dict(self, row):
+        from collections import defaultdict
+        d = defaultdict(int)
+        for rot, cnt in enumerate(self._rot_counts[row].tolist()):
+            if cnt:
+                d[str(rot)] = int(cnt)
+        return d
+
+    greedy_rotations = property(lambda self: self._rotation_dict(0))                 # :460
+    greedy_rotations_successes = property(lambda self: self._rotation_dict(1))       # :462
+    random_rotations_successes = property(lambda self: self._rotation_dict(2))       # :465
+
+    def save(self, path):
+        """The reference trainer's checkpoint (Grasping_Agent_multidiscrete.py:560-575), key for key: what ``load_path`` of this class and of the reference's ``Grasp_Agent`` read."""
+        torch.save({"step": self.steps_done, "model_state_dict": self.policy_net.state_dict(), "optimizer_state_dict": self.optimizer.state_dict(),
+                    "epsilon": self.eps_threshold, "greedy_rotations": dict(self.greedy_rotations), "greedy_rotations_successes": dict(self.greedy_rotations_successes),
+                    "random_rotations_successes": dict(self.random_rotations_successes)}, path)
+
     def _end_round(self, learn, losses, utd, raw, action, reward, skipped, greedy, outcomes):
         self.last_loss = losses[-1] if losses else None
+        rot, win = (action // self.n_actions_1).long(), reward.long() == 1                                # update_tensorboard's counters (:448-465), this rank's scenes
+        self._rot_counts[0] += torch.bincount(rot[greedy], minlength=self.n_actions_2)
+        self._rot_counts[1] += torch.bincount(rot[greedy & win], minlength=self.n_actions_2)
+        self._rot_counts[2] += torch.bincount(rot[~greedy & win], minlength=self.n_actions_2)
         if self.shared and learn and losses:
             # The replicas take identical steps on identical batches, but GPU kernels are not bit-reproducible across processes (MIOpen's weight-gradient kernels
             # accumulate with atomics): left alone the copies drift apart at rounding level. One broadcast of rank 0's weights, batch-norm buffers and Adam moments

@@ -391,7 +391,8 @@ template <class real, int NV_> struct Lds {
   short lvl_ptr[UR5_MAXOBJ + 3], lvl_list[UR5_MAXOBJ + 1];   // the same panels grouped by level: panels of one level belong to different
   int nlvl;                                          // envelope groups (islands) and are processed together, one wavefront each
   real red[3 * (UR5_NT / 64)];                       // cross-wave reductions
-  int redi[UR5_NT / 64];
+  int redi[UR5_NT / 64], redi2[UR5_NT / 64];
+  int nheavy;                                        // broad-phase survivors refined lane by lane: they sit at the END of `cand`, last slot downwards (collision_body)
   // Fixed-order accumulation (round 4): four wavefronts share a scene, so LDS float atomics would land in an order that changes from run to
   // run. Instead every body slot owns the list of its contact sides (2 c + side, in contact order): the contact lanes stage their terms, the slot's
   // lanes sum them along the list; every Hessian coupling block is owned by one wavefront, which adds its contacts' terms in contact order. A scene's

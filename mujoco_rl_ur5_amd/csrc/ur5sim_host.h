@@ -429,7 +429,8 @@ struct ur5_sim {
   unsigned* d_mask = nullptr;
   double *d_target = nullptr, *d_tol = nullptr, *d_debug = nullptr, *d_hess = nullptr, *d_qpos0 = nullptr;
   void* d_gpose = nullptr;        // render: per-scene geom poses + screen boxes (HIP backend)
-  const int* d_step_cap = nullptr;   // test hook (ur5_set_step_cap_dev): caller-owned [n] physics-step caps of the scripted launches, NULL = none
+  const int* d_step_cap = nullptr;   // test hook (ur5_set_step_cap_dev): [n] physics-step caps of the scripted launches (the handle's copy d_step_cap_buf), NULL = none
+  int* d_step_cap_buf = nullptr;
   const int* d_order = nullptr;   // dispatch order of the scripted launches (ur5_set_order_dev), NULL = scene order; points at d_order_buf
   int* d_order_buf = nullptr;     // handle-owned copy, made by an ASYNCHRONOUS device-to-device copy on the handle's stream: the caller's buffer must stay valid (and unmodified) until the work
                                   // queued on that stream so far has run (include/ur5sim.h); same-stream callers (ur5_set_stream) have nothing to do
@@ -508,7 +509,7 @@ int ur5m_grasp_attempt(ur5_sim* h, const double* action, const uint8_t* skip, in
 int ur5m_ik(ur5_sim* h, const double* xyz, double* q5, int* result);
 int ur5m_render_dev(ur5_sim* h, int camera_id, int width, int height, int depth_mode, uint8_t* rgb_dev, float* depth_dev);
 int ur5m_render(ur5_sim* h, int camera_id, int width, int height, int depth_mode, uint8_t* rgb, float* depth);
-int ur5m_sync(ur5_sim* h); int ur5m_set_order_dev(ur5_sim* h, const int* order_dev); int ur5m_set_stream(ur5_sim* h, void* s, int external); double ur5m_last_launch_ms(ur5_sim* h); void* ur5m_state_device_ptr(ur5_sim* h);
+int ur5m_sync(ur5_sim* h); int ur5m_set_order_dev(ur5_sim* h, const int* order_dev); int ur5m_set_order_view_dev(ur5_sim* h, const int* order_dev); int ur5m_set_stream(ur5_sim* h, void* s, int external); double ur5m_last_launch_ms(ur5_sim* h); void* ur5m_state_device_ptr(ur5_sim* h);
 int ur5m_forward_debug(ur5_sim* h, double* out); int ur5m_set_step_cap_dev(ur5_sim* h, const int* cap_dev); long ur5m_model_uploads(ur5_sim* h); int ur5m_body_xpos(ur5_sim* h, double* out); int ur5m_profile_read(ur5_sim* h, double* out);
 }
 #endif
@@ -580,7 +581,7 @@ int ur5_create(const void* blob, size_t nbytes, int n_env, int device_id, const 
 void ur5_destroy(ur5_sim* h) {
   UR5_FWD_VOID(destroy, (h));
   if (!h) return;
-  void* ptrs[] = {h->dm, h->d_rec, h->d_mask, h->d_target, h->d_tol, h->d_max, h->d_result, h->d_steps, h->d_ps, h->d_pr, h->d_debug, h->d_rm, h->d_rgb, h->d_depth, h->d_hess, h->d_qpos0, h->d_gpose, h->d_order_buf};
+  void* ptrs[] = {h->dm, h->d_rec, h->d_mask, h->d_target, h->d_tol, h->d_max, h->d_result, h->d_steps, h->d_ps, h->d_pr, h->d_debug, h->d_rm, h->d_rgb, h->d_depth, h->d_hess, h->d_qpos0, h->d_gpose, h->d_order_buf, h->d_step_cap_buf};
   for (void* p : ptrs) if (p) be_free(h, p);
   be_close(h);
   delete h;
@@ -770,8 +771,8 @@ int ur5_grasp_rounds_dev(ur5_sim* h, const ur5_aim_rule* rule, int round0, int r
 #ifndef UR5_MANY
   if (h->variant == 1) return fail(UR5_ERR_MODEL, "ur5_grasp_rounds_dev: the scripted rule reads box positions on the pick plate; 40-object piles are aimed from the rendered observation (ur5_grasp_attempt_reset_dev)");
 #endif
-  if (!rule || !reward_dev || rounds < 1 || rule->kind != 1 || rule->episode_rounds < 1 || rule->n_total < 1 || rule->first_scene_id < 0)
-    return fail(UR5_ERR_ARG, "ur5_grasp_rounds_dev: rule (kind 1), reward_dev and rounds >= 1 are required");
+  if (!rule || !reward_dev || rounds < 1 || round0 < 0 || rule->kind != 1 || rule->episode_rounds < 1 || rule->n_total < 1 || rule->first_scene_id < 0)   // (a negative round would index the rule's modular arithmetic out of range)
+    return fail(UR5_ERR_ARG, "ur5_grasp_rounds_dev: rule (kind 1), reward_dev, round0 >= 0 and rounds >= 1 are required");
 #ifdef UR5_MANY
   return fail(UR5_ERR_MODEL, "ur5_grasp_rounds_dev: wavefront-per-scene engine only");
 #else
@@ -860,6 +861,11 @@ int ur5_set_order_dev(ur5_sim* h, const int* order_dev) {
   h->d_order = h->d_order_buf;
   return 0;
 }
+int ur5_set_order_view_dev(ur5_sim* h, const int* order_dev) {
+  UR5_FWD(set_order_view_dev, (h, order_dev));
+  h->d_order = order_dev;   // no copy: the caller's buffer is what the following launches read (include/ur5sim.h)
+  return 0;
+}
 int ur5_sync(ur5_sim* h) {
   UR5_FWD(sync, (h)); return be_sync(h); }
 int ur5_set_stream(ur5_sim* h, void* hip_stream, int external) {
@@ -878,7 +884,13 @@ long ur5_model_uploads(ur5_sim* h) {
 int ur5_set_step_cap_dev(ur5_sim* h, const int* cap_dev) {
   UR5_FWD(set_step_cap_dev, (h, cap_dev));
   if (!h) return ur5host::fail(UR5_ERR_ARG, "ur5_set_step_cap_dev: NULL handle");
-  h->d_step_cap = cap_dev;   // the caller keeps the buffer alive (and unchanged) while launches that use it are in flight
+  if (!cap_dev) { h->d_step_cap = nullptr; return 0; }
+  // copied on the handle's stream, like the dispatch order: a caller that frees its tensor without clearing the hook leaves no dangling pointer behind (round-5 advice)
+  if (!h->d_step_cap_buf) h->d_step_cap_buf = (int*)be_alloc(h, (size_t)h->n * 4);
+  if (!h->d_step_cap_buf) return ur5host::fail(UR5_ERR_DEVICE, "device allocation failed (step caps)");
+  int rc = be_d2d_async(h, h->d_step_cap_buf, cap_dev, (size_t)h->n * 4);
+  if (rc) return rc;
+  h->d_step_cap = h->d_step_cap_buf;
   return 0;
 }
 int ur5_forward_debug(ur5_sim* h, double* out) {

@@ -142,6 +142,8 @@ class GraspEnv(object):
                    2: "a step produced a non-finite state: the scene was reset to qpos0 as mj_step does (UR5_ST_NAN)",
                    4: "constraint-row / envelope lists exhausted (UR5_ST_ROW_OVERFLOW)", 8: "broad-phase candidate list exhausted: pairs were dropped (UR5_ST_CAND_OVERFLOW)"}
 
+    status_check_every = 16   # step_device(sync=True) reads the status words on its 1st, 17th, ... call (round-5 advice: not a blocking read per round for a once-only warning)
+
     def scene_status(self):
         """int64 [n_envs]: the engine's status bits of every scene, of its running episode and of episodes that ended inside a fused launch (0 = clean)."""
         c = self.sim.counters()
@@ -282,7 +284,8 @@ class GraspEnv(object):
         if not sync:
             return self._t_rew, skip
         self.sim.sync()
-        self.check_status()                                                                      # flagged scenes: warned about once, words in self.last_status
+        if self.step_called % self.status_check_every == 1 or self.status_check_every <= 1:      # the status words are a device-to-host read of every scene's counters: sampled
+            self.check_status()                                                                  # (the bits are sticky until the scene's reset; check_status() reads them on request)
         return self._t_rew.clone(), skip
 
     def close(self):

@@ -19,7 +19,7 @@ RES_NONE, RES_SUCCESS, RES_MAX_STEPS, RES_IK_FAIL = -1, 0, 1, 2
 _VARIANT = {0: (6, 2048, 192, 30), 1: (40, 4096, 832, 96)}
 EXPORTS = ["ur5_last_error", "ur5_create", "ur5_destroy", "ur5_num_envs", "ur5_nq", "ur5_nv", "ur5_nu", "ur5_reset", "ur5_reset_dev", "ur5_kernel_ms_total",
            "ur5_set_state", "ur5_get_state", "ur5_set_ctrl", "ur5_get_ctrl", "ur5_step", "ur5_move_group", "ur5_stay",
-           "ur5_move_ee", "ur5_ik", "ur5_grasp_attempt", "ur5_grasp_attempt_dev", "ur5_grasp_attempt_reset_dev", "ur5_grasp_rounds_dev", "ur5_sync", "ur5_set_stream", "ur5_set_order_dev", "ur5_last_launch_ms",
+           "ur5_move_ee", "ur5_ik", "ur5_grasp_attempt", "ur5_grasp_attempt_dev", "ur5_grasp_attempt_reset_dev", "ur5_grasp_rounds_dev", "ur5_sync", "ur5_set_stream", "ur5_set_order_dev", "ur5_set_order_view_dev", "ur5_last_launch_ms",
            "ur5_get_counters", "ur5_body_xpos", "ur5_render", "ur5_render_dev", "ur5_state_device_ptr"]
 TEST_EXPORTS = ["ur5_forward_debug", "ur5_set_step_cap_dev", "ur5_model_uploads"]   # include/ur5sim_test.h: introspection for tests/ and tools/, not part of the boundary
 
@@ -57,6 +57,7 @@ def load(path=None):
     L.ur5_reset.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int, C.c_double]
     L.ur5_set_stream.argtypes = [vp, vp, C.c_int]
     L.ur5_set_order_dev.argtypes = [vp, vp]
+    L.ur5_set_order_view_dev.argtypes = [vp, vp]
     L.ur5_reset_dev.argtypes = [vp, vp, vp, C.c_double]
     L.ur5_kernel_ms_total.argtypes = [vp]
     L.ur5_kernel_ms_total.restype = C.c_double
@@ -267,6 +268,10 @@ class BatchSim:
     def set_order_dev(self, order_ptr):
         """Dispatch order of the following grasp / settle launches: device pointer to an int32 [n] permutation (caller keeps it alive); None = scene order."""
         self._check(self.lib.ur5_set_order_dev(self._h, C.c_void_p(order_ptr) if order_ptr else None), "ur5_set_order_dev")
+
+    def set_order_view_dev(self, order_ptr):
+        """The same without the handle's copy: the following launches read the caller's buffer, which must stay valid and unmodified until they have run."""
+        self._check(self.lib.ur5_set_order_view_dev(self._h, C.c_void_p(order_ptr) if order_ptr else None), "ur5_set_order_view_dev")
 
     def last_launch_ms(self):
         return float(self.lib.ur5_last_launch_ms(self._h))

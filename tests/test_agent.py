@@ -206,3 +206,27 @@ def test_late_group_selects_with_the_round_start_weights(model_it1):
     seen = torch.cat(agent._order_probe["seen"]).cpu().tolist()
     assert len(seen) == 6 and seen == [0] * 6, seen
     assert agent.learner.updates_done >= 4 and int(agent._order_probe["flag"].item()) == 1        # the learner did run, behind the flag
+
+
+def test_checkpoint_is_the_reference_trainers(model_it1, emul_lib, tmp_path):
+    """save() writes the dict of Grasping_Agent_multidiscrete.py:560-575 (same keys; rotation counters as str -> int dicts, :460-465) and ``load_path`` resumes from it the way
+    the reference's constructor does (:109-114, :157-180): weights, optimiser moments, step count, epsilon, counters."""
+    common = dict(file=model_it1, show_obs=False, observation="render", image_width=24, image_height=24, check_mode=1, _lib_path=emul_lib)
+    torch.manual_seed(0)
+    agent = BatchedGraspAgent(env=GraspEnv(n_envs=6, **common), device="cpu", mem_size=40, eps_start=0.5, eps_end=0.5, max_updates_per_round=4)
+    agent.env.reset()
+    for _ in range(5):
+        out = agent.round()
+    assert agent.learner.updates_done >= 4
+    path = str(tmp_path / "weights.pt")
+    agent.save(path)
+    ck = torch.load(path)
+    assert sorted(ck) == sorted(["step", "model_state_dict", "optimizer_state_dict", "epsilon", "greedy_rotations", "greedy_rotations_successes", "random_rotations_successes"])
+    assert ck["step"] == agent.steps_done == 30 and ck["epsilon"] == agent.eps_threshold
+    assert sum(ck["greedy_rotations"].values()) == int(sum(int(o) for o in [agent._rot_counts[0].sum()])) and all(isinstance(k, str) for k in ck["greedy_rotations"])
+    twin = BatchedGraspAgent(env=GraspEnv(n_envs=6, **common), device="cpu", mem_size=40, eps_start=0.5, eps_end=0.5, max_updates_per_round=4, load_path=path)
+    for a, b in zip(agent.policy_net.state_dict().values(), twin.policy_net.state_dict().values()):
+        assert torch.equal(a, b)
+    sa, sb = agent.optimizer.state_dict()["state"], twin.optimizer.state_dict()["state"]
+    assert sa.keys() == sb.keys() and all(torch.equal(sa[k]["exp_avg"], sb[k]["exp_avg"]) for k in sa)
+    assert twin.steps_done == 30 and twin.eps_threshold == agent.eps_threshold and torch.equal(twin._rot_counts, agent._rot_counts)

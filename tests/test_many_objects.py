@@ -320,22 +320,22 @@ def _forward_parity_from_engine_state(model, sim, scene, min_contacts):
     oc = o.contacts()
     assert d["ncon"][scene] == len(oc) and len(oc) >= min_contacts, (d["ncon"][scene], len(oc))
     ec = d["contacts"][scene][:len(oc)]
+    # Round 6: BIT-equal. Both lists are in geom-pair order; every contact between objects, and between an object and the bins, has the oracle's distance, position and
+    # normal word for word (the pile unit's kinematics and collision follow the oracle's text without fused multiply-adds: tools/contact_bits.py, 3 610 of 3 610 contacts on
+    # the MI355X). Rounds 3-5 accepted 1e-8 m / 1e-6 / 1e-10 m here and one portal flip per scene (a 5e-3 jump of a normal, 1 contact in 935: the two texts then differed in
+    # the last bit of a quaternion normalisation and of the box-box vertices). Contacts of a ROBOT geom keep those bounds: the arm's kinematics is another text by design.
+    gb = np.asarray(model.geom_bodyid)
     flips = 0
-    for c in oc:                                                      # contact order differs (pair order vs slot claiming)
-        best = min(ec, key=lambda e: np.abs(e[1:4] - c[1:4]).sum())
-        # Round 3: the many-object kernel computes kinematics and collision without fused multiply-adds, like the oracle (-ffp-contract=off): from the same
-        # state it reproduces the oracle's contacts -- measured on 24 settled piles (tools/gpu_many_forward_errors.py): 934 of 935 contacts to 3e-10 m /
-        # 4e-8 (normal) / 4e-16 m (depth), qacc to 9e-9 relative in the 23 scenes without a flip (it was 5e-3 with fused arithmetic). What is left is
-        # MPR's discontinuity itself: oracle and engine are two texts of one algorithm, and where a portal decision falls on a last-bit difference of an
-        # association order the refinement takes another face (1 contact in 935; its normal moves by ~5e-3).
-        ok = np.abs(best[1:4] - c[1:4]).max() < 1e-8 and np.abs(best[4:7] - c[4:7]).max() < 1e-6 and abs(best[0] - c[0]) < 1e-10
-        if not ok:
-            assert np.abs(best[1:4] - c[1:4]).max() < 2e-2 and np.abs(best[4:7] - c[4:7]).max() < 5e-2, (best, c)
+    for e, c in zip(ec, oc):
+        robot = any(model.body_treeid[int(gb[int(g)])] == 0 for g in (c[7], c[8]))   # the robot's kinematic tree (the bins and the floor have none)
+        if robot:
+            assert np.abs(e[1:4] - c[1:4]).max() < 1e-8 and np.abs(e[4:7] - c[4:7]).max() < 1e-6 and abs(e[0] - c[0]) < 1e-10, (e, c)
+        elif not np.array_equal(e[:7].view(np.uint64), c[:7].view(np.uint64)):
             flips += 1
-    assert flips <= 1, flips
+    assert flips == 0, flips
     qacc = o.vec("qacc")
     err = np.abs(d["qacc"][scene][:model.nv] - qacc).max() / max(1.0, np.abs(qacc).max())
-    assert err < (1e-6 if flips == 0 else 5e-2), (err, flips)
+    assert err < 1e-9, err                                            # (round 5: 1e-6; measured 1e-14 on the lane emulation, tools/pile_early_divergence.py has the trajectories)
     return flips
 
 
@@ -347,7 +347,7 @@ def test_settled_pile_forward_parity_on_gpu(model_many):
     sim.reset(300 + np.arange(8, dtype=np.uint64), 1, 1000.0)
     assert sim.counters()["status"].max() == 0
     flips = sum(_forward_parity_from_engine_state(model_many, sim, scene, 30) for scene in range(8))
-    assert flips <= 2, flips                                              # eight piles, ~300 contacts at ~1 flip per 900
+    assert flips == 0, flips                                              # eight piles, ~300 contacts, every one the oracle's bits
 
 
 @pytest.mark.gpu
@@ -375,8 +375,8 @@ def test_pile_grasp_bits_against_the_oracle_on_gpu(model_many):
     rew, ps, pr = sim.grasp_attempt(acts, rot=rots, check_mode=0)
     assert sim.counters()["status"].max() == 0
 
-    CK = [10, 40, 120, 240, 400, 640, 1000]                                   # physics steps into the attempt at which trajectories are compared (below)
-    NT = 8                                                                    # scenes that also get a rounding-level twin of the oracle
+    CK = [10, 20, 40, 60, 80, 100, 120, 160, 240, 400, 640, 1000]            # physics steps into the attempt at which trajectories are compared (below)
+    NT = 12                                                                   # scenes that also get a rounding-level twin of the oracle
 
     def one(job):
         e, twin = job
@@ -417,8 +417,15 @@ def test_pile_grasp_bits_against_the_oracle_on_gpu(model_many):
         return int(bad[0]) if len(bad) else K
     kernel_idx = [first(gq[i], allres[i][2]) for i in range(NT)]
     twin_idx = [first(allres[n + i][2], allres[i][2]) for i in range(NT)]
-    assert np.abs(gq[:, 0] - np.stack([allres[i][2][0] for i in range(NT)])).max() < 1e-7, "ten steps in, kernel and oracle still agree to rounding"
-    assert np.median(kernel_idx) >= np.median(twin_idx) - 1 and min(kernel_idx) >= 1, (kernel_idx, twin_idx)
+    # Round 6: contacts bit-equal to the oracle's from the same state and the position update in the oracle's arithmetic (csrc/ur5_engine_integrate.inc): ten steps in, the
+    # kernel is where the oracle's own rounding twins are (1e-15; round 5: 1e-13, bound 1e-7), and it parts from the oracle WHEN the twin does -- the round-5 form of this
+    # line granted the kernel one checkpoint of a four-point grid, i.e. a factor 3 in steps. (256 scenes: tools/pile_divergence_time.py, profiles/r06_pile_divergence_time.json.)
+    assert np.abs(gq[:, 0] - np.stack([allres[i][2][0] for i in range(NT)])).max() < 1e-12, "ten steps in, kernel and oracle agree to rounding"
+    kernel_steps, twin_steps = [(CK + [2 * CK[-1]])[i] for i in kernel_idx], [(CK + [2 * CK[-1]])[i] for i in twin_idx]
+    # Twelve scenes are a small sample of a wide distribution (quartiles 60 - 120 over 256 scenes): the suite asks for the verdict's absolute bar -- a median of at least 72
+    # steps; round 5: 40 -- and for the twin's median within one step of THIS grid (80 -> 100); the 256-scene statistic with the 0.9 x control-twin criterion is
+    # profiles/r06_pile_divergence_time.json (kernel 80 steps, control twins 80).
+    assert np.median(kernel_steps) >= 72 and np.median(kernel_steps) >= 0.75 * np.median(twin_steps) and min(kernel_idx) >= 1, (kernel_steps, twin_steps)
     assert sum(orew) >= 2, orew                                               # a statistic with positives (28 % in the 256-scene run)
     # Piles are chaotic, and round 4 measured how chaotic (tools/pile_chaos_floor.py, profiles/r04_pile_chaos_floor_256of3072.json): the ORACLE agrees with its own
     # rounding-level twins -- the same contacts in reversed order, one coordinate moved by 1 ulp -- on 94.5-96.1 % of the grasp bits and 89-91 % of the result codes of
@@ -488,7 +495,7 @@ def _arm_contact_state(model):
 
 
 def _check_arm_hull_contact(model, sim, tol=(1e-9, 1e-9, 1e-9, 1e-7)):
-    """tol = (contact point, normal, depth, relative qacc); the GPU build runs MPR in fused arithmetic, see _forward_parity_from_engine_state"""
+    """tol = (contact point, normal, depth, relative qacc)"""
     arm_geoms = {g for g in range(model.ngeom) if model.geom_meshid[g] >= 0 and model.names["mesh"][model.geom_meshid[g]] in ARM_MESHES}
     assert len(arm_geoms) == 7 and all(model.geom_collide[g] for g in arm_geoms)
     o, state = _arm_contact_state(model)
@@ -545,7 +552,11 @@ def test_small_engine_rejects_arm_hulls_loudly(emul_lib):
 def test_arm_link_hulls_on_gpu(model_many_armcol):
     sim = BatchSim(model_many_armcol, 2)
     assert sim.variant == 1
-    _check_arm_hull_contact(model_many_armcol, sim, tol=(2e-5, 1e-4, 1e-5, 5e-3))
+    # Round 6: the bounds of the shipped scene's forward parity (_forward_parity_from_engine_state: 1e-8 m / 1e-6 / 1e-10 m, qacc 1e-6 relative). Round 5 accepted 2e-5 / 1e-4 /
+    # 1e-5 / 5e-3 here with a comment from round 2 ("the GPU build runs MPR in fused arithmetic"); the pile unit has compiled its geometry without fused multiply-adds
+    # since round 3, and what is left between the two sides of a ROBOT contact is the arm's kinematics (Rodrigues + pointer jumping against the oracle's quaternion
+    # chain: 1e-16 in the hull's pose).
+    _check_arm_hull_contact(model_many_armcol, sim, tol=(1e-8, 1e-6, 1e-10, 1e-6))
     sim.reset(20 + np.arange(2, dtype=np.uint64), 1, 0.0)
     _drop_parity(model_many_armcol, sim, 1, 21, 25, 1e-9)
 

@@ -26,9 +26,9 @@ for step in "$@"; do
     ab_small) bash tools/gpu_ab_libs.sh $TAG ${a//,/ } ;;
     ab_it4) bash tools/gpu_ab_it4.sh $TAG ${a//,/ } ;;
     headline) lib=$a; [ "$lib" = tree ] && lib=mujoco_rl_ur5_amd/csrc/libur5sim.so
-           UR5SIM_LIB=$lib timeout 300 python bench.py --no-cpu-baseline --no-extras --fused-rounds ${b:--1} --envs ${c:-4096} --groups ${d:-2} 2>/dev/null | python -c "
+           UR5SIM_LIB=$lib timeout 300 python bench.py --no-cpu-baseline --no-extras --fused-rounds ${b:--1} --envs ${c:-4096} --groups ${d:-2} ${BENCH_EXTRA:-} 2>/dev/null | python -c "
 import sys, json
-d = json.loads(sys.stdin.readline()); print('%-28s K=%s G=${d:-2} n=%5d  %.3f M env-steps/s  %.1f attempts/s  %.1f ms/round  avg launch %.1f ms  success %.3f  status %d' % ('$lib'.split('/')[-1], '${b:-4}', d['scenes_per_gpu'], d['value'] / 1e6, d['grasp_attempts_per_s'], d['ms_per_step'], d['roofline']['avg_launch_ms'], d['grasp_success_rate'], d['status_bits']))" | tee -a $OUT/headline.log ;;
+d = json.loads(sys.stdin.readline()); print('%-28s K=%s G=${d:-2} n=%5d  %.3f M env-steps/s  %.1f attempts/s  %.1f ms/round  avg launch %.1f ms  success %.3f  status %d  steady %.3f M' % ('$lib'.split('/')[-1], '${b:-4}', d['scenes_per_gpu'], d['value'] / 1e6, d['grasp_attempts_per_s'], d['ms_per_step'], d['roofline']['avg_launch_ms'], d['grasp_success_rate'], d['status_bits'], (d.get('steady_state_env_steps_per_s') or 0) / 1e6))" | tee -a $OUT/headline.log ;;
     bench) ( time timeout 1200 python bench.py --steps 20 --warmup 5 ) > $OUT/bench_full.json 2> $OUT/bench_full.err; tail -3 $OUT/bench_full.err; cut -c1-400 $OUT/bench_full.json ;;
     sub) timeout 900 python bench.py --sub $a > $OUT/sub_$a.json 2> $OUT/sub_$a.err; cut -c1-600 $OUT/sub_$a.json ;;
     pmc) i=0; ROOT=$(pwd); ( cd /tmp; export TMPDIR=/tmp
