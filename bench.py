@@ -110,6 +110,8 @@ class It1Rounds:
             px = pixel.long()
             act[:, 2] = self.cam_z - self.dep[torch.arange(self.n, device=px.device), px // 200, px % 200].double()
         est = torch.where(any_on, 2300, 1300) + torch.where(seeds != 0, 500, 0)   # expected physics steps of the scene in this launch
+        if os.environ.get("UR5_BENCH_ORDER_RESETS_ONLY"):                          # experiment: what the order is worth (the in-kernel rule cannot know `any_on` before the launch)
+            est = torch.where(seeds != 0, 500, 0)
         order = torch.argsort(est, descending=True, stable=True).to(torch.int32)
         self.sim.set_order_dev(order.data_ptr())
         self.sim.grasp_attempt_reset_dev(act.data_ptr(), reward_row.data_ptr(), seeds.data_ptr(), check_mode=check_mode, table_height=0.91,
@@ -118,10 +120,13 @@ class It1Rounds:
         return act, pixel
 
     def rule(self):
-        """The headline's aiming rule as the engine evaluates it in the kernel (include/ur5sim.h ur5_aim_rule, kind 1): exactly `actions()` below for rule "aimed"."""
+        """The aiming rule as the engine evaluates it in the kernel (include/ur5sim.h ur5_aim_rule): exactly `actions()` below for rule "aimed" -- kind 1 (an object still on
+        the pick plate) for the small scenes, kind 2 (the pile box rule) for 40-object piles; the rendered workloads take the grasp height from the depth image the scene
+        renders for itself at the start of the round (z_from_depth, ur5_set_observation_dev), through the top-down camera's pixel map at table height."""
         from mujoco_rl_ur5_amd.native import AimRule
-        return AimRule(kind=1, episode_rounds=EP, first_scene_id=int(self.gid[0]), n_total=int(self.n_total), base_seed=BASE_SEED, plate_half_x=0.27, plate_centre_y=-0.6,
-                       plate_half_y=0.19, z_min=0.905, z_max=1.0, grasp_z=0.91, fallback_x=0.0, fallback_y=-0.6)
+        cam = {} if self.kind == "it1" else dict(z_from_depth=1, cam_x0=self.px0[0], cam_y0=self.px0[1], cam_dx=self.dxdpx, cam_dy=self.dydpy, cam_z=self.cam_z)
+        return AimRule(kind=2 if self.kind == "many" else 1, episode_rounds=EP, first_scene_id=int(self.gid[0]), n_total=int(self.n_total), base_seed=BASE_SEED, plate_half_x=0.27,
+                       plate_centre_y=-0.6, plate_half_y=0.19, z_min=0.905, z_max=1.0, grasp_z=0.91, fallback_x=0.0, fallback_y=-0.6, **cam)
 
     def plan_rounds(self, r0, r1, fused):
         """Everything the launches of rounds r0 .. r1 - 1 need besides the engine, for ALL of them at once: the action-record buffer the kernel fills and one dispatch order
@@ -129,7 +134,7 @@ class It1Rounds:
         launch: the zero-fill of one launch's records then sat between two engine launches of the stream and waited for a free wave slot while the OTHER group's launch
         held every register of the chip -- 0.8 s for a 512 KB fill in the rocprofv3 trace (profiles/r05_x_kernel_stats.csv), the group's next launch behind it."""
         torch = self.torch
-        assert self.kind == "it1" and self.rule_name == "aimed", "the in-kernel rule is the headline's (physics only, fixed grasp height)"
+        assert self.rule_name == "aimed", "the rules the kernel evaluates are the aimed ones"
         starts = list(range(r0, r1, fused))
         act = torch.zeros((r1 - r0, self.n, 8), dtype=torch.float64, device=self.gid.device)
         rr = torch.arange(r0, r1, device=self.gid.device)
@@ -137,7 +142,17 @@ class It1Rounds:
         stops = starts[1:] + [r1]
         resets = torch.stack([ends[:, s - r0:e - r0].sum(dim=1) for s, e in zip(starts, stops)])      # [launches, n]
         order = torch.argsort(resets, dim=1, descending=True, stable=True).to(torch.int32).contiguous()
-        return dict(r0=r0, r1=r1, starts=starts, act=act, order=order)
+        plan = dict(r0=r0, r1=r1, starts=starts, act=act, order=order)
+        if self.kind != "it1":
+            # the rendered workloads (round 6): every scene renders its own 200x200 RGB-D observation at the start of each of its rounds, inside the launch
+            # (ur5_set_observation_dev); one frame per round of a launch, so that a launch leaves the observations of all its rounds behind
+            frames = min(fused, r1 - r0)
+            if getattr(self, "_frames", None) is None or self._frames[0].shape[0] < frames:
+                self._frames = (torch.zeros((frames, self.n, 200, 200, 3), dtype=torch.uint8, device=self.gid.device),
+                                torch.zeros((frames, self.n, 200, 200), dtype=torch.float32, device=self.gid.device))
+            self.sim.set_observation_dev(self._frames[0].data_ptr(), self._frames[1].data_ptr(), self.cam_id, 200, 200, frames=int(self._frames[0].shape[0]))
+            plan["frames"] = self._frames
+        return plan
 
     def launch_planned(self, plan, i, reward):
         """Launch i of a plan: rounds starts[i] .. of every scene in ONE launch, no lock step between scenes (ur5_grasp_rounds_dev): the scene aims by itself with rule(),
@@ -146,8 +161,8 @@ class It1Rounds:
         s0 = plan["starts"][i]
         k = min(plan["starts"][i + 1] if i + 1 < len(plan["starts"]) else plan["r1"], plan["r1"]) - s0
         self.sim.set_order_view_dev(plan["order"][i].data_ptr())
-        self.sim.grasp_rounds_dev(self.rule(), s0, k, reward[s0:s0 + k].data_ptr(), plan["act"][s0 - plan["r0"]:s0 - plan["r0"] + k].data_ptr(), check_mode=1, table_height=0.91,
-                                  settle_ms=1000.0)
+        self.sim.grasp_rounds_dev(self.rule(), s0, k, reward[s0:s0 + k].data_ptr(), plan["act"][s0 - plan["r0"]:s0 - plan["r0"] + k].data_ptr(),
+                                  check_mode=1 if self.kind == "it1" else 0, table_height=0.91, settle_ms=1000.0)
 
     def planned_pixels(self, plan):
         """aimed pixel [rounds, n] int32 of the action records the kernel wrote"""
@@ -161,7 +176,7 @@ class It1Rounds:
         Returns (action records [k, n, 8], aimed pixels [k, n] int32)."""
         plan = self.plan_rounds(r0, r0 + k, k)
         self.sim.set_order_view_dev(plan["order"][0].data_ptr())
-        self.sim.grasp_rounds_dev(self.rule(), r0, k, reward_rows.data_ptr(), plan["act"].data_ptr(), check_mode=1, table_height=0.91, settle_ms=1000.0)
+        self.sim.grasp_rounds_dev(self.rule(), r0, k, reward_rows.data_ptr(), plan["act"].data_ptr(), check_mode=1 if self.kind == "it1" else 0, table_height=0.91, settle_ms=1000.0)
         self._alive = (plan, reward_rows)
         return plan["act"], self.planned_pixels(plan)
 
@@ -307,7 +322,7 @@ class Job:
                     self.reward = torch.zeros((rows, job.n_g), dtype=torch.int32, device=dev)
                     self.ids = torch.arange(self.lo, self.lo + job.n_g, dtype=torch.int32, device=dev)
         # streams that the runtime has put on different hardware queues -- measured, not assumed (mujoco_rl_ur5_amd/streams.py)
-        self.streams, self.streams_overlap_verified = group_streams(torch, dev, self.G)
+        self.streams, self.streams_overlap_verified = group_streams(torch, dev, self.G, first_high_priority=bool(int(os.environ.get("UR5_GROUP0_HIGH_PRIORITY", "0"))))
         self.groups = [Group(g) for g in range(self.G)]
         torch.cuda.synchronize()
 
@@ -316,7 +331,7 @@ class Job:
         wait for the others between its rounds (ur5_grasp_rounds_dev), and the outcome records of the K rounds travel in ONE all_gather per launch."""
         torch, gathered = self.torch, None
         self.launches = getattr(self, "launches", 0)
-        if fused > 0 and wls is None and self.kind == "it1":
+        if fused > 0 and wls is None:
             # (1) every group's plan (zeroed records, dispatch orders) while the chip is idle, (2) ALL engine launches of the region, group by group inside a launch index, with
             # nothing between two launches of a stream but an event record, (3) the outcome records of the whole region in one pass per group and ONE all_gather per group
             # (16 B per scene and round). With K rounds per launch an outcome becomes visible to the other ranks when its region ends, not its launch: the scripted-policy
@@ -398,7 +413,7 @@ class Job:
             gr.sim.close()
 
 
-def rendered_sub_result(torch, dist, sharding, dev, dev_id, workload, n, rounds, warmup, with_cpu, groups=2):
+def rendered_sub_result(torch, dist, sharding, dev, dev_id, workload, n, rounds, warmup, with_cpu, groups=2, fused=1):
     """N = 1 measurement of BASELINE.json configs[2] (it4) / configs[3] (many) in the driver's one line, with the headline's machinery: the same
     stationary episode structure (EP rounds, a quarter of the batch resets per round inside the attempt's launch), every round renders the
     200x200 RGB-D observation, re-aims ON THE DEVICE from the current state, takes the grasp height from the rendered depth under the aimed pixel
@@ -407,8 +422,10 @@ def rendered_sub_result(torch, dist, sharding, dev, dev_id, workload, n, rounds,
     many = workload == "many"
     model = load_model("/UR5+gripper/UR5gripper_2_finger_many_objects.xml" if many else "/UR5+gripper/UR5gripper_2_finger.xml")
     job = Job(torch, dist, sharding, model, workload, "aimed", n, n, 0, 1, dev, dev_id, groups, warmup + rounds)
-    job.run_rounds(0, warmup)
-    dt, c0, c1, kms, _ = job.timed(warmup, warmup + rounds)
+    # fused = K > 0 (round 6): K rounds per launch, every scene renders its own observation and aims inside the launch (ur5_set_observation_dev, rule kind 1 + depth /
+    # kind 2): no stand-alone render and no torch kernel between two launches of a stream. 0: the round-5 shape (render, torch rule, one launch per round).
+    job.run_rounds(0, warmup, None, fused)
+    dt, c0, c1, kms, _ = job.timed(warmup, warmup + rounds, None, fused)
     steps = int((c1["total_steps"] - c0["total_steps"]).sum())
     succ = sum(float(gr.reward[warmup:warmup + rounds].sum().item()) for gr in job.groups)
     words = model.nq + 2 * model.nv + 5 * model.nu + 8
@@ -416,12 +433,15 @@ def rendered_sub_result(torch, dist, sharding, dev, dev_id, workload, n, rounds,
                         "box rule of tools/pile_aim.py on the device, depth-derived grasp height, one grasp script; episodes of 4 rounds with reset_model + 1000 ms settle" if many
                         else "BASELINE.json configs[2] shape: IT4 (in-tree UR5gripper_2_finger.xml, 3 boxes + 3 spheres), per round a 200x200 RGB-D render, device-side "
                         "re-aim at an object still on the plate, depth-derived grasp height, one grasp script; episodes of 4 rounds with reset_model + 1000 ms settle"),
-           "scenes": n, "rounds": rounds, "warmup": warmup, "scene_groups": job.G, "scene_group_streams_overlap_verified": job.streams_overlap_verified, "env_steps_per_s": steps / dt, "grasp_attempts_per_s": rounds * n / dt,
+           "scenes": n, "rounds": rounds, "warmup": warmup, "scene_groups": job.G, "rounds_per_launch": fused if fused else 1,
+           "observation": ("rendered by every scene for itself at the start of each of its rounds, inside the launch (ur5_set_observation_dev); rule evaluated in the kernel" if fused
+                           else "stand-alone render + torch rule between the launches (round-5 shape)"), "scene_group_streams_overlap_verified": job.streams_overlap_verified, "env_steps_per_s": steps / dt, "grasp_attempts_per_s": rounds * n / dt,
            "grasp_success_rate": succ / (rounds * n), "env_steps_per_attempt": steps / (rounds * n),
            "newton_iters_per_step": float((c1["solver_iters"] - c0["solver_iters"]).sum()) / max(1, steps),
            "status_bits": int(np.bitwise_or.reduce(c1["status"] | c1["status_ended"])), "ms_per_round": 1e3 * dt / rounds, "kernel_ms_per_round_and_group": kms / (rounds * job.G),
            "roofline_frac": steps * 2 * words * 8 / dt / 8e12, "bytes_per_env_step": 2 * words * 8,
            "kernel": "ur5m_run_kernel<248>" if many else "ur5_run_kernel<44>"}
+    reward_round0 = torch.cat([gr.reward[0] for gr in job.groups]).cpu().numpy()   # the warm-up round = every scene's FIRST attempt after reset_model: what the CPU leg's piles do
     job.close()
     # counter traffic of this kernel, from the round's rocprofv3 PMC passes of `bench.py --sub many` (tools/gpu_evidence_extras.sh): not measured in this run
     tp = os.path.join(ROOT, "profiles", "many_hbm_traffic_latest.json")
@@ -432,7 +452,16 @@ def rendered_sub_result(torch, dist, sharding, dev, dev_id, workload, n, rounds,
         out["traffic_over_algorithmic"] = tj["hbm_bytes_per_env_step"] / (2 * words * 8)
         out["traffic_source"] = f"profiles/many_hbm_traffic_latest.json ({tj.get('source', '')}): 2 x FETCH_SIZE + WRITE_SIZE per env-step, separate PMC passes; NOT measured in this run"
     if with_cpu:
-        out["cpu_baseline"] = cpu_baseline(model, 20.0 if many else 8.0, workload)
+        out["cpu_baseline"] = cb = cpu_baseline(model, 20.0 if many else 8.0, workload)
+        if many:
+            # the same (scene, round 0) pairs on the GPU (round-5 verdict 1g: the CPU leg completed 12 - 15 attempts with 0 successes two rounds in a row against the GPU
+            # rounds' 0.19 -- P ~ 8 % by chance): scenes 0 .. k - 1, first attempt after reset_model + settle, the same box rule on both sides
+            k_done, k_started = int(round(cb["grasp_attempts_per_s"] * 20.0)), int(cb["sample"].split(" piles")[0])
+            cb["gpu_rewards_same_scenes_round0"] = {"scenes_started_on_the_cpu": k_started, "gpu_successes_among_them": int(reward_round0[:k_started].sum()),
+                                                    "gpu_success_rate_round0_all_scenes": float(reward_round0.mean()),
+                                                    "note": f"the CPU leg completed about {k_done} of these attempts inside its budget (which ones depends on thread timing); the GPU's "
+                                                            "round-0 rewards of the same scene ids are listed so that a CPU leg without a success can be read against them",
+                                                    "gpu_rewards_first_scenes": reward_round0[:min(k_started, 64)].astype(int).tolist()}
     return out
 
 
@@ -443,6 +472,8 @@ def dqn_sub_result(torch, dev, dev_id, n, rounds, warmup, groups=2):
     from mujoco_rl_ur5_amd.agent import BatchedGraspAgent
     # two scene groups per rank (round 5): group 1's render -> CNN forward -> action selection runs under group 0's grasp launch, a group's replay pushes and
     # optimiser steps under the next group's launch; the transitions, batches and optimiser steps are those of the unpipelined loop (tests/test_agent.py)
+    from mujoco_rl_ur5_amd import sharding as _sh0
+    _sh0.TIME_COLLECTIVES = _sh0.collectives_active()
     agent = BatchedGraspAgent(n_envs=n, device=dev, max_updates_per_round=16, pipeline_groups=groups, device_id=dev_id)
     for e in agent.envs:
         e.reset()
@@ -464,11 +495,27 @@ def dqn_sub_result(torch, dev, dev_id, n, rounds, warmup, groups=2):
            "scenes": n, "rounds": rounds, "warmup": warmup, "pipelined_scene_groups": groups, "grasp_attempts_per_s": rounds * n / dt, "env_steps_per_s": steps / dt, "ms_per_round": 1e3 * dt / rounds,
            "optimiser_steps_per_round": (agent.learner.updates_done - u0) / rounds, "update_to_data": out["update_to_data"], "grasp_success_rate": rew / rounds,
            "epsilon": out["epsilon"], "loss": out["loss"], "cnn_gflop_per_scene_forward": 42.0}
+    from mujoco_rl_ur5_amd import sharding as _sh
+    if _sh.collectives_active():
+        # what the multi-rank agent path adds per round (round-5 verdict 7b): the flattened weight / Adam-state broadcast, the replay batch's all-reduce per optimiser step, the
+        # outcome all_gather -- issued here by ONE rank through RCCL (--collectives --backend nccl): device time of RCCL's own kernels; the wire estimate is per xGMI link
+        st = _sh.collective_stats()
+        tot_rounds = rounds + warmup
+        res["collectives_per_round"] = {k: dict(calls=v["calls"] / tot_rounds, mbytes=v["bytes"] / tot_rounds / 1e6, device_ms=v["ms"] / tot_rounds) for k, v in st.items()}
+        bw = 153e9                                                                  # one xGMI link, bytes/s (7 per GPU; ring collectives are per-link bound)
+        b, a = st.get("broadcast", dict(bytes=0, calls=0)), st.get("all_reduce_replay_batch", dict(bytes=0, calls=0))
+        res["collectives_xgmi_estimate_ms_per_round_8_gpus"] = dict(
+            broadcast=(b["bytes"] / tot_rounds) / bw * 1e3, all_reduce=2 * 7 / 8 * (a["bytes"] / tot_rounds) / bw * 1e3 + a["calls"] / tot_rounds * 14 * 0.02,
+            note="ring estimate on one 153 GB/s link: broadcast = bytes / link rate (pipelined ring); all-reduce = 2 (N-1)/N x bytes / link rate + 2 (N-1) hops x ~20 us per call")
     res["learning_cadence"] = (f"{res['optimiser_steps_per_round']:.0f} optimiser steps per round of {n} transitions (update_to_data {res['update_to_data']:.4f}); the reference takes one step per "
                                "transition (Grasping_Agent_multidiscrete.py:551-556): max_updates_per_round caps the replicated learner's share of a round")
     for e in agent.envs:
         e.sim.close()
     return res
+
+
+# rounds per launch of the rendered sub-results (the observation rendered and the rule evaluated inside the launch, round 6): same-box sweeps in profiles/r06_*_rendered_rounds_per_launch.log
+SUB_FUSED = {"it4": 2, "many": 1, "many4096": 1}
 
 
 def default_rounds_per_launch(n_local):
@@ -519,6 +566,8 @@ def main():
                     help="run ONLY this secondary measurement (N = 1) and print it as {name: result}: what the rocprofv3 passes of tools/gpu_evidence_extras.sh profile")
     ap.add_argument("--sub-scenes", type=int, default=None, help="with --sub: scene count instead of the sub-result's own (same-box A/Bs of engine builds)")
     ap.add_argument("--sub-rounds", type=int, default=None, help="with --sub: timed rounds")
+    ap.add_argument("--sub-fused", type=int, default=-1, help="with --sub it4 / many / many4096: rounds per launch with the observation rendered and the rule evaluated inside the launch (0 = the round-5 shape: "
+                    "stand-alone render + torch rule + one launch per round); default: the sub-result's own")
     ap.add_argument("--sub-groups", type=int, default=2, help="with --sub-scenes / --sub-rounds: scene groups (handles + streams) of the sub-result; with --sub dqn / dqn2048: pipelined scene groups of the agent (1 = the serial loop)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for 2 ranks on one device)")
     ap.add_argument("--collectives", action="store_true", help="N = 1 only: create a one-rank process group on --backend and issue every collective of an N-rank job "
@@ -557,9 +606,9 @@ def main():
         dist.init_process_group(args.backend, rank=0, world_size=1, **({"device_id": dev} if args.backend == "nccl" else {}))
         sharding.FORCE_COLLECTIVES = True
 
-    subs = {"it4": lambda cpu: rendered_sub_result(torch, dist, sharding, dev, dev_id, "it4", 4096, 4, 1, cpu),
-            "many": lambda cpu: rendered_sub_result(torch, dist, sharding, dev, dev_id, "many", 2048, 2, 1, cpu),   # BASELINE configs[3]: 16384 piles on 8 GPUs = 2048 per GPU
-            "many4096": lambda cpu: rendered_sub_result(torch, dist, sharding, dev, dev_id, "many", 4096, 2, 1, False),   # north_star: "a 4096-env synthetic pile" on one GPU
+    subs = {"it4": lambda cpu: rendered_sub_result(torch, dist, sharding, dev, dev_id, "it4", 4096, 4, 1, cpu, 2, SUB_FUSED["it4"]),
+            "many": lambda cpu: rendered_sub_result(torch, dist, sharding, dev, dev_id, "many", 2048, 2, 1, cpu, 2, SUB_FUSED["many"]),   # BASELINE configs[3]: 16384 piles on 8 GPUs = 2048 per GPU
+            "many4096": lambda cpu: rendered_sub_result(torch, dist, sharding, dev, dev_id, "many", 4096, 2, 1, False, 2, SUB_FUSED["many4096"]),   # north_star: "a 4096-env synthetic pile" on one GPU
             # pipelined scene groups (agent.BatchedGraspAgent): +3 % at 512 piles (one pile per CU: the other group's CNN finds LDS), -2 % at 2048 (two piles per CU hold
             # 99.5 % of a CU's LDS: a CNN kernel only gets a CU in the launch's tail, and runs 3.7 x slower there) -- same-box A/B in profiles/r05_g_dqn_ab.log
             "dqn": lambda cpu: dqn_sub_result(torch, dev, dev_id, 512, 2, 1, 2),
@@ -571,10 +620,11 @@ def main():
             dflt = {"dqn": (512, 2), "dqn2048": (2048, 1)}[args.sub]
             print(json.dumps({args.sub: dqn_sub_result(torch, dev, dev_id, args.sub_scenes or dflt[0], args.sub_rounds or dflt[1], 1, args.sub_groups)}), flush=True)
             return
-        if args.sub in ("it4", "many", "many4096") and (args.sub_scenes or args.sub_rounds or args.sub_groups != 2):
+        if args.sub in ("it4", "many", "many4096") and (args.sub_scenes or args.sub_rounds or args.sub_groups != 2 or args.sub_fused >= 0):
             wl = "it4" if args.sub == "it4" else "many"
             dflt = {"it4": (4096, 4), "many": (2048, 2), "many4096": (4096, 2)}[args.sub]
-            res = rendered_sub_result(torch, dist, sharding, dev, dev_id, wl, args.sub_scenes or dflt[0], args.sub_rounds or dflt[1], 1, False, args.sub_groups)
+            res = rendered_sub_result(torch, dist, sharding, dev, dev_id, wl, args.sub_scenes or dflt[0], args.sub_rounds or dflt[1], 1, False, args.sub_groups,
+                                      SUB_FUSED[args.sub] if args.sub_fused < 0 else args.sub_fused)
         else:
             res = subs[args.sub](False)
         print(json.dumps({args.sub: res}), flush=True)

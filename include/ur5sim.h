@@ -95,16 +95,31 @@ int ur5_grasp_attempt_reset_dev(ur5_sim* h, const double* action_dev, int check_
    grasp_z with wrist rotation (g / episode_rounds + r) % 6; an empty plate gets an attempt at (fallback_x, fallback_y). Scene g's episode ends
    after the rounds r with (r + 1 + g) % episode_rounds == 0. Every per-scene result is bit-identical to `rounds` launches of
    ur5_grasp_attempt_reset_dev fed with the same rule's actions (tests/test_grasp_rounds.py). reward_dev [rounds][n] int32; action_out_dev
-   [rounds][n][8] doubles or NULL: the records the rule produced (x y z rot 0 box-found - -), for the caller's outcome records. Asynchronous;
-   wavefront-per-scene engine only (40-object piles are aimed from the rendered observation: UR5_ERR_MODEL). */
+   [rounds][n][8] doubles or NULL: the records the rule produced (x y z rot 0 box-found - -), for the caller's outcome records. Asynchronous.
+   Round 6 -- the rendered workloads: rule kind 2 (40-object piles only) is the box rule of bench.py It1Rounds.pile_box_actions / tools/pile_aim.py (the box in
+   the bin with the most level top face whose sides are parallel to the fingers at wrist angle 0 / +30 / -30 degrees and nothing lying on it; else the highest
+   object in the bin; else the bin's centre). z_from_depth = 1 (either kind; needs ur5_set_observation_dev): the grasp height is cam_z minus the metric depth
+   the round's observation shows under the aimed pixel -- GraspEnv.step, GraspingEnv.py:100-104 -- where pixel column = rint((x - cam_x0) / cam_dx),
+   row = rint((y - cam_y0) / cam_dy) (the top-down camera's affine map at table height, MujocoController.py:742-806). */
 typedef struct {
   int kind, episode_rounds;
   int64_t first_scene_id, n_total;
   uint64_t base_seed;
   double plate_half_x, plate_centre_y, plate_half_y, z_min, z_max, grasp_z, fallback_x, fallback_y;
+  int z_from_depth, pad;
+  double cam_x0, cam_y0, cam_dx, cam_dy, cam_z;
 } ur5_aim_rule;
 int ur5_grasp_rounds_dev(ur5_sim* h, const ur5_aim_rule* rule, int round0, int rounds, int check_mode, double table_height, int* reward_dev,
                          double* action_out_dev, double settle_ms);
+/* The observation of a round INSIDE the launch (round 6): every following ur5_grasp_rounds_dev launch has each scene render its own RGB-D observation --
+   GraspEnv.get_observation, GraspingEnv.py:390-406 -> sim.render(width, height, camera, depth=True) + the two flips, MujocoController.py:708-727 -- at the start of
+   each of its rounds, from the state it has then, into frame (round of the launch % frames) of rgb_dev [frames][n][height][width][3] uint8 and depth_dev
+   [frames][n][height][width] float32 (depth_mode as ur5_render_dev). The pixels are those of ur5_render_dev on the same state (one ray caster, csrc/ur5_raster.h).
+   A scene that renders for itself never waits for a free wave slot, which a stand-alone render between two launches of a stream does while another handle's launch
+   holds the chip; and K rounds of a rendered workload fit one launch (frames >= K keeps every round's frame: a rollout with its observations, as
+   generate_data.py stores them). rgb_dev = NULL switches it off. Engines whose scene image has no room for the ray caster's working set (the four-box IT1
+   scene) refuse with UR5_ERR_MODEL. */
+int ur5_set_observation_dev(ur5_sim* h, int camera_id, int width, int height, int depth_mode, uint8_t* rgb_dev, float* depth_dev, int frames);
 /* Dispatch order of the following grasp-attempt / settle launches: order_dev[n] int32 (HIP device pointer) is a permutation of the scene
    ids; the engine starts scenes in that order. The handle COPIES the list (device to device, on its stream, ordered with its launches): the
    caller's buffer may be reused or freed once work queued on that stream so far has run; a caller that filled it on another stream

@@ -186,7 +186,7 @@ struct Ur5Launch {
   // job. The action of a round is NOT an input: the scene aims by itself, from its own record, with the scripted rule below -- a function of that record only, so a
   // scene never waits for the other scenes' round to end (example_agent.py:15-27 has no barrier between scenes either: it has one scene). result is [rounds][n].
   int rounds;                   // 0 / 1: one round with the caller's action records (every other entry point)
-  int rule_kind;                // 0: none; 1: "first candidate box still on the pick plate" (bench.py It1Rounds, rule "aimed")
+  int rule_kind;                // 0: none; 1: "first candidate object still on the pick plate" (bench.py It1Rounds, rule "aimed"); 2: the box rule for 40-object piles (tools/pile_aim.py)
   int rule_r0, rule_ep;         // first round of the launch, rounds per episode
   long long rule_gid0, rule_ntotal;   // global id of scene 0 of this handle, scenes of the whole job (episode seeds: base + gid + ntotal * episode)
   uint64_t rule_base_seed;
@@ -194,6 +194,18 @@ struct Ur5Launch {
   const int* step_cap;          // test hook, optional [n]: the scene stops after this many physics steps of the launch (capped replay: the same attempt cut off at
                                 // several step counts shows WHEN two implementations part; include/ur5sim_test.h ur5_set_step_cap_dev)
   double* action_out;           // optional [rounds][n][8]: the action records the rule produced (x y z rot skip box-found - -), for the caller's outcome records
+  // Round 6, ruled launches: the OBSERVATION of a round is produced inside the launch, by the scene's own workgroup, at the start of the round (GraspEnv.step's
+  // current_observation, GraspingEnv.py:87-88,152: get_observation -> sim.render(width, height, camera, depth=True), MujocoController.py:708-740) -- frame
+  // (round of the launch) % obs_frames of obs_rgb [frames][n][h][w][3] / obs_depth [frames][n][h][w] (obs_mode 0: metres along the optical axis, 1: GL window depth).
+  // A scene that renders for itself never waits for a free wave slot (a stand-alone render between two launches of a stream does, while another handle's launch holds
+  // the chip), and with rule_z_from_depth its grasp height is what the depth image shows under the aimed pixel (GraspingEnv.py:100-104): the rendered workloads of
+  // bench.py then run K rounds per launch like the headline.
+  const struct Ur5RenderModel* obs_rm;
+  unsigned char* obs_rgb;
+  float* obs_depth;
+  int obs_cam, obs_w, obs_h, obs_mode, obs_frames;
+  int rule_z_from_depth;        // the rule's grasp height = rule_cam[4] - (metric depth under the aimed pixel) instead of rule_plate[5]
+  double rule_cam[5];           // top-down camera at table height: world x of pixel column 0, world y of pixel row 0, dx per column, dy per row (pixel = rint((x - x0) / dx)); camera z
 };
 #ifndef UR5_MANY
 #define UR5_DEBUG_STRIDE 2048

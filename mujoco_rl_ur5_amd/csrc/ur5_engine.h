@@ -25,6 +25,7 @@
 #include <math.h>
 #include <stddef.h>
 #include "ur5_devmodel.h"
+#include "ur5_raster.h"   // the ray caster of the observation (stand-alone kernels of ur5sim.hip and Engine::observe)
 
 #ifdef UR5_EMUL
 #define UR5_FN inline
@@ -597,6 +598,7 @@ template <class real, int NV_, int GS_ = UR5_NT> struct Engine {
 #include "ur5_engine_envelope.inc"   // pile unit only: envelope (skyline) storage of the Newton Hessian -- structure, assembly, level-parallel factorisation, sweeps
 #include "ur5_engine_solve.inc"   // the Newton iteration itself: warm start, exact line search in registers, step
 #include "ur5_engine_integrate.inc"   // mj_Euler with implicit damping, forward(), step(), mj_step's state guard
+#include "ur5_engine_observe.inc"   // the observation of a round, rendered by the lanes that own the scene between two rounds of a launch
 #include "ur5_engine_script.inc"   // controller layer (PID, IK), the scripts of the C ABI operations, the interpreter, the introspection dump
 };
 

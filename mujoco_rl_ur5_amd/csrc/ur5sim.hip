@@ -222,6 +222,13 @@ static int be_launch(ur5_sim* h, const Ur5Launch& P) {
   be_event_commit(b);
   return 0;
 }
+static bool be_can_observe(ur5_sim* h) {
+#ifdef UR5_MANY
+  (void)h; return ur5::Engine<double, UR5_MAXNV, UR5_NT>::CAN_OBSERVE;
+#else
+  return h->nvt == 32 ? ur5::Engine<double, 32, 64>::CAN_OBSERVE : ur5::Engine<double, UR5_MAXNV, 64>::CAN_OBSERVE;
+#endif
+}
 static int be_reset_dev(ur5_sim* h, const uint64_t* seeds_dev, const uint8_t* mask_dev, int chunks, int* max_steps_dev) {
   HipBackend* b = (HipBackend*)h->be;
   HIPCHK(hipSetDevice(h->device));

@@ -431,6 +431,8 @@ struct ur5_sim {
   void* d_gpose = nullptr;        // render: per-scene geom poses + screen boxes (HIP backend)
   const int* d_step_cap = nullptr;   // test hook (ur5_set_step_cap_dev): [n] physics-step caps of the scripted launches (the handle's copy d_step_cap_buf), NULL = none
   int* d_step_cap_buf = nullptr;
+  // observation inside ruled launches (ur5_set_observation_dev): caller-owned frame buffers
+  uint8_t* obs_rgb = nullptr; float* obs_depth = nullptr; int obs_cam = 0, obs_w = 0, obs_h = 0, obs_mode = 0, obs_frames = 0;
   const int* d_order = nullptr;   // dispatch order of the scripted launches (ur5_set_order_dev), NULL = scene order; points at d_order_buf
   int* d_order_buf = nullptr;     // handle-owned copy, made by an ASYNCHRONOUS device-to-device copy on the handle's stream: the caller's buffer must stay valid (and unmodified) until the work
                                   // queued on that stream so far has run (include/ur5sim.h); same-stream callers (ur5_set_stream) have nothing to do
@@ -453,6 +455,7 @@ static int be_launch(ur5_sim* h, const Ur5Launch& P);
 static int be_sync(ur5_sim* h);
 static int be_set_stream(ur5_sim* h, void* stream, int external);
 static int be_render(ur5_sim* h, int cam, int W, int Hh, int mode, uint8_t* rgb_dev, float* depth_dev);
+static bool be_can_observe(ur5_sim* h);   // the engine instantiation that runs this handle's scenes has room for Engine::observe's working set
 static int be_reset_dev(ur5_sim* h, const uint64_t* seeds_dev, const uint8_t* mask_dev, int chunks, int* max_steps_dev);
 static long g_model_uploads = 0;   // test hook (ur5_model_uploads): model copies this unit has sent to a device -- one per handle, by ur5_create, never at a launch
 
@@ -509,7 +512,8 @@ int ur5m_grasp_attempt(ur5_sim* h, const double* action, const uint8_t* skip, in
 int ur5m_ik(ur5_sim* h, const double* xyz, double* q5, int* result);
 int ur5m_render_dev(ur5_sim* h, int camera_id, int width, int height, int depth_mode, uint8_t* rgb_dev, float* depth_dev);
 int ur5m_render(ur5_sim* h, int camera_id, int width, int height, int depth_mode, uint8_t* rgb, float* depth);
-int ur5m_sync(ur5_sim* h); int ur5m_set_order_dev(ur5_sim* h, const int* order_dev); int ur5m_set_order_view_dev(ur5_sim* h, const int* order_dev); int ur5m_set_stream(ur5_sim* h, void* s, int external); double ur5m_last_launch_ms(ur5_sim* h); void* ur5m_state_device_ptr(ur5_sim* h);
+int ur5m_sync(ur5_sim* h); int ur5m_set_order_dev(ur5_sim* h, const int* order_dev); int ur5m_set_order_view_dev(ur5_sim* h, const int* order_dev); int ur5m_set_observation_dev(ur5_sim* h, int camera_id, int width, int height, int depth_mode, uint8_t* rgb_dev, float* depth_dev, int frames);
+int ur5m_grasp_rounds_dev(ur5_sim* h, const ur5_aim_rule* rule, int round0, int rounds, int check_mode, double table_height, int* reward_dev, double* action_out_dev, double settle_ms); int ur5m_set_stream(ur5_sim* h, void* s, int external); double ur5m_last_launch_ms(ur5_sim* h); void* ur5m_state_device_ptr(ur5_sim* h);
 int ur5m_forward_debug(ur5_sim* h, double* out); int ur5m_set_step_cap_dev(ur5_sim* h, const int* cap_dev); long ur5m_model_uploads(ur5_sim* h); int ur5m_body_xpos(ur5_sim* h, double* out); int ur5m_profile_read(ur5_sim* h, double* out);
 }
 #endif
@@ -766,16 +770,17 @@ int ur5_grasp_attempt_reset_dev(ur5_sim* h, const double* action_dev, int check_
 }
 int ur5_grasp_rounds_dev(ur5_sim* h, const ur5_aim_rule* rule, int round0, int rounds, int check_mode, double table_height, int* reward_dev,
                          double* action_out_dev, double settle_ms) {
+  UR5_FWD(grasp_rounds_dev, (h, rule, round0, rounds, check_mode, table_height, reward_dev, action_out_dev, settle_ms));
   using namespace ur5host;
   if (!h) return fail(UR5_ERR_ARG, "ur5_grasp_rounds_dev: NULL handle");
-#ifndef UR5_MANY
-  if (h->variant == 1) return fail(UR5_ERR_MODEL, "ur5_grasp_rounds_dev: the scripted rule reads box positions on the pick plate; 40-object piles are aimed from the rendered observation (ur5_grasp_attempt_reset_dev)");
-#endif
-  if (!rule || !reward_dev || rounds < 1 || round0 < 0 || rule->kind != 1 || rule->episode_rounds < 1 || rule->n_total < 1 || rule->first_scene_id < 0)   // (a negative round would index the rule's modular arithmetic out of range)
-    return fail(UR5_ERR_ARG, "ur5_grasp_rounds_dev: rule (kind 1), reward_dev, round0 >= 0 and rounds >= 1 are required");
+  if (!rule || !reward_dev || rounds < 1 || round0 < 0 || (rule->kind != 1 && rule->kind != 2) || rule->episode_rounds < 1 || rule->n_total < 1 || rule->first_scene_id < 0)   // (a negative round would index the rule's modular arithmetic out of range)
+    return fail(UR5_ERR_ARG, "ur5_grasp_rounds_dev: rule (kind 1 or 2), reward_dev, round0 >= 0 and rounds >= 1 are required");
 #ifdef UR5_MANY
-  return fail(UR5_ERR_MODEL, "ur5_grasp_rounds_dev: wavefront-per-scene engine only");
+  if (rule->kind != 2 || h->hm.nobj == 0 || h->hm.obj_kind[0] == 0) return fail(UR5_ERR_MODEL, "ur5_grasp_rounds_dev: 40-object piles are aimed by rule kind 2 (the box rule)");
 #else
+  if (rule->kind != 1) return fail(UR5_ERR_MODEL, "ur5_grasp_rounds_dev: rule kind 2 (the pile box rule) needs the 40-object scene");
+#endif
+  if (rule->z_from_depth && !h->obs_depth) return fail(UR5_ERR_ARG, "ur5_grasp_rounds_dev: z_from_depth needs the observation inside the launch (ur5_set_observation_dev)");
   Ur5Launch P = base_launch(h, UR5_OP_GRASP);
   P.check_mode = check_mode; P.table_height = table_height;
   P.result = reward_dev; P.steps = h->d_steps; P.phase_steps = h->d_ps; P.phase_result = h->d_pr;
@@ -788,8 +793,25 @@ int ur5_grasp_rounds_dev(ur5_sim* h, const ur5_aim_rule* rule, int round0, int r
   const double plate[8] = {rule->plate_half_x, rule->plate_centre_y, rule->plate_half_y, rule->z_min, rule->z_max, rule->grasp_z, rule->fallback_x, rule->fallback_y};
   for (int k = 0; k < 8; k++) P.rule_plate[k] = plate[k];
   P.action_out = action_out_dev;
+  if (h->obs_depth) {
+    P.obs_rm = h->d_rm; P.obs_rgb = h->obs_rgb; P.obs_depth = h->obs_depth; P.obs_cam = h->obs_cam; P.obs_w = h->obs_w; P.obs_h = h->obs_h; P.obs_mode = h->obs_mode; P.obs_frames = h->obs_frames;
+    P.rule_z_from_depth = rule->z_from_depth ? 1 : 0;
+    const double cam[5] = {rule->cam_x0, rule->cam_y0, rule->cam_dx, rule->cam_dy, rule->cam_z};
+    for (int k = 0; k < 5; k++) P.rule_cam[k] = cam[k];
+    if (P.rule_z_from_depth && (cam[2] == 0 || cam[3] == 0)) return fail(UR5_ERR_ARG, "ur5_grasp_rounds_dev: z_from_depth needs the camera's pixel map (cam_dx, cam_dy != 0)");
+  }
   return be_launch(h, P);
-#endif
+}
+int ur5_set_observation_dev(ur5_sim* h, int camera_id, int width, int height, int depth_mode, uint8_t* rgb_dev, float* depth_dev, int frames) {
+  UR5_FWD(set_observation_dev, (h, camera_id, width, height, depth_mode, rgb_dev, depth_dev, frames));
+  using namespace ur5host;
+  if (!h) return fail(UR5_ERR_ARG, "ur5_set_observation_dev: NULL handle");
+  if (!rgb_dev) { h->obs_rgb = nullptr; h->obs_depth = nullptr; h->obs_frames = 0; return 0; }
+  if (!depth_dev || width <= 0 || height <= 0 || frames < 1) return fail(UR5_ERR_ARG, "ur5_set_observation_dev: bad arguments");
+  if (camera_id < 0 || camera_id >= h->hrm.ncam) return fail(UR5_ERR_ARG, "ur5_set_observation_dev: unknown camera id");
+  if (!be_can_observe(h)) return fail(UR5_ERR_MODEL, "ur5_set_observation_dev: this scene's engine image has no room for the ray caster's working set (render with ur5_render_dev between launches)");
+  h->obs_rgb = rgb_dev; h->obs_depth = depth_dev; h->obs_cam = camera_id; h->obs_w = width; h->obs_h = height; h->obs_mode = depth_mode; h->obs_frames = frames;
+  return 0;
 }
 int ur5_grasp_attempt_dev(ur5_sim* h, const double* action_dev, int check_mode, double table_height, int* reward_dev) {
   return ur5_grasp_attempt_reset_dev(h, action_dev, check_mode, table_height, reward_dev, nullptr, 0.0);

@@ -19,7 +19,7 @@ RES_NONE, RES_SUCCESS, RES_MAX_STEPS, RES_IK_FAIL = -1, 0, 1, 2
 _VARIANT = {0: (6, 2048, 192, 30), 1: (40, 4096, 832, 96)}
 EXPORTS = ["ur5_last_error", "ur5_create", "ur5_destroy", "ur5_num_envs", "ur5_nq", "ur5_nv", "ur5_nu", "ur5_reset", "ur5_reset_dev", "ur5_kernel_ms_total",
            "ur5_set_state", "ur5_get_state", "ur5_set_ctrl", "ur5_get_ctrl", "ur5_step", "ur5_move_group", "ur5_stay",
-           "ur5_move_ee", "ur5_ik", "ur5_grasp_attempt", "ur5_grasp_attempt_dev", "ur5_grasp_attempt_reset_dev", "ur5_grasp_rounds_dev", "ur5_sync", "ur5_set_stream", "ur5_set_order_dev", "ur5_set_order_view_dev", "ur5_last_launch_ms",
+           "ur5_move_ee", "ur5_ik", "ur5_grasp_attempt", "ur5_grasp_attempt_dev", "ur5_grasp_attempt_reset_dev", "ur5_grasp_rounds_dev", "ur5_sync", "ur5_set_stream", "ur5_set_order_dev", "ur5_set_order_view_dev", "ur5_set_observation_dev", "ur5_last_launch_ms",
            "ur5_get_counters", "ur5_body_xpos", "ur5_render", "ur5_render_dev", "ur5_state_device_ptr"]
 TEST_EXPORTS = ["ur5_forward_debug", "ur5_set_step_cap_dev", "ur5_model_uploads"]   # include/ur5sim_test.h: introspection for tests/ and tools/, not part of the boundary
 
@@ -32,7 +32,8 @@ class AimRule(C.Structure):
     """ur5_aim_rule of include/ur5sim.h: the scripted aiming rule a multi-round launch evaluates in the kernel (ur5_grasp_rounds_dev)."""
     _fields_ = [("kind", C.c_int), ("episode_rounds", C.c_int), ("first_scene_id", C.c_int64), ("n_total", C.c_int64), ("base_seed", C.c_uint64),
                 ("plate_half_x", C.c_double), ("plate_centre_y", C.c_double), ("plate_half_y", C.c_double), ("z_min", C.c_double), ("z_max", C.c_double),
-                ("grasp_z", C.c_double), ("fallback_x", C.c_double), ("fallback_y", C.c_double)]
+                ("grasp_z", C.c_double), ("fallback_x", C.c_double), ("fallback_y", C.c_double),
+                ("z_from_depth", C.c_int), ("pad", C.c_int), ("cam_x0", C.c_double), ("cam_y0", C.c_double), ("cam_dx", C.c_double), ("cam_dy", C.c_double), ("cam_z", C.c_double)]
 
 
 _libs = {}
@@ -58,6 +59,7 @@ def load(path=None):
     L.ur5_set_stream.argtypes = [vp, vp, C.c_int]
     L.ur5_set_order_dev.argtypes = [vp, vp]
     L.ur5_set_order_view_dev.argtypes = [vp, vp]
+    L.ur5_set_observation_dev.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int]
     L.ur5_reset_dev.argtypes = [vp, vp, vp, C.c_double]
     L.ur5_kernel_ms_total.argtypes = [vp]
     L.ur5_kernel_ms_total.restype = C.c_double
@@ -245,6 +247,12 @@ class BatchSim:
         waits for another one's round. reward_ptr -> int32 [rounds][n], action_out_ptr -> float64 [rounds][n][8] or None (device pointers). Asynchronous."""
         self._check(self.lib.ur5_grasp_rounds_dev(self._h, C.byref(rule), int(round0), int(rounds), int(check_mode), float(table_height), C.c_void_p(reward_ptr),
                                                   C.c_void_p(action_out_ptr) if action_out_ptr else None, float(settle_ms)), "ur5_grasp_rounds_dev")
+
+    def set_observation_dev(self, rgb_ptr, depth_ptr, camera, width, height, frames=1, depth_mode=0):
+        """The following grasp_rounds_dev launches render every scene's observation at the start of each of its rounds into frame (round % frames) of
+        rgb [frames][n][h][w][3] uint8 / depth [frames][n][h][w] float32 (device pointers, caller-owned); rgb_ptr None switches it off."""
+        self._check(self.lib.ur5_set_observation_dev(self._h, int(camera), int(width), int(height), int(depth_mode), C.c_void_p(rgb_ptr) if rgb_ptr else None,
+                                                     C.c_void_p(depth_ptr) if depth_ptr else None, int(frames)), "ur5_set_observation_dev")
 
     def model_uploads(self):
         """Test hook: model copies this handle's engine unit has sent to a device so far -- one per handle, at creation (include/ur5sim_test.h)."""

@@ -222,7 +222,8 @@ class ReplayBuffer:
                 dist.all_reduce(host)
                 state = host.to(self.device)
             else:
-                dist.all_reduce(state)
+                from . import sharding
+                sharding._timed("all_reduce_replay_batch", state.numel() * state.element_size(), lambda: dist.all_reduce(state), state.is_cuda)
         return state, self.action[idx], self.reward[idx]
 
     # ---- the SHARED replay buffer of a multi-rank job (BASELINE.json north_star: "RCCL ... to all-gather grasp outcomes into the shared replay buffer")

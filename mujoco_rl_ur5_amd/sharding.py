@@ -36,6 +36,41 @@ import os as _os
 FORCE_COLLECTIVES = _os.environ.get("UR5_FORCE_COLLECTIVES", "0") not in ("", "0")
 
 
+# Accounting of the collectives (round 6; bench.py's dqn sub-results and `--collectives`): with TIME_COLLECTIVES set, every collective below is bracketed by a pair of CUDA events
+# on the current stream (no host synchronisation); collective_stats() resolves them. {name: [calls, payload bytes, device ms]}.
+TIME_COLLECTIVES = False
+_pending, _stats = [], {}
+
+
+def _timed(name, nbytes, fn, on_cuda):
+    import torch
+    if not (TIME_COLLECTIVES and on_cuda):
+        st = _stats.setdefault(name, [0, 0, 0.0])
+        st[0] += 1; st[1] += int(nbytes)
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    out = fn()
+    e1.record()
+    _pending.append((name, int(nbytes), e0, e1))
+    return out
+
+
+def collective_stats(reset=False):
+    """{name: {"calls", "bytes", "ms"}} of the collectives issued so far (device time between the bracketing events: on one rank that is RCCL's own cost, the wire adds to it)."""
+    import torch
+    if _pending:
+        torch.cuda.synchronize()
+        for name, nbytes, e0, e1 in _pending:
+            st = _stats.setdefault(name, [0, 0, 0.0])
+            st[0] += 1; st[1] += nbytes; st[2] += e0.elapsed_time(e1)
+        _pending.clear()
+    out = {k: dict(calls=v[0], bytes=v[1], ms=v[2]) for k, v in _stats.items()}
+    if reset:
+        _stats.clear()
+    return out
+
+
 def collectives_active():
     """True when the calls below really go through torch.distributed: a process group exists and has peers (or FORCE_COLLECTIVES is set)."""
     import torch.distributed as dist
@@ -60,7 +95,7 @@ def gather_outcomes(records, device=None):
         dist.all_gather(parts, t.cpu().contiguous())
         return torch.cat(parts).to(t.device)
     out = torch.empty((dist.get_world_size() * t.shape[0], t.shape[1]), dtype=t.dtype, device=t.device)
-    dist.all_gather_into_tensor(out, t.contiguous())
+    _timed("all_gather_outcomes", t.numel() * t.element_size(), lambda: dist.all_gather_into_tensor(out, t.contiguous()), t.is_cuda)
     return out
 
 
@@ -79,7 +114,7 @@ def broadcast_from_rank0(t):
         dist.broadcast(d, 0)
         t.copy_(d.cpu())
     else:
-        dist.broadcast(t, 0)
+        _timed("broadcast", t.numel() * t.element_size(), lambda: dist.broadcast(t, 0), t.is_cuda)
     return t
 
 

@@ -22,15 +22,17 @@ def _spin_ms(torch, streams, cycles):
     return 1e3 * (time.perf_counter() - t0)
 
 
-def group_streams(torch, device, n, tries=16):
+def group_streams(torch, device, n, tries=16, first_high_priority=False):
     """``n`` torch streams on ``device`` whose kernels overlap, and whether that was verified: (streams, verified). One stream: torch's current one. Without a GPU
-    (or without torch's spin kernel) the streams are returned unverified."""
+    (or without torch's spin kernel) the streams are returned unverified. first_high_priority: stream 0 is a high-priority stream -- when two groups' launches are BOTH
+    larger than the chip (40-object piles: 2048 scenes per group, 512 resident), equal priorities make the dispatcher alternate between the two queues, the two launches
+    advance at one rate and their tails coincide; with group 0 ahead, each group's tail is filled by the other's bulk."""
     if device.type != "cuda":
         return [None] * n, False
     if n <= 1:
         return [torch.cuda.current_stream(device)], True
     with torch.cuda.device(device):
-        chosen = [torch.cuda.Stream(device=device)]
+        chosen = [torch.cuda.Stream(device=device, priority=-1) if first_high_priority else torch.cuda.Stream(device=device)]
         if not hasattr(torch.cuda, "_sleep"):
             return chosen + [torch.cuda.Stream(device=device) for _ in range(n - 1)], False
         cycles = 1 << 17
@@ -52,5 +54,11 @@ def group_streams(torch, device, n, tries=16):
                     pick = cand
                     break
             verified = verified and pick is not None
-            chosen.append(pick if pick is not None else cand)
+            if pick is None:                                                  # nothing verified: at least never the SAME stream twice (round-5 advice) -- and say so
+                import warnings
+                pick = cand
+                while pick is None or any(pick.cuda_stream == s.cuda_stream for s in chosen):
+                    pick = torch.cuda.Stream(device=device)
+                warnings.warn("group_streams: no stream was seen to overlap the chosen ones (one hardware queue?): scene groups may run one after the other", RuntimeWarning)
+            chosen.append(pick)
         return chosen, verified

@@ -59,6 +59,13 @@ static int be_render(ur5_sim* h, int cam, int W, int Hh, int mode, uint8_t* rgb,
   }
   return 0;
 }
+static bool be_can_observe(ur5_sim* h) {
+#ifdef UR5_MANY
+  (void)h; return ur5::Engine<double, UR5_MAXNV>::CAN_OBSERVE;
+#else
+  return h->nvt == 32 ? ur5::Engine<double, 32>::CAN_OBSERVE : ur5::Engine<double, UR5_MAXNV>::CAN_OBSERVE;
+#endif
+}
 static int be_launch(ur5_sim* h, const Ur5Launch& P) {
 #ifdef UR5_MANY
   run_all<UR5_MAXNV>(h, P);

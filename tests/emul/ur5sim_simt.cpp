@@ -163,6 +163,13 @@ template <int NV> static void run_all(ur5_sim* h, const Ur5Launch& P) {
   }
 }
 static int be_render(ur5_sim*, int, int, int, int, uint8_t*, float*) { return ur5host::fail(UR5_ERR_ARG, "the SIMT test build has no renderer"); }
+static bool be_can_observe(ur5_sim* h) {
+#ifdef UR5_MANY
+  (void)h; return ur5::Engine<double, UR5_MAXNV, UR5_NT>::CAN_OBSERVE;
+#else
+  return h->nvt == 32 ? ur5::Engine<double, 32, UR5_NT>::CAN_OBSERVE : ur5::Engine<double, UR5_MAXNV, UR5_NT>::CAN_OBSERVE;
+#endif
+}
 static int be_launch(ur5_sim* h, const Ur5Launch& P) {
 #ifdef UR5_MANY
   run_all<UR5_MAXNV>(h, P);

@@ -200,11 +200,11 @@ def test_late_group_selects_with_the_round_start_weights(model_it1):
     for e in agent.envs:
         e.reset()
     agent._order_probe = dict(flag=torch.zeros(1, dtype=torch.int32, device="cuda"), delay_cycles=100_000_000, seen=[])
-    for _ in range(3):
+    for _ in range(5):                                                                            # (the ring holds 2 x batch transitions after three rounds of 8: the learner steps from then on)
         out = agent.round()
     torch.cuda.synchronize()
     seen = torch.cat(agent._order_probe["seen"]).cpu().tolist()
-    assert len(seen) == 6 and seen == [0] * 6, seen
+    assert len(seen) == 10 and seen == [0] * 10, seen
     assert agent.learner.updates_done >= 4 and int(agent._order_probe["flag"].item()) == 1        # the learner did run, behind the flag
 
 

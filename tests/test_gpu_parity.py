@@ -129,9 +129,33 @@ def test_full_size_batch_properties(native_mod, model_it1):
     assert np.abs(st["qpos"][:, 6] - st["qpos"][:, 7]).max() < 1e-2           # `fingers` equality holds (xml :333)
     c = sim.counters()
     assert np.all(c["status"] == 0) and np.all(c["total_steps"] == c["total_steps"][0])
-    rew, ps, pr = sim.grasp_attempt(aimed_actions(st["qpos"], 4), rot=np.arange(n) % 6, check_mode=1)
+    acts = aimed_actions(st["qpos"], 4)
+    rew, ps, pr = sim.grasp_attempt(acts, rot=np.arange(n) % 6, check_mode=1)
     assert set(np.unique(rew)) <= {0, 1} and 0.05 < rew.mean() < 0.98
-    assert np.isfinite(sim.get_state()["qpos"]).all()
+    q_end = sim.get_state()["qpos"]
+    assert np.isfinite(q_end).all()
+    # ... and the oracle itself on a sample of the batch (round-5 verdict 11): 64 of the 4096 scenes, reset + settle + attempt on the host, against the scene's place in the
+    # full-size launch -- reward bit, the 12 phase step counts, arm joints, untouched objects
+    from oracle.oracle import Oracle
+    for e in np.random.default_rng(11).choice(n, 64, replace=False):
+        o = Oracle(m)
+        o.reset(int(seeds[e]), 1, True)
+        assert np.array_equal(o.get_state()["qpos"][:8], st["qpos"][e][:8]) or np.abs(o.get_state()["qpos"] - st["qpos"][e]).max() < 1e-8
+        q_before = o.get_state()["qpos"].copy()
+        r, pso, pro = o.grasp_attempt(acts[e], int(e % 6), 1)
+        assert r == rew[e] and pso.tolist() == ps[e].tolist() and pro.tolist() == pr[e].tolist(), (e, r, rew[e], pso, ps[e])
+        assert np.abs(q_end[e][:8] - o.get_state()["qpos"][:8]).max() < 1e-6, e
+        untouched_objects_agree(q_end[e], q_before, o.get_state()["qpos"])
+
+
+def untouched_objects_agree(q_gpu, q_before, q_after, tol=1e-8):
+    """north_star's "joint trajectories" include the OBJECT joints (round-5 verdict 1d). Objects the attempt never touched -- the oracle moved none of their seven
+    coordinates by more than 1e-6 -- are where they were on both sides, to `tol` (metres / quaternion components); returns how many objects that was. (An object the
+    gripper released follows another trajectory on every rounding: it is bounded where the step counts are equal, test_grasp_bit_agreement_statistics.)"""
+    ob, oa, og = q_before[8:].reshape(-1, 7), q_after[8:].reshape(-1, 7), q_gpu[8:].reshape(-1, 7)
+    still = np.abs(oa - ob).max(axis=1) < 1e-6
+    assert np.abs(og[still] - oa[still]).max(initial=0.0) < tol, (np.abs(og - oa).max(axis=1), still)
+    return int(still.sum())
 
 
 def test_six_object_scene_nv44_kernel(native_mod, model_2f):
@@ -147,9 +171,11 @@ def test_six_object_scene_nv44_kernel(native_mod, model_2f):
     assert np.abs(st["qpos"][1] - o.get_state()["qpos"]).max() < 1e-8
     acts = aimed_actions(st["qpos"], 6)
     rew, ps, pr = sim.grasp_attempt(acts, rot=0, check_mode=0)
+    q_before = o.get_state()["qpos"].copy()
     r, pso, pro = o.grasp_attempt(acts[1], 0, 0)
     assert r == rew[1] and pso.tolist() == ps[1].tolist()
     assert np.abs(sim.get_state()["qpos"][1][:8] - o.get_state()["qpos"][:8]).max() < 1e-6
+    assert untouched_objects_agree(sim.get_state()["qpos"][1], q_before, o.get_state()["qpos"]) >= 3      # one of six is aimed at; at least three never move
     assert np.all(sim.counters()["status"] == 0)
 
 
@@ -228,10 +254,11 @@ def check_random_agent_parity(BatchSim, model, n, **kw):
     sim.reset(seeds, 1, 1000.0)
     rew, ps, pr = sim.grasp_attempt(acts, rot=rots, check_mode=0)
     q = sim.get_state()["qpos"]
-    codes = set()
+    codes, still = set(), 0
     for e in range(n):
         o = Oracle(model)
         o.reset(int(seeds[e]), 1, True)
+        q_before = o.get_state()["qpos"].copy()
         r, pso, pro = o.grasp_attempt(acts[e], int(rots[e]), 0)
         assert r == rew[e] and pro.tolist() == pr[e].tolist(), (e, acts[e], pro, pr[e])
         if pro[3] == 1:
@@ -245,8 +272,9 @@ def check_random_agent_parity(BatchSim, model, n, **kw):
             continue
         assert pso.tolist() == ps[e].tolist(), (e, acts[e], pso, ps[e])
         assert np.abs(q[e][:8] - o.qpos[:8]).max() < 1e-6, e
+        still += untouched_objects_agree(q[e], q_before, o.get_state()["qpos"])
         codes.add(tuple(pro.tolist()))
-    assert sim.counters()["status"].max() == 0
+    assert sim.counters()["status"].max() == 0 and still >= 2 * n                  # most objects of a random attempt are never touched: they are bounded, not skipped
     return codes
 
 

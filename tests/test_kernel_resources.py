@@ -47,7 +47,7 @@ def test_kernel_registers_and_scratch(tmp_path):
     assert six["private_segment_fixed_size"] <= 824, six
     # round 4: TWO pile scenes per CU -- the kernel is capped at 256 registers (same-box A/B of the cap alone: +-0 %, the step is latency-bound), spills 1 KB per lane, and
     # its LDS image must leave room for a second scene (checked where the image is defined: static_assert in csrc/ur5sim.hip)
-    assert many["private_segment_fixed_size"] <= 1408 and many["vgpr_count"] <= 256, many
+    assert many["private_segment_fixed_size"] <= 1536 and many["vgpr_count"] <= 256, many
     assert find("ur5_render_kernel")["private_segment_fixed_size"] == 0
     # the scene image is STATIC LDS (round 5: an absolute address in every called function, csrc/ur5_engine.h); what caps residency is its size:
     # 8 IT1 scenes, 7 six-object scenes (18 of the CU's 128 granules of 1 280 B), 2 piles per CU
