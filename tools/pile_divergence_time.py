@@ -62,12 +62,13 @@ if cached is not None and cached["checkpoints"].tolist() == CK and len(cached["b
     T = {v: cached[v][:n] for v in VARIANTS if v in cached.files}
 todo = [v for v in VARIANTS if v not in T]
 if todo:
-    jobs = [(e, v) for e in range(n) for v in todo]
-    with ThreadPoolExecutor(max_workers=threads) as ex:
-        res = list(ex.map(one, jobs))
-    for k, v in enumerate(todo):
-        T[v] = np.stack([res[e * len(todo) + k][0] for e in range(n)])                           # [n, K, nq]
-    np.savez_compressed(CACHE, checkpoints=np.array(CK), qpos0=D["qpos"][:n], **T)
+    for v in todo:                                                                               # one variant at a time, the cache rewritten after each: a killed run resumes
+        with ThreadPoolExecutor(max_workers=threads) as ex:
+            res = list(ex.map(one, [(e, v) for e in range(n)]))
+        T[v] = np.stack([r[0] for r in res])                                                     # [n, K, nq]
+        np.savez_compressed(CACHE + ".tmp.npz", checkpoints=np.array(CK), qpos0=D["qpos"][:n], **T)
+        os.replace(CACHE + ".tmp.npz", CACHE)
+        print(v, "done after", round(time.time() - t0, 1), "s", file=sys.stderr, flush=True)
 if G is None:
     print(json.dumps(dict(scenes=n, oracle_seconds=round(time.time() - t0, 1), cache=CACHE)))
     sys.exit(0)
