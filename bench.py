@@ -515,7 +515,10 @@ def dqn_sub_result(torch, dev, dev_id, n, rounds, warmup, groups=2):
 
 
 # rounds per launch of the rendered sub-results (the observation rendered and the rule evaluated inside the launch, round 6): same-box sweeps in profiles/r06_*_rendered_rounds_per_launch.log
-SUB_FUSED = {"it4": 2, "many": 1, "many4096": 1}
+# Piles: lock-step launches (K = 0) -- 679 / 681 / 679 / 680 k env-steps/s against 652 k for K = 1 on one box (profiles/r06_o_many_rounds_per_launch.log). The two groups' K = 1
+# launches start together and stay in phase: both drain at once and every round has a tail nobody fills; the lock-step shape's small kernels between two launches of a stream
+# offset the groups by chance (a 1 s spin in front of group 1's first launch gives K = 1 the same 680 k). What the dispatch order is worth there: nothing (resets-only order: 681 / 680 k).
+SUB_FUSED = {"it4": 2, "many": 0, "many4096": 0}
 
 
 def default_rounds_per_launch(n_local):
@@ -607,7 +610,9 @@ def main():
         sharding.FORCE_COLLECTIVES = True
 
     subs = {"it4": lambda cpu: rendered_sub_result(torch, dist, sharding, dev, dev_id, "it4", 4096, 4, 1, cpu, 2, SUB_FUSED["it4"]),
-            "many": lambda cpu: rendered_sub_result(torch, dist, sharding, dev, dev_id, "many", 2048, 2, 1, cpu, 2, SUB_FUSED["many"]),   # BASELINE configs[3]: 16384 piles on 8 GPUs = 2048 per GPU
+            # 4 timed rounds (round 5: 2): a region ends with its last launches draining alone -- about 1 s of a 4.4 s round here -- and two rounds measured that edge more than the rate
+            # (same box: 2 rounds 645 k, 4 rounds 680 k; a 512-slot packing model puts the steady state at 720 k: DESIGN.md section 3)
+            "many": lambda cpu: rendered_sub_result(torch, dist, sharding, dev, dev_id, "many", 2048, 4, 1, cpu, 2, SUB_FUSED["many"]),   # BASELINE configs[3]: 16384 piles on 8 GPUs = 2048 per GPU
             "many4096": lambda cpu: rendered_sub_result(torch, dist, sharding, dev, dev_id, "many", 4096, 2, 1, False, 2, SUB_FUSED["many4096"]),   # north_star: "a 4096-env synthetic pile" on one GPU
             # pipelined scene groups (agent.BatchedGraspAgent): +3 % at 512 piles (one pile per CU: the other group's CNN finds LDS), -2 % at 2048 (two piles per CU hold
             # 99.5 % of a CU's LDS: a CNN kernel only gets a CU in the launch's tail, and runs 3.7 x slower there) -- same-box A/B in profiles/r05_g_dqn_ab.log
@@ -622,7 +627,7 @@ def main():
             return
         if args.sub in ("it4", "many", "many4096") and (args.sub_scenes or args.sub_rounds or args.sub_groups != 2 or args.sub_fused >= 0):
             wl = "it4" if args.sub == "it4" else "many"
-            dflt = {"it4": (4096, 4), "many": (2048, 2), "many4096": (4096, 2)}[args.sub]
+            dflt = {"it4": (4096, 4), "many": (2048, 4), "many4096": (4096, 2)}[args.sub]
             res = rendered_sub_result(torch, dist, sharding, dev, dev_id, wl, args.sub_scenes or dflt[0], args.sub_rounds or dflt[1], 1, False, args.sub_groups,
                                       SUB_FUSED[args.sub] if args.sub_fused < 0 else args.sub_fused)
         else:

@@ -474,6 +474,9 @@ template <class real, int NV_> struct Lds {
   UR5_FN real* sr_jv_() { return sr_jv; }
   UR5_FN real* Mv_() { return Mv; }
 #endif
+#ifdef UR5_LDS_PAD   // residency probe (make variant EXTRA=-DUR5_LDS_PAD=2400): dead bytes at the end of the image -- the four-box kernel at SEVEN scenes per CU prices the eighth
+  char lds_pad_[UR5_LDS_PAD];
+#endif
 };
 
 // ---------------------------------------------------------------------------------------------- the engine

@@ -16,8 +16,10 @@ static_assert(2 * sizeof(ur5::Lds<double, UR5_MAXNV>) <= 160 * 1024, "two 40-obj
 #else
 #define UR5_KERNEL_ATTR(GS) __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
 #ifndef UR5_PROFILE   // (the per-phase cycle accounting build adds its counters to the image)
+#ifndef UR5_LDS_PAD   // (the residency probe pads the image on purpose)
 static_assert(8 * sizeof(ur5::Lds<double, 32>) <= 160 * 1024, "the IT1 scene image must leave room for 8 scenes per CU (2 waves per SIMD): LDS is what caps residency");
 static_assert(7 * sizeof(ur5::Lds<double, 44>) <= 160 * 1024 && sizeof(ur5::Lds<double, 44>) <= 18 * 1280, "the six-object image: 7 scenes per CU = 18 of the 128 LDS granules of 1 280 B (profiles/r04_z_lds_residency.log)");
+#endif
 #endif
 #endif
 template <int NV, int GS>
