@@ -8,7 +8,8 @@ from mujoco_rl_ur5_amd.native import BatchSim
 NAMES = ["kin", "crb", "vel", "broad", "narrow", "rows", "newton_init", "images", "linesearch", "grad+G", "H_asm", "chol", "solve", "integrate", "pid", "ik"]
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 MANY = len(sys.argv) > 2 and sys.argv[2] == "many"        # the 40-object pile (many-object engine variant)
-m = load_model("/UR5+gripper/UR5gripper_2_finger_many_objects.xml" if MANY else "it1_4box")
+SIX = len(sys.argv) > 2 and sys.argv[2] == "six"          # the six-object scene (NV = 44 instantiation of the wavefront-per-scene engine)
+m = load_model("/UR5+gripper/UR5gripper_2_finger_many_objects.xml" if MANY else ("/UR5+gripper/UR5gripper_2_finger.xml" if SIX else "it1_4box"))
 sim = BatchSim(m, n, lib_path=os.environ.get("UR5_PROF_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), "libur5sim_prof.so")))
 sim.lib.ur5_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
 def read():
@@ -30,8 +31,8 @@ print("  lifetime percentiles (ms) 10/50/90/99/max: %s; steps 10/50/90/max: %s; 
     np.percentile(lt * 1e3 / steps, [10, 50, 90, 100]).round(1).tolist()))
 st = sim.get_state(); acts = np.zeros((n, 3))
 for e in range(n):
-    objs = st["qpos"][e][8:].reshape(-1, 7); k = e % (40 if MANY else 4)
-    acts[e] = [objs[k, 0], objs[k, 1], max(0.9, objs[k, 2])] if MANY else [objs[k, 0], -0.6 + objs[k, 1], 0.91]   # free joints hold world coordinates
+    objs = st["qpos"][e][8:].reshape(-1, 7); k = e % (40 if MANY else (6 if SIX else 4))
+    acts[e] = [objs[k, 0], objs[k, 1], max(0.9, objs[k, 2])] if (MANY or SIX) else [objs[k, 0], -0.6 + objs[k, 1], 0.91]   # free joints hold world coordinates
 rew, ps, pr = sim.grasp_attempt(acts, rot=0, check_mode=0, table_height=0.89 if MANY else 0.91)
 c1 = sim.counters(); p = read(); steps = (c1["total_steps"] - c0["total_steps"]).astype(float)
 print("grasp: kernel %.1f ms, mean %d steps/env, success %.2f" % (sim.last_launch_ms(), steps.mean(), rew.mean()))
