@@ -56,6 +56,7 @@ class It1Rounds:
         from mujoco_rl_ur5_amd.controller import MJ_Controller
         self.torch, self.sim, self.rule_name, self.n, self.n_total, self.kind = torch, sim, rule, n_local, n_total, kind
         self.gid = torch.arange(lo, lo + n_local, dtype=torch.int64, device=dev)
+        self.gid0 = int(lo)   # (host copy: reading gid[0] back per launch is a blocking device-to-host copy BETWEEN two engine launches of the stream -- profiles/r06_x_headline_trace_finding.txt)
         self.state = sim.state_tensor(dev)                                        # [n, stride] f64, aliases the engine's records
         # objects: 3 slides + ball each (UR5gripper_2_finger.xml:233-239): world position = body_pos + slide offsets; free joints hold world coordinates
         self.nobj = (model.nq - 8) // 7
@@ -125,7 +126,7 @@ class It1Rounds:
         renders for itself at the start of the round (z_from_depth, ur5_set_observation_dev), through the top-down camera's pixel map at table height."""
         from mujoco_rl_ur5_amd.native import AimRule
         cam = {} if self.kind == "it1" else dict(z_from_depth=1, cam_x0=self.px0[0], cam_y0=self.px0[1], cam_dx=self.dxdpx, cam_dy=self.dydpy, cam_z=self.cam_z)
-        return AimRule(kind=2 if self.kind == "many" else 1, episode_rounds=EP, first_scene_id=int(self.gid[0]), n_total=int(self.n_total), base_seed=BASE_SEED, plate_half_x=0.27,
+        return AimRule(kind=2 if self.kind == "many" else 1, episode_rounds=EP, first_scene_id=self.gid0, n_total=int(self.n_total), base_seed=BASE_SEED, plate_half_x=0.27,
                        plate_centre_y=-0.6, plate_half_y=0.19, z_min=0.905, z_max=1.0, grasp_z=0.91, fallback_x=0.0, fallback_y=-0.6, **cam)
 
     def plan_rounds(self, r0, r1, fused):
