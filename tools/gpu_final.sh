@@ -16,7 +16,7 @@ timeout 600 python tools/gpu_many_dump.py 3072 256 $OUT/${PFX}_many_states.npz >
 # box's host cores, and the capped replays of the dumped piles for the CPU-side divergence-time statistic (tools/pile_divergence_time.py)
 timeout 300 python bench.py --steps 8 --warmup 4 --no-extras --no-cpu-baseline --collectives --backend nccl > $OUT/${PFX}_bench_collectives_nccl.json 2> $OUT/bench_collectives.err; cut -c1-300 $OUT/${PFX}_bench_collectives_nccl.json
 # the agent path's collectives (weights / Adam state broadcast, replay batch all-reduce, outcome all_gather) issued by ONE rank through RCCL: device ms per round in the dqn line
-timeout 400 python bench.py --sub dqn --collectives --backend nccl 2> $OUT/dqn_collectives.err | tail -1 > $OUT/${PFX}_dqn_collectives_nccl.json; python -c "
+timeout 400 python bench.py --sub dqn --collectives --backend nccl 2> $OUT/dqn_collectives.err | grep "^{" | tail -1 > $OUT/${PFX}_dqn_collectives_nccl.json; python -c "
 import json; d = json.load(open('$OUT/${PFX}_dqn_collectives_nccl.json'))['dqn']; print({k: d.get(k) for k in ('grasp_attempts_per_s', 'collectives_per_round', 'collectives_xgmi_estimate_ms_per_round_8_gpus')})"
 timeout 600 python tools/gpu_agreement.py 1024 it1_4box 2>/dev/null | tail -1 > $OUT/${PFX}_grasp_agreement_1024_it1.json; cut -c1-400 $OUT/${PFX}_grasp_agreement_1024_it1.json
 timeout 600 python tools/gpu_agreement.py 768 /UR5+gripper/UR5gripper_2_finger.xml 2>/dev/null | tail -1 > $OUT/${PFX}_grasp_agreement_768_2f.json; cut -c1-400 $OUT/${PFX}_grasp_agreement_768_2f.json
