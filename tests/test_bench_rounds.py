@@ -71,6 +71,12 @@ def test_rendered_rounds_on_the_emulation_build(model_2f, emul_lib):
     assert wl.dep.min() > 0.9 and wl.img.float().std() > 1.0                    # an image was rendered
     assert ((act[:, 2] > 0.935) & (act[:, 2] < 0.975)).all(), act[:, 2]           # plate top 0.91 + an object of 3-6 cm
     assert sim.counters()["total_steps"].min() > 1000 and sim.counters()["status"].max() == 0
+    # the rule struct of a launch is built from HOST values only (round 6: `int(self.gid[0])` was a blocking one-element device-to-host copy in front of every engine launch
+    # of a stream -- 56-380 ms each while the other scene group's launch held the chip, profiles/r06_x_headline_trace_finding.txt)
+    gid, wl.gid = wl.gid, None                                                   # rule() must not touch the device tensor at all
+    r = wl.rule()
+    wl.gid = gid
+    assert r.first_scene_id == 0 and isinstance(wl.gid0, int)
 
 
 def test_device_side_pile_rule_equals_tools_pile_aim(model_it1):
