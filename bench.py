@@ -21,9 +21,10 @@ Everything a round needs (seeds, action records, dispatch order) is produced on 
 kernel (ur5_set_stream): no host synchronisation inside a round except the outcome all_gather's own. A launch ends with its slowest
 scene, so scenes are dispatched longest-expected-first (ur5_set_order_dev): episode-ending scenes (attempt + 500 settle steps), then
 scenes with a box to carry, then attempts on an empty plate. The order changes the makespan only, never a result.
-For the same reason the rank's scenes are simulated as --groups G = 2 scene groups (one engine handle + one HIP stream each, half of the
-scenes each): the next round of one group is queued behind its current one while the other group's round is still running, so the wave
-slots that the tail of a launch leaves empty are taken by the other group's launch. Scenes, seeds and results are those of one group.
+For the same reason the rank's scenes are simulated as --groups G scene groups (one engine handle + one HIP stream each, 1 / G of the
+scenes each; G = 4 since round 6, one per hardware queue): the next launch of one group is queued behind its current one while the other
+groups' launches are still running, so the wave slots that the tail of a launch leaves empty are taken by another group's launch.
+Scenes, seeds and results are those of one group.
 
 Prints ONE JSON line on rank 0. value = env-steps/s of the whole job (2 ms physics steps actually executed, summed over all scenes
 and ranks, / max-over-ranks wall time of the K timed rounds); grasp-attempts/s next to it. N > 1: scenes shard over ranks
@@ -439,7 +440,8 @@ def rendered_sub_result(torch, dist, sharding, dev, dev_id, workload, n, rounds,
                            else "stand-alone render + torch rule between the launches (round-5 shape)"), "scene_group_streams_overlap_verified": job.streams_overlap_verified, "env_steps_per_s": steps / dt, "grasp_attempts_per_s": rounds * n / dt,
            "grasp_success_rate": succ / (rounds * n), "env_steps_per_attempt": steps / (rounds * n),
            "newton_iters_per_step": float((c1["solver_iters"] - c0["solver_iters"]).sum()) / max(1, steps),
-           "status_bits": int(np.bitwise_or.reduce(c1["status"] | c1["status_ended"])), "ms_per_round": 1e3 * dt / rounds, "kernel_ms_per_round_and_group": kms / (rounds * job.G),
+           "status_bits": int(np.bitwise_or.reduce(c1["status"] | c1["status_ended"])), "scenes_flagged": int(((c1["status"] | c1["status_ended"]) != 0).sum()),
+           "ms_per_round": 1e3 * dt / rounds, "kernel_ms_per_round_and_group": kms / (rounds * job.G),
            "roofline_frac": steps * 2 * words * 8 / dt / 8e12, "bytes_per_env_step": 2 * words * 8,
            "kernel": "ur5m_run_kernel<248>" if many else "ur5_run_kernel<44>"}
     reward_round0 = torch.cat([gr.reward[0] for gr in job.groups]).cpu().numpy()   # the warm-up round = every scene's FIRST attempt after reset_model: what the CPU leg's piles do
@@ -539,7 +541,7 @@ def strong_scaling_points(torch, dist, sharding, model, dev, dev_id, args):
     for n in (2048, 1024, 512):
         try:
             k = 0 if args.fused_rounds == 0 else default_rounds_per_launch(n)
-            job = Job(torch, dist, sharding, model, "it1", "aimed", n, n, 0, 1, dev, dev_id, args.groups, 20)
+            job = Job(torch, dist, sharding, model, "it1", "aimed", n, n, 0, 1, dev, dev_id, 2, 20)   # two groups: the shards' sweeps (profiles/r06_g_*) were taken so
             job.run_rounds(0, 2, None, k)
             dt, c0, c1, _, _ = job.timed(2, 18, None, k)
             steps = int((c1["total_steps"] - c0["total_steps"]).sum())
@@ -560,7 +562,9 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: 4096 scenes per GPU; strong: 4096 scenes in total, 4096 / N per GPU (SURVEY.md section 8e)")
     ap.add_argument("--rule", choices=("aimed", "uniform"), default="aimed", help="action rule of the timed rounds (see the module docstring)")
-    ap.add_argument("--groups", type=int, default=2, help="scene groups per GPU, one engine handle + HIP stream each, rounds pipelined (1 = one handle)")
+    ap.add_argument("--groups", type=int, default=4, help="scene groups per GPU, one engine handle + HIP stream each, rounds pipelined (1 = one handle). Round 6: 4 -- with launches "
+                    "queued back to back four groups beat two by 1 % on the headline and 2.7 % on the six-object rounds, same box (profiles/r06_ae_scene_groups.log); until the blocking read "
+                    "in front of every launch was found, more groups than two only added such waits (round 5: -20 %). Eight groups share hardware queues: 8.4 M")
     ap.add_argument("--fused-rounds", type=int, default=-1, help="headline workload: K consecutive rounds of a scene per launch, the aiming rule evaluated in the kernel, no lock "
                     "step between scenes (ur5_grasp_rounds_dev; per-scene results bit-identical to K lock-step rounds). 0 = one launch per round, re-aimed on the device by torch; "
                     "default: default_rounds_per_launch() -- 2 at 4096 scenes per GPU and more (the chip is full: short launches, short tails), 8 / 16 for shards of 1024+ / fewer scenes, where a launch's end is the only tail")
@@ -612,7 +616,7 @@ def main():
 
     # six-object rounds: the headline's protocol, 20 timed rounds (round 5: 4 -- two launches per group, of which the region's edge is a quarter: same box 4 rounds 12.2 M, 8 rounds 13.0,
     # 12 rounds 13.3, 20 rounds 13.7 M env-steps/s, profiles/r06_ac_it4_timed_rounds.log)
-    subs = {"it4": lambda cpu: rendered_sub_result(torch, dist, sharding, dev, dev_id, "it4", 4096, 20, 1, cpu, 2, SUB_FUSED["it4"]),
+    subs = {"it4": lambda cpu: rendered_sub_result(torch, dist, sharding, dev, dev_id, "it4", 4096, 20, 1, cpu, 4, SUB_FUSED["it4"]),
             # 6 timed rounds (round 5: 2): a region ends with its last launches draining alone -- about 1 s of a 4.4 s round here -- and two rounds measured that edge more than the rate
             # (same box: 2 rounds 645 k, 4 rounds 680 k; a 512-slot packing model puts 6 rounds at 689 k and the steady state at 720 k: DESIGN.md section 3)
             "many": lambda cpu: rendered_sub_result(torch, dist, sharding, dev, dev_id, "many", 2048, 6, 1, cpu, 2, SUB_FUSED["many"]),   # BASELINE configs[3]: 16384 piles on 8 GPUs = 2048 per GPU
@@ -694,6 +698,7 @@ def main():
             "env_steps_per_attempt": steps_all / attempts,
             "newton_iters_per_step": float((c1["solver_iters"] - c0["solver_iters"]).sum()) / max(1, steps_local),
             "status_bits": int(np.bitwise_or.reduce(c1["status"] | c1["status_ended"])),   # incl. the episodes that ended inside the timed launches
+            "scenes_flagged": int(((c1["status"] | c1["status_ended"]) != 0).sum()),
             "scene_group_streams_overlap_verified": job.streams_overlap_verified,        # the groups' HIP streams sit on different hardware queues: measured (streams.py)
             "config": {"workload": "BASELINE.json configs[1]: IT1 (UR5gripper_2_finger.xml robot + bins, 4 equal 4 cm boxes), physics only, fixed "
                                    "z = 0.91, lift + 500-step closing check; one grasp-attempt round per step, episodes of 4 rounds with reset_model "
