@@ -348,7 +348,7 @@ def test_bench_driver_path_with_two_ranks_on_one_gpu(scaling):
     import subprocess
     bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
     per_gpu = 128 if scaling == "weak" else 2048                              # strong: bench.py's own split of the metric's 4096 scenes (no --envs), weak: a small shard per rank
-    common = ["--steps", "4", "--warmup", "2", "--no-extras", "--no-cpu-baseline", "--scaling", scaling]
+    common = ["--steps", "4", "--warmup", "2", "--no-extras", "--no-cpu-baseline", "--scaling", scaling, "--groups", "2"]   # (two scene groups: the record count below is per group)
 
     def run(args):
         out = subprocess.run([sys.executable, bench] + args + common, capture_output=True, text=True, timeout=600)
