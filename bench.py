@@ -562,9 +562,9 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: 4096 scenes per GPU; strong: 4096 scenes in total, 4096 / N per GPU (SURVEY.md section 8e)")
     ap.add_argument("--rule", choices=("aimed", "uniform"), default="aimed", help="action rule of the timed rounds (see the module docstring)")
-    ap.add_argument("--groups", type=int, default=4, help="scene groups per GPU, one engine handle + HIP stream each, rounds pipelined (1 = one handle). Round 6: 4 -- with launches "
-                    "queued back to back four groups beat two by 1 % on the headline and 2.7 % on the six-object rounds, same box (profiles/r06_ae_scene_groups.log); until the blocking read "
-                    "in front of every launch was found, more groups than two only added such waits (round 5: -20 %). Eight groups share hardware queues: 8.4 M")
+    ap.add_argument("--groups", type=int, default=None, help="(default: 4 at 4096 scenes per GPU and more, 2 below -- shards of 2048 / 1024 / 512 scenes: 14.3 / 7.6 / 4.2 M with four groups against 14.6 / 7.5 / 4.4 M with two) scene groups per GPU, one engine handle + HIP stream each, rounds pipelined (1 = one handle). Round 6: 4 -- with launches "
+                    "queued back to back four groups beat two by 1 %% on the headline and 2.7 %% on the six-object rounds, same box (profiles/r06_ae_scene_groups.log); until the blocking read "
+                    "in front of every launch was found, more groups than two only added such waits (round 5: -20 %%). Eight groups share hardware queues: 8.4 M")
     ap.add_argument("--fused-rounds", type=int, default=-1, help="headline workload: K consecutive rounds of a scene per launch, the aiming rule evaluated in the kernel, no lock "
                     "step between scenes (ur5_grasp_rounds_dev; per-scene results bit-identical to K lock-step rounds). 0 = one launch per round, re-aimed on the device by torch; "
                     "default: default_rounds_per_launch() -- 2 at 4096 scenes per GPU and more (the chip is full: short launches, short tails), 8 / 16 for shards of 1024+ / fewer scenes, where a launch's end is the only tail")
@@ -645,6 +645,8 @@ def main():
     n_local = args.envs if args.envs else (4096 if args.scaling == "weak" else 4096 // world)
     n_total = n_local * world
     lo, hi = sharding.shard_range(n_total, rank, world)
+    if args.groups is None:
+        args.groups = 4 if n_local >= 4096 else 2
     rounds = args.warmup + args.steps
     job = Job(torch, dist, sharding, model, "it1", args.rule, n_local, n_total, lo, world, dev, dev_id, args.groups, rounds + 8)
     groups, G, n_g, run_rounds, timed = job.groups, job.G, job.n_g, job.run_rounds, job.timed
