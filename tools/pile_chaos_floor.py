@@ -25,7 +25,7 @@ VARIANTS = tuple(sys.argv[4].split(",")) if len(sys.argv) > 4 else ("base", "rev
 
 def one(job):
     e, variant = job
-    o = Oracle(m)
+    o = Oracle(m, variant="fmadyn" if variant == "fmadyn" else "")   # round 6: the control twins of tools/pile_divergence_time.py -- the oracle's own text on another arithmetic
     q = D["qpos"][e].copy()
     if variant == "one_ulp":
         q[8] = np.nextafter(q[8], np.inf)                     # x of object 0
@@ -33,6 +33,8 @@ def one(job):
     o.set_ctrl(D["ctrl"][e])
     if variant == "reversed_contacts":
         o.set_contact_order(1)
+    if variant == "rsqrt_cholesky":
+        o.set_cholesky_order(2)
     r, ps, pr = o.grasp_attempt(D["acts"][e], int(D["rots"][e]), 0)
     return int(r), ps.copy(), pr.copy(), o.get_state()["qpos"], o.solver_iters, o.total_steps
 
@@ -63,6 +65,15 @@ gpu = [(int(D["gpu_reward"][e]), D["gpu_phase_steps"][e], D["gpu_phase_result"][
 if VARIANTS == ("base",):
     print(json.dumps(dict(scenes=n, source=os.path.basename(src), oracle_seconds=round(time.time() - t0, 1), threads=threads, gpu_vs_oracle=compare(R["base"], gpu),
                           note="GPU kernel vs the oracle from the kernel's settled states; the floor to compare with is profiles/r04_pile_chaos_floor_256of3072.json")))
+    sys.exit(0)
+if VARIANTS != ("base", "reversed_contacts", "one_ulp"):   # any other list (round 6: base,fmadyn,rsqrt_cholesky): every pair of variants, and the GPU against each
+    out = dict(scenes=n, source=os.path.basename(src), oracle_seconds=round(time.time() - t0, 1), threads=threads, variants=list(VARIANTS))
+    for i, a in enumerate(VARIANTS):
+        for b in VARIANTS[i + 1:]:
+            out["oracle_%s_vs_oracle_%s" % (a, b)] = compare(R[a], R[b])
+        out["gpu_vs_oracle_%s" % a] = compare(R[a], gpu)
+    out["note"] = "all runs start from the HIP kernel's settled state of the same scenes; fmadyn = fused dynamics + strict geometry (the pile unit's arithmetic split), rsqrt_cholesky = pivots by reciprocal square root"
+    print(json.dumps(out))
     sys.exit(0)
 out = dict(scenes=n, source=os.path.basename(src), oracle_seconds=round(time.time() - t0, 1), threads=threads,
            oracle_newton_iters_per_step=float(sum(r[4] for r in R["base"]) / max(1, sum(r[5] for r in R["base"]))),
