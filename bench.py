@@ -617,10 +617,10 @@ def main():
     # six-object rounds: the headline's protocol, 20 timed rounds (round 5: 4 -- two launches per group, of which the region's edge is a quarter: same box 4 rounds 12.2 M, 8 rounds 13.0,
     # 12 rounds 13.3, 20 rounds 13.7 M env-steps/s, profiles/r06_ac_it4_timed_rounds.log)
     subs = {"it4": lambda cpu: rendered_sub_result(torch, dist, sharding, dev, dev_id, "it4", 4096, 20, 1, cpu, 4, SUB_FUSED["it4"]),
-            # 6 timed rounds (round 5: 2): a region ends with its last launches draining alone -- about 1 s of a 4.4 s round here -- and two rounds measured that edge more than the rate
-            # (same box: 2 rounds 645 k, 4 rounds 680 k; a 512-slot packing model puts 6 rounds at 689 k and the steady state at 720 k: DESIGN.md section 3)
-            "many": lambda cpu: rendered_sub_result(torch, dist, sharding, dev, dev_id, "many", 2048, 6, 1, cpu, 2, SUB_FUSED["many"]),   # BASELINE configs[3]: 16384 piles on 8 GPUs = 2048 per GPU
-            "many4096": lambda cpu: rendered_sub_result(torch, dist, sharding, dev, dev_id, "many", 4096, 2, 1, False, 2, SUB_FUSED["many4096"]),   # north_star: "a 4096-env synthetic pile" on one GPU
+            # 10 timed rounds (round 5: 2): a region ends with its last launches draining alone -- about 1 s of a 4.4 s round here -- and two rounds measured that edge more than the rate
+            # (2 rounds 645 k, 4 rounds 680 k, 6 rounds 714-717 k, 20 rounds 742 k; 4096 piles: 2 rounds 694 k, 8 rounds 742 k -- profiles/r06_al_pile_long_regions.log)
+            "many": lambda cpu: rendered_sub_result(torch, dist, sharding, dev, dev_id, "many", 2048, 10, 1, cpu, 2, SUB_FUSED["many"]),   # BASELINE configs[3]: 16384 piles on 8 GPUs = 2048 per GPU
+            "many4096": lambda cpu: rendered_sub_result(torch, dist, sharding, dev, dev_id, "many", 4096, 4, 1, False, 2, SUB_FUSED["many4096"]),   # north_star: "a 4096-env synthetic pile" on one GPU
             # pipelined scene groups (agent.BatchedGraspAgent): +3 % at 512 piles (one pile per CU: the other group's CNN finds LDS), -2 % at 2048 (two piles per CU hold
             # 99.5 % of a CU's LDS: a CNN kernel only gets a CU in the launch's tail, and runs 3.7 x slower there) -- same-box A/B in profiles/r05_g_dqn_ab.log
             "dqn": lambda cpu: dqn_sub_result(torch, dev, dev_id, 512, 2, 1, 2),
@@ -634,7 +634,7 @@ def main():
             return
         if args.sub in ("it4", "many", "many4096") and (args.sub_scenes or args.sub_rounds or args.sub_groups != 2 or args.sub_fused >= 0):
             wl = "it4" if args.sub == "it4" else "many"
-            dflt = {"it4": (4096, 20), "many": (2048, 6), "many4096": (4096, 2)}[args.sub]
+            dflt = {"it4": (4096, 20), "many": (2048, 10), "many4096": (4096, 4)}[args.sub]
             res = rendered_sub_result(torch, dist, sharding, dev, dev_id, wl, args.sub_scenes or dflt[0], args.sub_rounds or dflt[1], 1, False, args.sub_groups,
                                       SUB_FUSED[args.sub] if args.sub_fused < 0 else args.sub_fused)
         else:
